@@ -1,0 +1,41 @@
+"""Shared helpers for the tests (metric of SURVEY.md 8d)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def nmax(a, b):
+    """normalised max error  max|a-b| / max|b|  (the parity metric; element-wise relative
+    error is unusable near zero relevance -- SURVEY.md finding 3)."""
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.asarray(a))
+    return x.to(dtype) if dtype is not None else x
+
+
+def llama_case(name):
+    """-> (cfg, W, ids, fixture) ; weights regenerated from the recorded seed (or carried)."""
+    from oracle import llama as ol
+    fx = load(f"llama_{name}.npz")
+    cfg = {k: (float(v) if k in ("rope_theta", "rms_eps") else int(v))
+           for k, v in zip(fx["cfg_keys"].tolist(), fx["cfg_vals"].tolist())}
+    W = ol.random_weights(cfg, seed=int(fx["wseed"]))
+    tot = float(W["embed"].double().abs().sum() + W["lm_head"].double().abs().sum())
+    for L in W["layers"]:
+        tot += sum(float(v.double().abs().sum()) for v in L.values())
+    assert abs(tot - float(fx["wsum"])) <= 1e-9 * abs(tot), "synthetic weights did not reproduce"
+    if "W_embed" in fx:  # self-contained fixture: the carried weights must equal the regenerated ones
+        assert np.array_equal(fx["W_embed"], W["embed"].numpy())
+    return cfg, W, t(fx["ids"]), fx
