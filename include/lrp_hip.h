@@ -1,0 +1,229 @@
+/*
+ * lrp_hip.h -- C ABI of liblrp_hip.so: MI355X (gfx950) kernels for the AttnLRP hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces an ATen op
+ * sequence that the reference reaches through PyTorch autograd; the reference file:line each
+ * one stands in for is cited per function ("ref:" = /root/reference/...).
+ *
+ * Contract
+ *   - plain pointers + sizes, no torch types.  All buffers are DEVICE pointers owned by the
+ *     caller (borrowed for the launch); the library never allocates or frees.
+ *   - asynchronous on the hipStream_t passed last (void* here so the header needs no HIP).
+ *   - return 0 on success, a negative LRP_E* code on a rejected call (nothing launched).
+ *   - re-entrant and thread-safe: no global mutable state (called from the Python main
+ *     thread in forward and from the autograd worker thread in backward).
+ *   - "gradient form": the propagated quantity is G = R / activation;
+ *     relevance of any activation a is a (*) G_a.  eps == 0 selects lxt.efficient semantics
+ *     (no stabiliser), eps > 0 the lxt.explicit stabiliser z/(c z + eps), UNSIGNED as in
+ *     ref: lxt/explicit/functional.py:266-273.
+ *   - dtype codes: LRP_F32 = 0 (fp32 storage, exact-fp32 MFMA), LRP_BF16 = 1 (bf16 storage,
+ *     fp32 accumulate).  Row statistics (rstd, lse, D) are always fp32.
+ */
+#ifndef LRP_HIP_H
+#define LRP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRP_F32 0
+#define LRP_BF16 1
+
+#define LRP_OK 0
+#define LRP_EINVAL -1   /* bad argument (null pointer, negative size, unknown dtype)   */
+#define LRP_EALIGN -2   /* pointer / leading dimension not aligned as the kernel needs */
+#define LRP_ESHAPE -3   /* shape outside what the kernel supports                      */
+#define LRP_ELAUNCH -4  /* hipLaunch failed; lrp_last_hip_error() has the HIP code     */
+
+#define LRP_ACT_SILU 0
+#define LRP_ACT_GELU_TANH 1
+#define LRP_ACT_GELU 2
+
+/* library identity / sanity */
+int lrp_version(void);                 /* ABI version, currently 1 */
+const char* lrp_build_arch(void);      /* "gfx950" */
+int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
+
+/* ---------------------------------------------------------------------------------------
+ * K1  Linear.   ref: forward  lxt/explicit/functional.py:345-351 (F.linear),
+ *               backward lxt/explicit/functional.py:355-364, lxt/explicit/rules.py:206-222
+ * lrp_gemm_nt: C[b][M,N] = A[b][M,K] . B[b][N,K]^T (+ bias[N]), fp32 accumulate on MFMA.
+ *   Both operands are K-contiguous ("NT"); the engine keeps W ([out,in]) for the forward
+ *   and a W^T copy ([in,out]) for the backward so every contraction is NT.
+ *   lda/ldb/ldc in elements; K, lda, ldb multiples of 16 bytes' worth of elements.
+ *   batch >= 1 with element strides sA/sB/sC (sB may be 0 to share B).
+ *   out_dtype may differ from dtype only as LRP_F32 (fp32 output from bf16 operands).
+ * --------------------------------------------------------------------------------------- */
+int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
+                int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                int batch, int64_t sA, int64_t sB, int64_t sC,
+                int dtype, int out_dtype, void* stream);
+
+/* out = g (*) z/(c z + eps)      (mode 0: gradient form; eps==0 -> g/c)
+ * out = r / (c z + eps)          (mode 1: relevance form, the reference's R_out/(z+eps))
+ * ref: lxt/explicit/functional.py:360 (linear), :403 (matmul, c=2), :445 (add2) */
+int lrp_eps_scale(const void* g, const void* z, void* out, int64_t n, float c, float eps,
+                  int mode, int dtype, void* stream);
+
+/* same, on 2-D strided views [rows, cols] (slices of fused GEMM outputs); row strides in elements */
+int lrp_eps_scale2d(const void* g, const void* z, void* out, int rows, int cols, int64_t ldg,
+                    int64_t ldz, int64_t ldo, float c, float eps, int mode, int dtype, void* stream);
+
+/* out = a (*) b  (R = x (*) G read-out of a rule, ref: functional.py:362 ".mul_(inputs)") */
+int lrp_mul(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
+/* Small-M Linear eps-rule in ONE pass over W (HBM-bound regime, M <= 8):
+ *   z = x W^T + b ; s = g (*) z/(z+eps)  [or r/(z+eps) if relevance_in] ;
+ *   out = s W  [ (*) x if relevance_out ]      out is fp32 [M,K] and must be ZEROED by the caller
+ *   (split-N partial sums are accumulated with atomics).  z_out (optional, fp32 [M,N]).
+ * ref: lxt/explicit/functional.py:345-364 ; BASELINE config 1 (768->768, M=1). */
+int lrp_linear_eps_smallm(const void* x, const void* W, const void* bias, const void* g,
+                          float* out, float* z_out, int M, int N, int K, float eps,
+                          int relevance_in, int relevance_out, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K2/K6  RMSNorm identity rule + residual add.
+ *   ref: lxt/efficient/patches.py:111-123, lxt/explicit/functional.py:481-495 (norm),
+ *        lxt/explicit/functional.py:430-459 via lxt/explicit/models/llama.py:481,488 (add2)
+ * forward:  hsum = h (+ branch) ; y = w' (*) hsum * rstd ; rstd = rsqrt(mean(hsum^2)+eps)
+ *           w' = w + w_offset (Gemma3: 1 + w).  branch/hsum_out may be NULL (no residual).
+ * backward: Gh = Gres + Gx (*) w' * rstd           (identity rule; Gres or Gx may be NULL)
+ *           Gs = Gh (*) hsum/(hsum+eps_add)         (add2 of the residual below; written to Gs_out)
+ *           A  = Gs (*) branch/(branch+eps_lin)     (eps-rule scale for the branch's last Linear)
+ *           rel_out[row] (optional, fp32) = sum_h hsum*Gh  (latent relevance per token)
+ *   branch == NULL means "no residual below" (embedding): Gs_out = Gh, A_out untouched.
+ * --------------------------------------------------------------------------------------- */
+int lrp_add_rmsnorm_fwd(const void* h, const void* branch, const void* w, void* hsum_out,
+                        void* y, float* rstd, int M, int H, float eps, float w_offset,
+                        int dtype, void* stream);
+int lrp_rmsnorm_bwd_add2(const void* Gres, const void* Gx, const void* w, const float* rstd,
+                         const void* hsum, const void* branch, void* Gs_out, void* A_out,
+                         float* rel_out, int M, int H, float w_offset, float eps_add,
+                         float eps_lin, int dtype, void* stream);
+
+/* K7 LayerNorm (BERT/GPT-2/ViT).  ref: lxt/efficient/patches.py:126-142,
+ *   lxt/explicit/functional.py:606-635.   y = (x-mean)/std * w + b ; std detached.
+ *   backward: u = Gy (*) y/(y+eps_y) (*) w * rstd ; Gx = u - mean_row(u). */
+int lrp_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean,
+                      float* rstd, int M, int H, float eps, int dtype, void* stream);
+int lrp_layernorm_bwd(const void* Gy, const void* y, const void* w, const float* rstd,
+                      void* Gx, int M, int H, float eps_y, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3/K8  gated MLP element-wise rules.
+ *   ref: lxt/efficient/patches.py:145-157 (identity rule on act, uniform rule on the product),
+ *        lxt/efficient/rules.py:88-100, lxt/explicit/rules.py:68-78,405-418,
+ *        lxt/explicit/models/llama.py:84-86,273-281
+ * forward : m = act(g) (*) u        (g,u,m [M,I] with row strides ldg/ldu/ldm)
+ * backward: Gact = Gm*u/2 ; Gu = Gm*act/2
+ *           Ag = Gact * act/(g + eps_g)            (identity rule (*) gate Linear eps scale;
+ *                                                   eps_g = 1e-10 efficient / eps_lin explicit)
+ *           Au = Gu * u/(u + eps_lin)              (eps_lin==0 -> Gu)
+ * --------------------------------------------------------------------------------------- */
+int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64_t ldg,
+                      int64_t ldu, int64_t ldm, int act, int dtype, void* stream);
+int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, void* Au,
+                      int M, int I, int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag,
+                      int64_t ldau, float eps_g, float eps_lin, int act, int dtype, void* stream);
+/* stand-alone activation identity rule (BERT/GPT-2 mlp_forward, ref: patches.py:160-168):
+ * forward y = act(x); backward A = Gy * act(x)/(x+eps_g)                                  */
+int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, float eps_g, int act,
+                int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K5  RoPE (rotate-half convention).  ref: HF apply_rotary_pos_emb;
+ *     explicit eps: lxt/explicit/models/llama.py:226-260 (add2 eps=1e-8 on the rotated sum).
+ * x [S, n_heads, d] with row stride ldx (elements); cos/sin fp32 [S, d].
+ * forward : xr = x*cos + rotate_half(x)*sin
+ * backward: Gp = Gr (*) xr/(xr+eps_rope) ; Gx = Gp*cos + rotate_half^T(Gp*sin) ;
+ *           A = Gx (*) x/(x+eps_lin)     (xr / x may be NULL when the matching eps is 0)
+ * pos0: position of row 0; rows are positions pos0 + (row % S_per_seq).
+ * --------------------------------------------------------------------------------------- */
+int lrp_rope_fwd(const void* x, void* xr, const float* cos_t, const float* sin_t, int rows,
+                 int seq, int n_heads, int d, int64_t ldx, int64_t ldxr, int dtype, void* stream);
+int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const float* cos_t,
+                 const float* sin_t, int rows, int seq, int n_heads, int d, int64_t ldg,
+                 int64_t ldxr, int64_t ldx, int64_t lda, float eps_rope, float eps_lin,
+                 int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K4  attention (flash-style, causal or full, GQA, optional sliding window).
+ *   ref: lxt/efficient/patches.py:193-203 (divide_gradient 4,4,2 == the two 1/2 below),
+ *        lxt/explicit/functional.py:293-322 (softmax, Prop 3.1), :385-408 (QK^T, R/(2s+eps)),
+ *        lxt/explicit/rules.py:267-282 (P.V uniform-epsilon), llama.py:379-391.
+ * Layout: q [B*S, Hq, d], k/v [B*S, Hkv, d] token-major with row strides ldq/ldk/ldv
+ * (slices of a fused QKV GEMM output are consumed in place); o [B*S, Hq, d] (ldo);
+ * lse fp32 [B, Hq, S] = log-sum-exp of the scaled scores; d in {16,32,64,128,256}.
+ * "_t" operands are head-transposed copies [B, H, d, ldt] (ldt >= S, multiple of 16 bytes'
+ * worth of elements, pad columns FINITE -- zero them once) made by lrp_transpose_heads: with
+ * 288 GB of HBM the engine keeps both layouts so every MFMA operand is K-contiguous and every
+ * LDS fill is a straight 16-byte copy (no in-kernel transposes).
+ * window <= 0: none; window = w: key j visible to query i iff i-w < j <= i (Gemma3 local).
+ * backward (gradient form):
+ *   Gho = f Go (*) o/(o+eps_pv), f = 1/2          [lrp_attn_bwd_prep, also D = rowsum(Gho*o)]
+ *   dP = Gho V^T ; dV = P^T Gho ; dS3 = P (*) (dP - D)
+ *   Ghs = dS3 * scale * s2/(s2+eps_mask) * s/(2 s+eps_qk)   (eps==0 -> 1/2) ; s2 = s*scale
+ *   dQ = Ghs K ; dK = Ghs^T Q
+ *   dK/dV are produced PER QUERY HEAD ([B*S, Hq, d]) so the grid has Hq-way parallelism and no
+ *   atomics; lrp_gqa_reduce sums the heads of a kv group (ref: HF repeat_kv's autograd sum).
+ * --------------------------------------------------------------------------------------- */
+int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int64_t ldx,
+                        int64_t ldt, int dtype, void* stream);
+int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse,
+                 int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt,
+                 int64_t ldo, float scale, int causal, int window, int dtype, void* stream);
+int lrp_attn_bwd_prep(const void* Go, const void* o, void* Gho, float* D, int B, int S, int Hq,
+                      int d, int64_t ldgo, int64_t ldo, int64_t ldgho, float eps_pv,
+                      float factor, int dtype, void* stream);
+int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t, const void* Gho,
+                    const float* lse, const float* D, void* dq, int B, int S, int Hq, int Hkv,
+                    int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho,
+                    int64_t lddq, float scale, float eps_mask, float eps_qk, int causal,
+                    int window, int dtype, void* stream);
+int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* q_t, const void* Gho,
+                     const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h,
+                     int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
+                     int64_t ldt, int64_t ldgho, int64_t lddk, int64_t lddv, float scale,
+                     float eps_mask, float eps_qk, int causal, int window, int dtype, void* stream);
+/* out[row, hk, :] = sum_{g<rep} in[row, hk*rep+g, :]   (in: Hkv*rep heads, out: Hkv heads) */
+int lrp_gqa_reduce(const void* in, void* out, int64_t rows, int Hkv, int rep, int d, int64_t ld_in,
+                   int64_t ld_out, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * explicit-API row ops on materialised scores (lf.softmax / lf.add2 / lf.matmul users).
+ *   ref: lxt/explicit/functional.py:293-322.  x,p,R [rows, n]; -inf entries of x -> 0.
+ *   lrp_softmax_fwd: p = softmax(x/T) ; lrp_softmax_rule_bwd: Rx = (x/T) (*) (Rp - p * sum(Rp))
+ * --------------------------------------------------------------------------------------- */
+int lrp_softmax_fwd(const void* x, void* p, int64_t rows, int n, float inv_temp, int dtype,
+                    void* stream);
+int lrp_softmax_rule_bwd(const void* x, const void* p, const void* Rp, void* Rx, int64_t rows,
+                         int n, float inv_temp, int dtype, void* stream);
+/* add2 rule: s = R/(a+b+eps) ; Ra = s*a ; Rb = s*b (Rb may be NULL). ref: functional.py:430-459 */
+int lrp_add2_rule_bwd(const void* a, const void* b, const void* R, void* Ra, void* Rb,
+                      int64_t n, float eps, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K9 / harness.  ref: docs/source/quickstart.rst:120-141, examples/paper/llama.py:45-46
+ *   lrp_readout      : R_tok[row] = sum_h emb[row,h]*G[row,h]   (fp32 out)
+ *   lrp_head_seed    : last-token head, one launch per prompt batch:
+ *        Gxn[b,:] = zfac * W_lm[idx[b],:]  with zfac = z/(z+eps_lin), z = logits[b,idx[b]]
+ *        then the final-norm identity rule: Gh_last[b,:] = Gxn (*) w' * rstd[b]
+ *   lrp_argmax_rows  : idx[b] = argmax_v logits[b,:] (fp32 logits), val[b] = max
+ *   lrp_transpose    : out[b][c,r] = in[b][r,c]  (weight W^T copies, operand re-layouts)
+ *   lrp_cast         : dtype conversion fp32 <-> bf16
+ * --------------------------------------------------------------------------------------- */
+int lrp_readout(const void* emb, const void* G, float* R_tok, int M, int H, int dtype, void* stream);
+int lrp_head_seed(const void* W_lm, const float* logits, const int* idx, const void* w_norm,
+                  const float* rstd_last, void* Gh_last, int B, int V, int H, int64_t ld_logits,
+                  float w_offset, float eps_lin, int dtype, void* stream);
+int lrp_argmax_rows(const float* logits, int* idx, float* val, int B, int V, int64_t ld, void* stream);
+int lrp_transpose(const void* in, void* out, int rows, int cols, int64_t ld_in, int64_t ld_out,
+                  int batch, int64_t s_in, int64_t s_out, int dtype, void* stream);
+int lrp_cast(const void* in, void* out, int64_t n, int in_dtype, int out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRP_HIP_H */

@@ -1,0 +1,136 @@
+// common.hpp -- shared device helpers for the gfx950 (CDNA4, wave64) AttnLRP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lrp_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LRP_DEVICE __device__ __forceinline__
+
+extern thread_local int g_lrp_last_hip_error;
+
+static inline int lrp_check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_lrp_last_hip_error = (int)e; return LRP_ELAUNCH; }
+    return LRP_OK;
+}
+
+// ---- scalar conversion --------------------------------------------------------------------
+LRP_DEVICE float to_f32(float x) { return x; }
+LRP_DEVICE float to_f32(bf16_t x) { return (float)x; }
+template <typename T> LRP_DEVICE T from_f32(float x);
+template <> LRP_DEVICE float from_f32<float>(float x) { return x; }
+template <> LRP_DEVICE bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE
+
+// ---- 16-byte vectors of T: 4 floats or 8 bf16 -----------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    LRP_DEVICE float get(int i) const { return v[i]; }
+    LRP_DEVICE void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    LRP_DEVICE float get(int i) const { return (float)v[i]; }
+    LRP_DEVICE void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <typename T> LRP_DEVICE Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> LRP_DEVICE void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+// ---- wave64 reductions ----------------------------------------------------------------------
+LRP_DEVICE float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+LRP_DEVICE float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+// block reduction through LDS; red must hold >= blockDim/64 floats; returns value to all threads
+LRP_DEVICE float block_sum(float x, float* red) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = x;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+LRP_DEVICE float block_max(float x, float* red) {
+    x = wave_max(x);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = x;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---- the eps stabiliser ratio  z/(c z + eps)  (unsigned eps, as the reference) ---------------
+LRP_DEVICE float eps_ratio(float z, float c, float eps) {
+    // eps == 0: lxt.efficient has no stabiliser at all -> exactly 1/c (never 0/0)
+    return (eps == 0.f) ? (1.f / c) : z / (c * z + eps);
+}
+
+LRP_DEVICE float act_apply(float x, int act) {
+    if (act == LRP_ACT_SILU) return x / (1.f + __expf(-x));
+    if (act == LRP_ACT_GELU_TANH) {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
+    }
+    return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+}
+
+// ---- MFMA 16x16 "macro" op, identical byte geometry for both dtypes ---------------------------
+// One macro step contracts a 64-BYTE K chunk: lane l supplies the 16 bytes at K-byte offset
+// (l>>4)*16 of row (l&15) for each operand (8 bf16 / 4 fp32).  bf16: one v_mfma_f32_16x16x32_bf16;
+// fp32: four v_mfma_f32_16x16x4_f32 (element e of the float4 feeds MFMA e, whose k-slot l>>4 is
+// then k = (l>>4)*4+e for BOTH operands, so the pairing is consistent).
+// D layout (both): lane l holds D[i = (l>>4)*4 + r][j = l&15], r = 0..3, where i indexes the rows of
+// the FIRST argument and j the rows of the SECOND.
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    typedef bf16x8 frag;
+    static LRP_DEVICE f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    typedef f32x4 frag;
+    static LRP_DEVICE f32x4 mma(frag a, frag b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// XCD-aware bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
+// consecutive remapped ids land on the same XCD so neighbouring tiles share that XCD's L2.
+LRP_DEVICE int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}

@@ -1,0 +1,242 @@
+"""Whole-model AttnLRP engine for Llama-style decoders: fused forward + LRP backward on the HIP
+kernels, one call per batch of prompts.
+
+This is the hot path named by BASELINE.json: it reproduces the user protocol of the reference
+(docs/source/quickstart.rst:120-141; examples/paper/llama.py:27-46 --  embed ids -> forward ->
+pick max(logits[0,-1]) -> seed the backward -> sum_h emb (*) grad) with the rule placement of
+lxt/efficient/models/llama.py:9-14 (mode="efficient") or of the explicit composite
+lxt/explicit/models/llama.py:83-93,226-260,273-281,379-391,481-488 (mode="explicit").
+
+MI355X-first decisions:
+  * everything an eps-rule needs (every Linear output z, pre/post-RoPE q/k, attention o + lse,
+    residual sums) is STASHED in HBM during the forward (~0.3 GB/layer at S=2048 bf16; 288 GB
+    available) -- the backward never recomputes a GEMM, it runs one dgrad GEMM per Linear;
+  * every weight is kept twice, W [out,in] for the forward and W^T [in,out] for the backward, and
+    QKV / gate+up are fused along N, so every contraction is an NT GEMM with K-contiguous operands;
+  * q/k/v/Gho are also kept head-transposed for the attention kernels (attention.hip);
+  * only the last token's logits are formed (the explained logit lives there), and the LM head
+    + final norm backward is a single row per prompt.
+Python only sequences kernel launches on the current stream; it performs no arithmetic.
+"""
+import torch
+
+from . import ops
+
+EXPLICIT = dict(lin=1e-8, add=1e-8, qk=1e-8, mask=1e-8, pv=1e-6, rope=1e-8, act=None)
+EFFICIENT = dict(lin=0.0, add=0.0, qk=0.0, mask=0.0, pv=0.0, rope=0.0, act=1e-10)
+
+
+def config_from_hf(hf_cfg):
+    hd = getattr(hf_cfg, "head_dim", None) or hf_cfg.hidden_size // hf_cfg.num_attention_heads
+    theta = None
+    rp = getattr(hf_cfg, "rope_parameters", None)
+    if isinstance(rp, dict):
+        theta = rp.get("rope_theta")
+    if theta is None:
+        theta = getattr(hf_cfg, "rope_theta", 10000.0)
+    return dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size, n_layers=hf_cfg.num_hidden_layers,
+                n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hd,
+                vocab=hf_cfg.vocab_size, rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps),
+                act=getattr(hf_cfg, "hidden_act", "silu"))
+
+
+def weights_from_hf(model):
+    """plain (cfg, W) view of a HF LlamaForCausalLM (no copies; tensors stay where they are)"""
+    m = model.model
+    W = dict(embed=m.embed_tokens.weight.detach(), norm=m.norm.weight.detach(), lm_head=model.lm_head.weight.detach(),
+             layers=[])
+    for L in m.layers:
+        a, mlp = L.self_attn, L.mlp
+        W["layers"].append(dict(ln1=L.input_layernorm.weight.detach(), ln2=L.post_attention_layernorm.weight.detach(),
+                                wq=a.q_proj.weight.detach(), wk=a.k_proj.weight.detach(), wv=a.v_proj.weight.detach(),
+                                wo=a.o_proj.weight.detach(), wg=mlp.gate_proj.weight.detach(),
+                                wu=mlp.up_proj.weight.detach(), wd=mlp.down_proj.weight.detach()))
+    return config_from_hf(model.config), W
+
+
+class LlamaLRP:
+    """Device-resident weights (both layouts) + explain()."""
+
+    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096):
+        if not torch.cuda.is_available():
+            raise RuntimeError("LlamaLRP needs a HIP device: the LRP kernels have no CPU fallback")
+        self.cfg, self.dtype, self.device = dict(cfg), dtype, torch.device(device)
+        self.set_mode(mode)
+        self.act = cfg.get("act", "silu")
+        dev = self.device
+
+        def put(t):
+            return t.to(device=dev, dtype=dtype).contiguous()
+
+        self.embed, self.norm, self.lm_head = put(W["embed"]), put(W["norm"]), put(W["lm_head"])
+        self.layers = []
+        for L in W["layers"]:
+            wqkv = torch.cat([put(L["wq"]), put(L["wk"]), put(L["wv"])], dim=0)
+            wgu = torch.cat([put(L["wg"]), put(L["wu"])], dim=0)
+            wo, wd = put(L["wo"]), put(L["wd"])
+            self.layers.append(dict(ln1=put(L["ln1"]), ln2=put(L["ln2"]), wqkv=wqkv, wqkv_t=ops.transpose(wqkv), wo=wo,
+                                    wo_t=ops.transpose(wo), wgu=wgu, wgu_t=ops.transpose(wgu), wd=wd, wd_t=ops.transpose(wd)))
+        d = cfg["head_dim"]
+        inv = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        fr = torch.arange(max_seq, dtype=torch.float32)[:, None] * inv[None, :]
+        emb = torch.cat((fr, fr), dim=-1)
+        # HF hands cos/sin to the layers in the model dtype; keep that rounding, store as fp32 tables
+        self.cos = emb.cos().to(dtype).to(torch.float32).to(dev).contiguous()
+        self.sin = emb.sin().to(dtype).to(torch.float32).to(dev).contiguous()
+        self.max_seq = max_seq
+        torch.cuda.synchronize(dev)
+
+    @classmethod
+    def from_hf(cls, model, **kw):
+        cfg, W = weights_from_hf(model)
+        kw.setdefault("dtype", next(model.parameters()).dtype)
+        return cls(cfg, W, **kw)
+
+    def set_mode(self, mode):
+        if mode not in ("explicit", "efficient"):
+            raise ValueError(f"mode must be 'explicit' or 'efficient', got {mode!r}")
+        self.mode = mode
+        self.eps = dict(EXPLICIT if mode == "explicit" else EFFICIENT)
+        # identity rule (*) gate Linear eps: act/(g+eps_lin) in explicit form, act/(g+1e-10) efficient
+        self.eps_g = self.eps["lin"] if mode == "explicit" else self.eps["act"]
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, emb, B, S):
+        c, E = self.cfg, self.eps
+        H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
+        M = B * S
+        dev, dt = self.device, self.dtype
+        nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
+        scale = d ** -0.5
+        new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        stash = []
+        h_prev, branch = emb, None
+        for Lw in self.layers:
+            st = {}
+            if branch is None:
+                st["h"] = h_prev
+                x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"])
+            else:
+                st["h"] = new(M, H)
+                x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"])
+            qkv = ops.gemm_nt_2d(x, Lw["wqkv"], new(M, nqkv))
+            qkr = ops.rope_fwd(qkv, new(M, nqk), self.cos, self.sin, S, nq + nk, d)
+            v = qkv[:, nqk:]
+            v_t = ops.transpose_heads(v, B, S, nk, d)
+            o = new(M, nq * d)
+            lse = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+            ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0)
+            a = ops.gemm_nt_2d(o, Lw["wo"], new(M, H))
+            h1 = new(M, H)
+            x2, st["rstd2"] = ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1)
+            gu = ops.gemm_nt_2d(x2, Lw["wgu"], new(M, 2 * I))
+            m = ops.gated_act_fwd(gu[:, :I], gu[:, I:], new(M, I), self.act)
+            dn = ops.gemm_nt_2d(m, Lw["wd"], new(M, H))
+            st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
+            stash.append(st)
+            h_prev, branch = h1, dn
+        # last token only: final residual add + norm + LM head
+        last = torch.arange(B, device=dev) * S + (S - 1)
+        h1_last, dn_last = h_prev.index_select(0, last), branch.index_select(0, last)
+        hL_last = new(B, H)
+        xn, rstd_f = ops.add_rmsnorm_fwd(h1_last, dn_last, self.norm, c["rms_eps"], hsum_out=hL_last)
+        logits = ops.gemm_nt_2d(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
+        return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits)
+
+    # ---------------------------------------------------------------------------------------------
+    def backward(self, fw, emb, idx, B, S, layer_relevance=False):
+        c, E = self.cfg, self.eps
+        H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
+        M, rep = B * S, nq // nk
+        dev, dt = self.device, self.dtype
+        nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
+        scale = d ** -0.5
+        new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        # LM head eps rule + final-norm identity rule on the single explained row of each prompt
+        Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
+        # add2 at h_L = h1 + dn and the eps scale of the last down_proj, still one row per prompt
+        Gs_last, A_last = new(B, H), new(B, H)
+        rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
+        ops.rmsnorm_bwd_add2(Gh_last, None, None, None, fw["hL_last"], fw["dn_last"], Gs_last, A_last, rel_last,
+                             0.0, E["add"], E["lin"])
+        Gs = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, fw["last"], Gs_last)
+        Adn = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, fw["last"], A_last)
+        layer_R = [rel_last] if layer_relevance else None
+
+        for li in range(len(self.layers) - 1, -1, -1):
+            Lw, st = self.layers[li], fw["stash"][li]
+            gu, qkv, qkr = st["gu"], st["qkv"], st["qkr"]
+            # ---- MLP
+            Gm = ops.gemm_nt_2d(Adn, Lw["wd_t"], new(M, I))
+            Agu = new(M, 2 * I)
+            ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
+            Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(M, H))
+            Gs1, Aa = new(M, H), new(M, H)
+            ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
+            # ---- attention
+            Gof = ops.gemm_nt_2d(Aa, Lw["wo_t"], new(M, nq * d))
+            Gho = new(M, nq * d)
+            D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+            ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
+            q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
+            k_t = ops.transpose_heads(k, B, S, nk, d)
+            q_t = ops.transpose_heads(q, B, S, nq, d)
+            Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
+            dqk = new(M, nqk)
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"])
+            dk_h, dv_h = new(M, nq * d), new(M, nq * d)
+            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"])
+            ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
+            Aqkv = new(M, nqkv)
+            if E["lin"] == 0.0:
+                ops.gqa_reduce(dv_h, Aqkv[:, nqk:], M, nk, rep, d)
+                ops.rope_bwd(dqk, None, None, Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, 0.0, 0.0)
+            else:
+                dv = ops.gqa_reduce(dv_h, new(M, nk * d), M, nk, rep, d)
+                ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
+                ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
+            Gx = ops.gemm_nt_2d(Aqkv, Lw["wqkv_t"], new(M, H))
+            # ---- input norm + the residual add below (or the embedding)
+            rel = torch.empty(M, device=dev, dtype=torch.float32) if layer_relevance else None
+            if li > 0:
+                prev = fw["stash"][li - 1]
+                Gs, Adn = new(M, H), new(M, H)
+                ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"], prev["dn"], Gs, Adn, rel, 0.0, E["add"], E["lin"])
+            else:
+                Gs = new(M, H)
+                ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"] if layer_relevance else None, None, Gs, None,
+                                     rel, 0.0, 0.0, 0.0)
+            if layer_relevance:
+                layer_R.append(rel)
+        return Gs, layer_R
+
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False):
+        """input_ids [B,S] (or inputs_embeds [B,S,H]); target: None (arg-max of the last position) or
+        int tensor [B].  Returns dict(idx [B], logit [B], R_tok [B,S] fp32, and optionally
+        layer_R [L+1, B] (sum_h h (*) G_h at every residual-stream boundary) and G_emb [B,S,H])."""
+        if inputs_embeds is None:
+            input_ids = input_ids.to(self.device)
+            B, S = input_ids.shape
+            emb = self.embed.index_select(0, input_ids.reshape(-1))
+        else:
+            B, S = inputs_embeds.shape[:2]
+            emb = inputs_embeds.to(device=self.device, dtype=self.dtype).reshape(B * S, -1).contiguous()
+        if S > self.max_seq:
+            raise ValueError(f"sequence length {S} exceeds max_seq={self.max_seq}")
+        fw = self.forward(emb, B, S)
+        if target is None:
+            idx, _ = ops.argmax_rows(fw["logits"])
+        else:
+            idx = torch.as_tensor(target, device=self.device).to(torch.int32).reshape(B).contiguous()
+        G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance)
+        R_tok = ops.readout(emb, G).view(B, S)
+        out = dict(idx=idx, logit=fw["logits"].gather(1, idx.long()[:, None])[:, 0], R_tok=R_tok, logits=fw["logits"])
+        if layer_relevance:
+            rows = [layer_R[0]] + [r.view(B, S).sum(1) for r in layer_R[1:]]
+            out["layer_R"] = torch.stack(rows[::-1], 0)          # [L+1, B], index 0 = embedding
+        if return_G:
+            out["G_emb"] = G.view(B, S, -1)
+            out["emb"] = emb.view(B, S, -1)
+        return out

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (include/lrp_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the current HIP stream;
+every computation below is a call into liblrp_hip.so with raw device pointers.  CPU tensors are
+rejected -- there is no fallback.
+"""
+import torch
+
+from ._lib import lib, check, F32, BF16, ACT
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"lrp_hip supports float32 and bfloat16 tensors, got {t.dtype}") from None
+
+
+def p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("lrp_hip kernels need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def epc(t):
+    return 16 // t.element_size()
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, bias=None, out=None, out_dtype=None):
+    """out[..., M, N] = a[..., M, K] @ b[..., N, K]^T (+bias).  a/b: last dim contiguous, 2-D or
+    batched 3-D with a uniform batch stride; b may be 2-D (shared).  K is zero-padded to a multiple
+    of 16 bytes if needed."""
+    assert a.dtype == b.dtype
+    K = a.shape[-1]
+    assert b.shape[-1] == K
+    e = epc(a)
+    if K % e:
+        pad = e - K % e
+        a = torch.nn.functional.pad(a, (0, pad))
+        b = torch.nn.functional.pad(b, (0, pad))
+        K += pad
+    lead = a.shape[:-2]
+    M, N = a.shape[-2], b.shape[-2]
+    a3 = a.reshape(-1, M, K)
+    batch = a3.shape[0]
+    if a3.stride(-1) != 1 or a3.stride(-2) % e or (batch > 1 and a3.stride(0) % e) or a3.data_ptr() % 16:
+        a3 = a3.contiguous()
+    if b.dim() == 2:
+        b3, sB = b, 0
+        if b3.stride(-1) != 1 or b3.stride(-2) % e or b3.data_ptr() % 16:
+            b3 = b3.contiguous()
+        ldb = b3.stride(0)
+    else:
+        b3 = b.reshape(-1, N, K)
+        assert b3.shape[0] == batch
+        if b3.stride(-1) != 1 or b3.stride(-2) % e or (batch > 1 and b3.stride(0) % e) or b3.data_ptr() % 16:
+            b3 = b3.contiguous()
+        sB, ldb = (b3.stride(0) if batch > 1 else 0), b3.stride(1)
+    odt = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty(*lead, M, N, device=a.device, dtype=odt)
+    o3 = out.view(-1, M, N)
+    assert o3.stride(-1) == 1
+    rc = lib.lrp_gemm_nt(p(a3), p(b3), p(o3), p(bias), M, N, K, a3.stride(1), ldb, o3.stride(1), batch,
+                         a3.stride(0) if batch > 1 else 0, sB, o3.stride(0) if batch > 1 else 0,
+                         dt(a), _DT[odt], stream())
+    check(rc, "lrp_gemm_nt")
+    return out
+
+
+def gemm_nt_2d(a, b, out, bias=None):
+    """strict 2-D fast path used by the engine: no reshapes, no copies; row strides may exceed K."""
+    M, K = a.shape
+    N = b.shape[0]
+    rc = lib.lrp_gemm_nt(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(bias), M, N, K, a.stride(0), b.stride(0),
+                         out.stride(0), 1, 0, 0, 0, dt(a), _DT[out.dtype], stream())
+    check(rc, "lrp_gemm_nt")
+    return out
+
+
+def transpose(x, out=None):
+    """[..., R, C] -> [..., C, R] (contiguous)"""
+    x = _c(x)
+    R, C = x.shape[-2], x.shape[-1]
+    lead = x.shape[:-2]
+    if out is None:
+        out = torch.empty(*lead, C, R, device=x.device, dtype=x.dtype)
+    batch = x.numel() // (R * C) if R * C else 1
+    rc = lib.lrp_transpose(p(x), p(out), R, C, C, R, batch, R * C, R * C, dt(x), stream())
+    check(rc, "lrp_transpose")
+    return out
+
+
+def cast(x, dtype):
+    x = _c(x)
+    out = torch.empty_like(x, dtype=dtype)
+    check(lib.lrp_cast(p(x), p(out), x.numel(), dt(x), _DT[dtype], stream()), "lrp_cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------- element-wise
+def eps_scale(g, z, c=1.0, eps=1e-8, relevance=False, out=None):
+    g, z = _c(g), _c(z)
+    out = torch.empty_like(g) if out is None else out
+    check(lib.lrp_eps_scale(p(g), p(z), p(out), g.numel(), c, eps, 1 if relevance else 0, dt(g), stream()), "lrp_eps_scale")
+    return out
+
+
+def eps_scale2d(g, z, out, c=1.0, eps=1e-8, relevance=False):
+    rows, cols = g.shape
+    check(lib.lrp_eps_scale2d(p(g), p(z), p(out), rows, cols, g.stride(0), z.stride(0), out.stride(0), c, eps,
+                              1 if relevance else 0, dt(g), stream()), "lrp_eps_scale2d")
+    return out
+
+
+def mul(a, b, out=None):
+    a, b = _c(a), _c(b)
+    out = torch.empty_like(a) if out is None else out
+    check(lib.lrp_mul(p(a), p(b), p(out), a.numel(), dt(a), stream()), "lrp_mul")
+    return out
+
+
+def add2_rule_bwd(a, b, R, eps=1e-8, need_b=True):
+    a, b, R = _c(a), _c(b), _c(R)
+    Ra = torch.empty_like(a)
+    Rb = torch.empty_like(b) if need_b else None
+    check(lib.lrp_add2_rule_bwd(p(a), p(b), p(R), p(Ra), p(Rb), a.numel(), eps, dt(a), stream()), "lrp_add2_rule_bwd")
+    return Ra, Rb
+
+
+def act_fwd(x, act="silu"):
+    x = _c(x)
+    y = torch.empty_like(x)
+    check(lib.lrp_act_fwd(p(x), p(y), x.numel(), ACT[act], dt(x), stream()), "lrp_act_fwd")
+    return y
+
+
+def act_bwd(Gy, x, act="silu", eps_g=1e-10):
+    Gy, x = _c(Gy), _c(x)
+    Gx = torch.empty_like(x)
+    check(lib.lrp_act_bwd(p(Gy), p(x), p(Gx), x.numel(), eps_g, ACT[act], dt(x), stream()), "lrp_act_bwd")
+    return Gx
+
+
+def gated_act_fwd(g, u, out=None, act="silu"):
+    M, I = g.shape
+    out = torch.empty(M, I, device=g.device, dtype=g.dtype) if out is None else out
+    check(lib.lrp_gated_act_fwd(p(g), p(u), p(out), M, I, g.stride(0), u.stride(0), out.stride(0), ACT[act], dt(g), stream()),
+          "lrp_gated_act_fwd")
+    return out
+
+
+def gated_act_bwd(Gm, g, u, Ag, Au, eps_g, eps_lin, act="silu"):
+    M, I = g.shape
+    check(lib.lrp_gated_act_bwd(p(Gm), p(g), p(u), p(Ag), p(Au), M, I, Gm.stride(0), g.stride(0), u.stride(0), Ag.stride(0),
+                                Au.stride(0), eps_g, eps_lin, ACT[act], dt(g), stream()), "lrp_gated_act_bwd")
+    return Ag, Au
+
+
+def rope_fwd(x, out, cos, sin, seq, n_heads, d):
+    """x/out: [rows, >= n_heads*d] 2-D views (row stride = stride(0)); cos/sin fp32 [seq, d]"""
+    rows = x.shape[0]
+    check(lib.lrp_rope_fwd(p(x), p(out), p(cos), p(sin), rows, seq, n_heads, d, x.stride(0), out.stride(0), dt(x), stream()),
+          "lrp_rope_fwd")
+    return out
+
+
+def rope_bwd(Gr, xr, x, A, cos, sin, seq, n_heads, d, eps_rope, eps_lin):
+    rows = Gr.shape[0]
+    check(lib.lrp_rope_bwd(p(Gr), p(xr), p(x), p(A), p(cos), p(sin), rows, seq, n_heads, d, Gr.stride(0),
+                           xr.stride(0) if xr is not None else 0, x.stride(0) if x is not None else 0, A.stride(0),
+                           eps_rope, eps_lin, dt(Gr), stream()), "lrp_rope_bwd")
+    return A
+
+
+# ---------------------------------------------------------------------------------------- row ops
+def add_rmsnorm_fwd(h, branch, w, eps, w_offset=0.0, hsum_out=None, y=None, rstd=None):
+    M, H = h.shape
+    y = torch.empty_like(h) if y is None else y
+    rstd = torch.empty(M, device=h.device, dtype=torch.float32) if rstd is None else rstd
+    check(lib.lrp_add_rmsnorm_fwd(p(h), p(branch), p(w), p(hsum_out), p(y), p(rstd), M, H, eps, w_offset, dt(h), stream()),
+          "lrp_add_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd_add2(Gres, Gx, w, rstd, hsum, branch, Gs_out, A_out, rel_out=None, w_offset=0.0, eps_add=0.0, eps_lin=0.0):
+    M, H = (Gx if Gx is not None else Gres).shape
+    check(lib.lrp_rmsnorm_bwd_add2(p(Gres), p(Gx), p(w), p(rstd), p(hsum), p(branch), p(Gs_out), p(A_out), p(rel_out), M, H,
+                                   w_offset, eps_add, eps_lin, dt(Gs_out), stream()), "lrp_rmsnorm_bwd_add2")
+    return Gs_out, A_out
+
+
+def layernorm_fwd(x, w, b, eps):
+    x = _c(x)
+    H = x.shape[-1]
+    M = x.numel() // H
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(lib.lrp_layernorm_fwd(p(x), p(w), p(b), p(y), p(mean), p(rstd), M, H, eps, dt(x), stream()), "lrp_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(Gy, y, w, rstd, eps_y=0.0):
+    Gy = _c(Gy)
+    H = Gy.shape[-1]
+    M = Gy.numel() // H
+    Gx = torch.empty_like(Gy)
+    check(lib.lrp_layernorm_bwd(p(Gy), p(y), p(w), p(rstd), p(Gx), M, H, eps_y, dt(Gy), stream()), "lrp_layernorm_bwd")
+    return Gx
+
+
+def softmax_fwd(x, inv_temp=1.0):
+    x = _c(x)
+    n = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.lrp_softmax_fwd(p(x), p(out), x.numel() // n, n, inv_temp, dt(x), stream()), "lrp_softmax_fwd")
+    return out
+
+
+def softmax_rule_bwd(x, pr, Rp, inv_temp=1.0):
+    x, pr, Rp = _c(x), _c(pr), _c(Rp)
+    n = x.shape[-1]
+    Rx = torch.empty_like(x)
+    check(lib.lrp_softmax_rule_bwd(p(x), p(pr), p(Rp), p(Rx), x.numel() // n, n, inv_temp, dt(x), stream()),
+          "lrp_softmax_rule_bwd")
+    return Rx
+
+
+def readout(emb, G):
+    M, H = emb.shape
+    out = torch.empty(M, device=emb.device, dtype=torch.float32)
+    check(lib.lrp_readout(p(emb), p(G), p(out), M, H, dt(emb), stream()), "lrp_readout")
+    return out
+
+
+def argmax_rows(logits):
+    B, V = logits.shape
+    idx = torch.empty(B, device=logits.device, dtype=torch.int32)
+    val = torch.empty(B, device=logits.device, dtype=torch.float32)
+    check(lib.lrp_argmax_rows(p(logits), p(idx), p(val), B, V, logits.stride(0), stream()), "lrp_argmax_rows")
+    return idx, val
+
+
+def head_seed(W_lm, logits, idx, w_norm, rstd_last, out, w_offset=0.0, eps_lin=0.0):
+    B, V = logits.shape
+    H = W_lm.shape[1]
+    check(lib.lrp_head_seed(p(W_lm), p(logits), p(idx), p(w_norm), p(rstd_last), p(out), B, V, H, logits.stride(0), w_offset,
+                            eps_lin, dt(W_lm), stream()), "lrp_head_seed")
+    return out
+
+
+def linear_eps_smallm(x, W, bias, g, eps, relevance_in=False, relevance_out=True, want_z=False):
+    """one-pass Linear eps rule for M <= 4 rows; returns fp32 [M,K] (and z fp32 [M,N])"""
+    M, K = x.shape
+    N = W.shape[0]
+    out = torch.zeros(M, K, device=x.device, dtype=torch.float32)
+    z = torch.empty(M, N, device=x.device, dtype=torch.float32) if want_z else None
+    check(lib.lrp_linear_eps_smallm(p(_c(x)), p(_c(W)), p(bias), p(_c(g)), p(out), p(z), M, N, K, eps, int(relevance_in),
+                                    int(relevance_out), dt(x), stream()), "lrp_linear_eps_smallm")
+    return (out, z) if want_z else out
+
+
+# -------------------------------------------------------------------------------------- attention
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def transpose_heads(x, B, S, H, d, out=None):
+    """x: [B*S, >= H*d] 2-D view -> [B, H, d, ldt] with ldt = S padded to 64 (pad columns zero)"""
+    ldt = pad_to(S, 64)
+    if out is None:
+        out = torch.zeros(B, H, d, ldt, device=x.device, dtype=x.dtype)
+    check(lib.lrp_transpose_heads(p(x), p(out), B, S, H, d, x.stride(0), out.stride(2), dt(x), stream()), "lrp_transpose_heads")
+    return out
+
+
+def attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0):
+    check(lib.lrp_attn_fwd(p(q), p(k), p(v_t), p(o), p(lse), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v_t.stride(2),
+                           o.stride(0), scale, int(causal), window, dt(q), stream()), "lrp_attn_fwd")
+    return o, lse
+
+
+def attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, eps_pv, factor=0.5):
+    check(lib.lrp_attn_bwd_prep(p(Go), p(o), p(Gho), p(D), B, S, Hq, d, Go.stride(0), o.stride(0), Gho.stride(0), eps_pv,
+                                factor, dt(Go), stream()), "lrp_attn_bwd_prep")
+    return Gho, D
+
+
+def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True, window=0):
+    check(lib.lrp_attn_bwd_dq(p(q), p(k), p(v), p(k_t), p(Gho), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0),
+                              k.stride(0), v.stride(0), k_t.stride(2), Gho.stride(0), dq.stride(0), scale, eps_mask, eps_qk,
+                              int(causal), window, dt(q), stream()), "lrp_attn_bwd_dq")
+    return dq
+
+
+def attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True,
+                 window=0):
+    check(lib.lrp_attn_bwd_dkv(p(q), p(k), p(v), p(q_t), p(Gho), p(Gho_t), p(lse), p(D), p(dk_h), p(dv_h), B, S, Hq, Hkv, d,
+                               q.stride(0), k.stride(0), v.stride(0), q_t.stride(2), Gho.stride(0), dk_h.stride(0),
+                               dv_h.stride(0), scale, eps_mask, eps_qk, int(causal), window, dt(q), stream()),
+          "lrp_attn_bwd_dkv")
+    return dk_h, dv_h
+
+
+def gqa_reduce(x, out, rows, Hkv, rep, d):
+    check(lib.lrp_gqa_reduce(p(x), p(out), rows, Hkv, rep, d, x.stride(0), out.stride(0), dt(x), stream()), "lrp_gqa_reduce")
+    return out

@@ -1,0 +1,79 @@
+"""GPU parity of the whole-model engine (lxt_amd.engine.LlamaLRP) against
+  (1) the oracle run live on the host CPU (fp32 and fp64), and
+  (2) the golden fixtures captured from the real reference (tests/golden/llama_*.npz):
+      lxt.explicit (hand-composed from the reference's Functions) and lxt.efficient.
+Metric: normalised max error max|dR|/max|R| over per-token (and per-neuron) relevance
+(SURVEY.md 8d).  Bars: fp32 engine <= 1e-4 (north-star tolerance); bf16 engine <= 5e-2."""
+import pytest
+import torch
+
+from oracle import llama as ol
+from tests.util import nmax, llama_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.engine as e
+    return e
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid", "d128"])
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_llama_fp32_vs_reference_and_oracle(eng_mod, name, mode):
+    cfg, W, ids, fx = llama_case(name)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512)
+    out = eng.explain(ids[None], layer_relevance=True, return_G=True)
+    assert int(out["idx"][0]) == int(fx["idx"])
+    ref_key = "exp64_R_tok" if mode == "explicit" else "eff_R_tok"
+    assert abs(float(out["logit"][0]) - float(fx["logit"])) < 1e-4
+    e_tok = nmax(out["R_tok"][0], fx[ref_key])
+    o64 = ol.explain(cfg, W, ids=ids, target=int(fx["idx"]), mode=mode, dtype=torch.float64)
+    e_or = nmax(out["R_tok"][0], o64["R_tok"])
+    e_neu = nmax((out["emb"][0].double() * out["G_emb"][0].double()), o64["R_emb"])
+    e_lay = nmax(out["layer_R"][:, 0], o64["layer_R"])
+    print(f"[{name}/{mode}] tok vs reference {e_tok:.2e} | tok vs oracle64 {e_or:.2e} | neuron {e_neu:.2e} | layer {e_lay:.2e}"
+          f" | reference's own fp32-fp64 gap {float(fx['cond_gap']):.1e}")
+    assert e_tok < 1e-4 and e_or < 1e-4 and e_neu < 1e-4 and e_lay < 1e-4
+
+
+def test_llama_batch_equals_single(eng_mod):
+    """prompts of a batch are independent: batched result == per-prompt result, bit for bit"""
+    cfg, W, ids, fx = llama_case("mid")
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="explicit", max_seq=512)
+    g = torch.Generator().manual_seed(5)
+    ids2 = torch.stack([ids, torch.randint(0, cfg["vocab"], ids.shape, generator=g)])
+    both = eng.explain(ids2)
+    for b in range(2):
+        one = eng.explain(ids2[b:b + 1])
+        assert torch.equal(one["R_tok"][0], both["R_tok"][b]) and int(one["idx"][0]) == int(both["idx"][b])
+
+
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_llama_bf16(eng_mod, mode):
+    cfg, W, ids, fx = llama_case("d128")
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode=mode, max_seq=512)
+    out = eng.explain(ids[None], target=torch.tensor([int(fx["idx"])]))
+    # bf16 reference: the oracle on the bf16-rounded weights, fp64 arithmetic
+    Wb = ol.cast_weights(ol.cast_weights(W, torch.bfloat16), torch.float32)
+    o64 = ol.explain(cfg, Wb, ids=ids, target=int(fx["idx"]), mode="efficient", dtype=torch.float64)
+    e = nmax(out["R_tok"][0], o64["R_tok"])
+    print(f"[bf16/{mode}] tok vs fp64 oracle on bf16 weights {e:.2e}")
+    assert torch.isfinite(out["R_tok"]).all() and e < 5e-2
+
+
+def test_conservation_large(eng_mod):
+    """size-independent property at a larger shape (no oracle needed): without biases the
+    efficient rules conserve relevance up to what RMSNorm/softmax absorb; the sum of token
+    relevance equals the latent relevance entering the embedding and stays O(logit)."""
+    cfg = dict(hidden=1024, inter=2048, n_layers=2, n_heads=8, n_kv=2, head_dim=128, vocab=1024, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=7)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=1024)
+    ids = torch.randint(0, 1024, (2, 1024), generator=torch.Generator().manual_seed(3))
+    out = eng.explain(ids, layer_relevance=True)
+    assert torch.isfinite(out["R_tok"]).all()
+    assert nmax(out["R_tok"].sum(1), out["layer_R"][0]) < 1e-4
+    assert (out["R_tok"].sum(1).abs() < 10 * out["logit"].abs() + 1).all()

@@ -1,0 +1,350 @@
+"""GPU parity of each HIP kernel (through the C ABI) against the oracle's closed forms /
+a plain PyTorch fp64 restatement of the same op, on seeded inputs.  fp32 kernels: normalised
+max error <= 2e-5 (fp32 MFMA is an exact fma chain; the slack is accumulation order);
+bf16 kernels: <= 2e-2 (bf16 storage rounding of inputs/outputs)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import nmax, load, t
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.ops as o
+    return o
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def f64(x):
+    return x.double()
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (128, 128, 64), (200, 136, 264), (257, 129, 72), (2048, 512, 1024), (64, 1000, 4096)])
+def test_gemm_nt(ops, dtype, M, N, K):
+    a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias = rnd(N, dtype=dtype, seed=3)
+    out = ops.gemm_nt(a, b, bias)
+    ref = f64(a) @ f64(b).T + f64(bias)
+    assert out.shape == (M, N) and nmax(out, ref) < TOL[dtype]
+    # transpose detection: asymmetric operands, A = shifted identity
+    if M == N == 128:
+        eye = torch.zeros(M, K, dtype=dtype, device="cuda")
+        eye[torch.arange(K), torch.arange(K)] = 1
+        out = ops.gemm_nt(eye, b)
+        assert nmax(out[:K], f64(b).T[:K]) < TOL[dtype]
+
+
+def test_gemm_batched_and_f32_out(ops):
+    a, b = rnd(3, 70, 96, seed=4), rnd(3, 50, 96, seed=5)
+    assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).transpose(1, 2)) < 2e-5
+    a16, b16 = a.bfloat16(), b[0].bfloat16()
+    out = ops.gemm_nt(a16, b16, out_dtype=torch.float32)
+    assert out.dtype == torch.float32 and nmax(out, f64(a16) @ f64(b16).T) < 1e-5
+    # ragged K (padding path of the wrapper)
+    a, b = rnd(16, 10, seed=6), rnd(5, 10, seed=7)
+    assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).T) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_cast(ops, dtype):
+    x = rnd(3, 70, 130, dtype=dtype)
+    assert torch.equal(ops.transpose(x), x.transpose(1, 2).contiguous())
+    y = rnd(1000, 33)
+    assert torch.equal(ops.cast(y, torch.bfloat16), y.bfloat16())
+    assert torch.equal(ops.cast(y.bfloat16(), torch.float32), y.bfloat16().float())
+
+
+# ------------------------------------------------------------------------------- Linear eps rule (K1)
+def test_linear_eps_c1_golden(ops):
+    """BASELINE config 1 on the device: Linear(768->768), M=1, against the reference's own output."""
+    fx = load("rules.npz")
+    for tag in ("c1", "toy", "mid"):
+        x, W, b, g = (t(fx[f"lin_{tag}_{k}"]).cuda() for k in "xWbg")
+        for eps_tag, eps in (("f", 1e-6), ("r", 1e-8)):
+            z = ops.gemm_nt(x, W, b)
+            # relevance form with the forward's own z (what lf.linear_epsilon saves): s = R/(z+eps)
+            R_out = ops.mul(z, g)
+            s = ops.eps_scale(R_out, z, 1.0, eps, relevance=True)
+            R_in = ops.mul(ops.gemm_nt(s, ops.transpose(W)), x)
+            assert nmax(R_in, fx[f"lin_{tag}_{eps_tag}_Rin"]) < 2e-5, (tag, eps_tag)
+            # gradient form: G = g  ->  R_in = x * ((g * z/(z+eps)) W)
+            A = ops.eps_scale(g, z, 1.0, eps)
+            assert nmax(ops.mul(ops.gemm_nt(A, ops.transpose(W)), x), fx[f"lin_{tag}_{eps_tag}_Rin"]) < 2e-5
+            if x.shape[0] <= 4:   # one-pass small-M kernel (W read once)
+                R1, z1 = ops.linear_eps_smallm(x, W, b, g, eps, relevance_in=False, relevance_out=True, want_z=True)
+                assert nmax(z1, z) < 1e-5
+                assert nmax(R1, fx[f"lin_{tag}_{eps_tag}_Rin"]) < 5e-5, (tag, eps_tag)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 1024, 2048), (4, 512, 1024), (1, 2048, 8192)])
+def test_linear_eps_smallm(ops, dtype, M, N, K):
+    e = 16 // torch.empty(0, dtype=dtype).element_size()
+    kch = -(-K // (64 * e))
+    kch_p = next(v for v in (1, 2, 4, 8, 16, 32, 64) if v >= kch)
+    mm = 1 if M == 1 else (2 if M == 2 else 4)
+    if kch_p > 16 or (kch_p >= 8 and mm * kch_p * e > 128):
+        pytest.skip("outside the one-pass kernel's register budget (the GEMM path covers it)")
+    x, W = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    g = rnd(M, N, dtype=dtype, seed=3)
+    eps = 1e-6
+    z = (f64(x) @ f64(W).T).to(dtype).double()
+    ref = ((f64(g) * z / (z + eps)) @ f64(W)) * f64(x)
+    out = ops.linear_eps_smallm(x, W, None, g, eps)
+    assert nmax(out, ref) < (5e-5 if dtype == torch.float32 else 2e-2)
+
+
+# ----------------------------------------------------------------------------------- element-wise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 37, 4096, 100003])
+def test_eps_scale_mul_add2(ops, dtype, n):
+    g, z = rnd(n, dtype=dtype, seed=1), rnd(n, dtype=dtype, seed=2)
+    for c, eps in ((1.0, 1e-6), (2.0, 1e-8), (1.0, 0.0)):
+        ref = f64(g) * (f64(z) / (c * f64(z) + eps) if eps else 1.0 / c)
+        assert nmax(ops.eps_scale(g, z, c, eps), ref) < TOL[dtype]
+    assert nmax(ops.eps_scale(g, z, 2.0, 1e-3, relevance=True), f64(g) / (2 * f64(z) + 1e-3)) < TOL[dtype]
+    assert nmax(ops.mul(g, z), f64(g) * f64(z)) < TOL[dtype]
+    a, b = rnd(n, dtype=dtype, seed=3), rnd(n, dtype=dtype, seed=4)
+    Ra, Rb = ops.add2_rule_bwd(a, b, g, 1e-6)
+    s = f64(g) / (f64(a) + f64(b) + 1e-6)
+    assert nmax(Ra, s * f64(a)) < TOL[dtype] * 50 and nmax(Rb, s * f64(b)) < TOL[dtype] * 50
+
+
+def test_rule_goldens_elementwise(ops):
+    fx = load("rules.npz")
+    a, b, g = (t(fx[k]).cuda() for k in ("add_a", "add_b", "add_g"))
+    Ra, Rb = ops.add2_rule_bwd(a, b, (a + b) * g, 1e-8)
+    assert nmax(Ra, fx["add_Ra"]) < 2e-5 and nmax(Rb, fx["add_Rb"]) < 2e-5
+    x, G = t(fx["act_x"]).cuda(), t(fx["act_G"]).cuda()
+    assert nmax(ops.act_fwd(x, "silu"), fx["act_silu_y"]) < 1e-6
+    assert nmax(ops.act_bwd(G, x, "silu", 1e-10), fx["act_silu_Gin"]) < 1e-5
+    assert nmax(ops.act_fwd(x, "gelu_tanh"), fx["act_gelut_y"]) < 1e-6
+    assert nmax(ops.act_bwd(G, x, "gelu_tanh", 1e-10), fx["act_gelut_Gin"]) < 1e-5
+    # softmax rule incl. -inf mask entries
+    xs, gs = t(fx["sm_x"]).cuda(), t(fx["sm_g"]).cuda()
+    p = ops.softmax_fwd(xs)
+    assert nmax(p, fx["sm_p"]) < 1e-6
+    Rx = ops.softmax_rule_bwd(xs, p, p * gs)
+    assert torch.isfinite(Rx).all() and nmax(Rx, fx["sm_Rx"]) < 2e-5
+    # layer norm
+    x, w, bb, g = (t(fx[k]).cuda() for k in ("ln_x", "ln_w", "ln_b", "ln_g"))
+    y, mean, rstd = ops.layernorm_fwd(x, w, bb, 1e-12)
+    assert nmax(y, fx["ln_y"]) < 1e-5
+    Gx = ops.layernorm_bwd(g, y, w, rstd, 1e-6)      # G_y = R_out / y = g
+    assert nmax(ops.mul(Gx, x), fx["ln_Rin"]) < 5e-5
+    # rms norm forward
+    x, w = t(fx["rms_x"]).cuda().reshape(-1, 64), t(fx["rms_w"]).cuda()
+    y, _ = ops.add_rmsnorm_fwd(x, None, w, 1e-5)
+    assert nmax(y, t(fx["rms_y"]).reshape(-1, 64)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I", [(5, 24), (130, 1024)])
+def test_gated_act(ops, dtype, M, I):
+    gu = rnd(M, 2 * I, dtype=dtype, seed=1)
+    g, u = gu[:, :I], gu[:, I:]
+    m = ops.gated_act_fwd(g, u)
+    act = F.silu(f64(g)).to(dtype).double()
+    assert nmax(m, act * f64(u)) < TOL[dtype]
+    Gm = rnd(M, I, dtype=dtype, seed=2)
+    Agu = torch.empty(M, 2 * I, dtype=dtype, device="cuda")
+    for eps_g, eps_lin in ((1e-10, 0.0), (1e-8, 1e-8)):
+        ops.gated_act_bwd(Gm, g, u, Agu[:, :I], Agu[:, I:], eps_g, eps_lin)
+        Ag = 0.5 * f64(Gm) * f64(u) * act / (f64(g) + eps_g)
+        Au = 0.5 * f64(Gm) * act * (f64(u) / (f64(u) + eps_lin) if eps_lin else 1.0)
+        assert nmax(Agu[:, :I], Ag) < TOL[dtype] * 20 and nmax(Agu[:, I:], Au) < TOL[dtype] * 20
+
+
+def _rope_ref(x, cos, sin):
+    d = x.shape[-1]
+    rot = torch.cat((-x[..., d // 2:], x[..., : d // 2]), -1)
+    return x * cos + rot * sin
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d", [16, 128])
+def test_rope(ops, dtype, d):
+    B, S, nh = 2, 37, 3
+    x = rnd(B * S, nh * d + 8, dtype=dtype, seed=1)[:, : nh * d]      # strided rows
+    pos = torch.arange(S, dtype=torch.float64)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+    emb = torch.cat((pos[:, None] * inv, pos[:, None] * inv), -1)
+    cos, sin = emb.cos().float().cuda(), emb.sin().float().cuda()
+    xr = ops.rope_fwd(x, torch.empty(B * S, nh * d, dtype=dtype, device="cuda"), cos, sin, S, nh, d)
+    x4 = f64(x).reshape(B, S, nh, d)
+    ref = _rope_ref(x4, f64(cos)[None, :, None], f64(sin)[None, :, None])
+    assert nmax(xr, ref.reshape(B * S, -1)) < TOL[dtype]
+    G = rnd(B * S, nh * d, dtype=dtype, seed=2)
+    for er, el in ((0.0, 0.0), (1e-8, 1e-8)):
+        A = ops.rope_bwd(G, xr if er else None, x if el else None, torch.empty_like(G), cos, sin, S, nh, d, er, el)
+        xg = x4.clone().requires_grad_()
+        yr = _rope_ref(xg, f64(cos)[None, :, None], f64(sin)[None, :, None])
+        Gp = f64(G).reshape(B, S, nh, d)
+        if er:
+            xrd = f64(xr).reshape(B, S, nh, d)
+            Gp = Gp * xrd / (xrd + er)
+        gx, = torch.autograd.grad(yr, xg, Gp)
+        if el:
+            gx = gx * x4 / (x4 + el)
+        assert nmax(A, gx.reshape(B * S, -1)) < TOL[dtype] * 5
+
+
+# ---------------------------------------------------------------------------------------- row ops
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,H", [(3, 64), (129, 4096), (7, 100)])
+def test_rmsnorm_fwd_bwd(ops, dtype, M, H):
+    h, br, w = rnd(M, H, dtype=dtype, seed=1), rnd(M, H, dtype=dtype, seed=2), rnd(H, dtype=dtype, seed=3)
+    hs = torch.empty_like(h)
+    y, rstd = ops.add_rmsnorm_fwd(h, br, w, 1e-5, hsum_out=hs)
+    hsum = (f64(h) + f64(br)).to(dtype).double()
+    rs = torch.rsqrt(hsum.pow(2).mean(-1, keepdim=True) + 1e-5)
+    assert nmax(hs, hsum) < 1e-6 and nmax(rstd, rs[:, 0]) < 1e-5
+    assert nmax(y, f64(w) * (hsum * rs).to(dtype).double()) < TOL[dtype]
+    y1, _ = ops.add_rmsnorm_fwd(h, None, w, 1e-5, w_offset=1.0)
+    rs1 = torch.rsqrt(f64(h).pow(2).mean(-1, keepdim=True) + 1e-5)
+    assert nmax(y1, f64(h) * rs1 * (1 + f64(w))) < TOL[dtype]
+    # backward
+    Gres, Gx = rnd(M, H, dtype=dtype, seed=4), rnd(M, H, dtype=dtype, seed=5)
+    Gs, A = torch.empty_like(h), torch.empty_like(h)
+    rel = torch.empty(M, device="cuda")
+    for ea, el in ((0.0, 0.0), (1e-8, 1e-8)):
+        ops.rmsnorm_bwd_add2(Gres, Gx, w, rstd, hs, br, Gs, A, rel, 0.0, ea, el)
+        Gh = f64(Gres) + f64(Gx) * f64(w) * rstd.double()[:, None]
+        Gs_ref = Gh * (f64(hs) / (f64(hs) + ea) if ea else 1.0)
+        A_ref = Gs_ref * (f64(br) / (f64(br) + el) if el else 1.0)
+        assert nmax(Gs, Gs_ref) < TOL[dtype] * 5 and nmax(A, A_ref) < TOL[dtype] * 5
+        assert nmax(rel, (f64(hs) * Gh).sum(-1)) < TOL[dtype] * 5
+    ops.rmsnorm_bwd_add2(Gres, None, None, None, hs, br, Gs, A, None, 0.0, 1e-8, 1e-8)
+    assert nmax(Gs, f64(Gres) * f64(hs) / (f64(hs) + 1e-8)) < TOL[dtype] * 5
+    ops.rmsnorm_bwd_add2(None, Gx, w, rstd, None, None, Gs, None, None, 0.0, 0.0, 0.0)
+    assert nmax(Gs, f64(Gx) * f64(w) * rstd.double()[:, None]) < TOL[dtype] * 5
+
+
+def test_readout_argmax_headseed(ops):
+    e, G = rnd(50, 264, seed=1), rnd(50, 264, seed=2)
+    assert nmax(ops.readout(e, G), (f64(e) * f64(G)).sum(-1)) < 1e-5
+    logits = rnd(3, 1000, seed=3)
+    logits[1, 77] = 50.0
+    idx, val = ops.argmax_rows(logits)
+    assert torch.equal(idx.long().cpu(), logits.argmax(-1).cpu()) and torch.equal(val, logits.max(-1).values)
+    W, wn, rstd = rnd(1000, 264, seed=4), rnd(264, seed=5), rnd(3, seed=6).abs()
+    out = ops.head_seed(W, logits, idx, wn, rstd, torch.empty(3, 264, device="cuda"), 0.0, 1e-8)
+    z = val.double()
+    ref = (z / (z + 1e-8) * rstd.double())[:, None] * f64(W)[idx.long()] * f64(wn)
+    assert nmax(out, ref) < 1e-5
+
+
+# -------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale, causal, window):
+    """fp64 eager attention with the LRP gradient modifiers; q [B,Hq,S,d], k/v [B,Hkv,S,d]"""
+    B, Hq, S, d = q.shape
+    rep = Hq // k.shape[1]
+    kx, vx = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
+    s = q @ kx.transpose(-1, -2)
+    i = torch.arange(S, device=q.device)
+    vis = torch.ones(S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        vis &= i[None, :] <= i[:, None]
+    if window > 0:
+        vis &= i[None, :] > i[:, None] - window
+    s3 = (s * scale).masked_fill(~vis, float("-inf"))
+    p = torch.softmax(s3, -1)
+    return s, p, p @ vx, vis, rep
+
+
+def _tm(x):      # [B,H,S,d] -> token-major [B*S, H*d]
+    B, H, S, d = x.shape
+    return x.permute(0, 2, 1, 3).reshape(B * S, H * d).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,Hq,Hkv,d,causal,window", [
+    (1, 16, 4, 2, 16, True, 0), (2, 100, 4, 2, 32, True, 0), (1, 192, 4, 1, 128, True, 0),
+    (1, 130, 2, 2, 64, False, 0), (1, 200, 2, 1, 64, True, 48), (1, 300, 8, 2, 128, True, 0)])
+@pytest.mark.parametrize("mode", ["efficient", "explicit"])
+def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
+    if dtype == torch.bfloat16 and d < 32:
+        pytest.skip("bf16 needs head_dim >= 32 (one 64-byte MFMA K chunk)")
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    q, k, v = rnd(B, Hq, S, d, dtype=dtype, seed=1), rnd(B, Hkv, S, d, dtype=dtype, seed=2), rnd(B, Hkv, S, d, dtype=dtype, seed=3)
+    scale = d ** -0.5
+    qt, kt, vt = _tm(q), _tm(k), _tm(v)
+    v_t = ops.transpose_heads(vt, B, S, Hkv, d)
+    assert torch.equal(v_t[..., :S], v.transpose(-1, -2))
+    o = torch.empty(B * S, Hq * d, dtype=dtype, device="cuda")
+    lse = torch.empty(B, Hq, S, device="cuda")
+    ops.attn_fwd(qt, kt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
+    s, p, o_ref, vis, rep = _attn_ref(f64(q), f64(k), f64(v), scale, causal, window)
+    assert nmax(o, _tm(o_ref)) < tol
+    lse_ref = torch.logsumexp((s * scale).masked_fill(~vis, float("-inf")), -1)
+    assert nmax(lse, lse_ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+    E = dict(pv=1e-6, mask=1e-8, qk=1e-8) if mode == "explicit" else dict(pv=0.0, mask=0.0, qk=0.0)
+    Go = rnd(B * S, Hq * d, dtype=dtype, seed=4)
+    Gho, D = torch.empty_like(Go), torch.empty(B, Hq, S, device="cuda")
+    ops.attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, E["pv"], 0.5)
+    od = f64(o).reshape(B, S, Hq, d).permute(0, 2, 1, 3)
+    God = f64(Go).reshape(B, S, Hq, d).permute(0, 2, 1, 3)
+    Gho_ref = 0.5 * God * (od / (od + E["pv"]) if E["pv"] else 1.0)
+    assert nmax(Gho, _tm(Gho_ref)) < tol
+    # reference backward from the kernel's own (rounded) Gho so only the attention math is compared
+    Gh = f64(Gho).reshape(B, S, Hq, d).permute(0, 2, 1, 3)
+    assert nmax(D, (Gh * od).sum(-1)) < tol
+    vx, kx = f64(v).repeat_interleave(rep, 1), f64(k).repeat_interleave(rep, 1)
+    dP = Gh @ vx.transpose(-1, -2)
+    dS3 = p * (dP - (dP * p).sum(-1, keepdim=True))
+    s2 = s * scale
+    f = torch.ones_like(s)
+    if E["mask"]:
+        f = f * s2 / (s2 + E["mask"])
+    f = f * (s / (2 * s + E["qk"]) if E["qk"] else 0.5)
+    Ghs = torch.where(vis, dS3 * scale * f, torch.zeros_like(s))
+    dQ = Ghs @ kx
+    dK = (Ghs.transpose(-1, -2) @ f64(q)).reshape(B, Hkv, rep, S, d).sum(2)
+    dV = (p.transpose(-1, -2) @ Gh).reshape(B, Hkv, rep, S, d).sum(2)
+    k_t, q_t, Gho_t = ops.transpose_heads(kt, B, S, Hkv, d), ops.transpose_heads(qt, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)
+    dq = torch.empty_like(qt)
+    ops.attn_bwd_dq(qt, kt, vt, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, E["mask"], E["qk"], causal, window)
+    assert nmax(dq, _tm(dQ)) < tol * 3
+    dk_h, dv_h = torch.empty_like(qt), torch.empty_like(qt)
+    ops.attn_bwd_dkv(qt, kt, vt, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, E["mask"], E["qk"], causal, window)
+    dk, dv = torch.empty_like(kt), torch.empty_like(vt)
+    ops.gqa_reduce(dk_h, dk, B * S, Hkv, rep, d)
+    ops.gqa_reduce(dv_h, dv, B * S, Hkv, rep, d)
+    assert nmax(dk, _tm(dK)) < tol * 3 and nmax(dv, _tm(dV)) < tol * 3
+
+
+def test_rule_goldens_attention_pieces(ops):
+    """matmul rule (Prop 3.3) and uniform-eps P.V rule against the reference's outputs, composed
+    from the C-ABI GEMM + eps-scale exactly as the explicit API layer does."""
+    fx = load("rules.npz")
+    a, b, g = t(fx["mm_a"]).cuda(), t(fx["mm_b"]).cuda(), t(fx["mm_g"]).cuda()
+    bt = ops.transpose(b)
+    o = ops.gemm_nt(a, bt)
+    s = ops.eps_scale(ops.mul(o, g), o, 2.0, 1e-8, relevance=True)
+    Ra = ops.mul(ops.gemm_nt(s, b), a)
+    Rb = ops.mul(ops.gemm_nt(ops.transpose(a), ops.transpose(s)), b)
+    assert nmax(Ra, fx["mm_Ra"]) < 2e-5 and nmax(Rb, fx["mm_Rb"]) < 2e-5
+    p, v, g = t(fx["pv_p"]).cuda(), t(fx["pv_v"]).cuda(), t(fx["pv_g"]).cuda()
+    o = ops.gemm_nt(p, ops.transpose(v))
+    s = ops.eps_scale(ops.mul(o, g), o, 1.0, 1e-6, relevance=True)
+    s = ops.mul(s, torch.full_like(s, 0.5))
+    Rp = ops.mul(ops.gemm_nt(s, v), p)
+    Rv = ops.mul(ops.gemm_nt(ops.transpose(p), ops.transpose(s)), v)
+    assert nmax(Rp, fx["pv_Rp"]) < 2e-5 and nmax(Rv, fx["pv_Rv"]) < 2e-5
