@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- explanations/sec of the full AttnLRP pass (forward + LRP backward + read-out) on a
+Llama-3-8B-shaped model, seq=2048, synthetic data, on N MI355X of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
+torch.distributed.run with one rank per GPU.  A "step" = every rank explains `--batch` prompts of
+`--seq` tokens (weak scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+
+  value        whole-job explanations/s = N * batch * K / max-over-ranks(time of K steps); inputs
+               (ids, weights) are resident in HBM before the timed region.
+  roofline     dominant kernel = gemm_nt_kernel<bf16,bf16> (94 % of the algorithmic FLOPs): achieved
+               = sum over its launches of 2*M*N*K divided by the sum of their durations, both taken
+               live with HIP events on the launching stream inside the timed region; peak = 2500
+               TFLOP/s (dense bf16 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline the oracle (CPU port of the same op sequence, oracle/llama.py) timed on this box's
+               host cores on a bounded sample (one decoder layer + head, fp32, extrapolated x32);
+               rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LLAMA3_8B = dict(hidden=4096, inter=14336, n_layers=32, n_heads=32, n_kv=8, head_dim=128, vocab=128256,
+                 rope_theta=500000.0, rms_eps=1e-5, act="silu")
+
+
+def synth_weights(cfg, device, dtype, seed=0):
+    """HF-default-style random init N(0, 0.02), generated directly on the device (no checkpoint,
+    no network); same seed on every rank."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    H, I, d, nq, nk, V = cfg["hidden"], cfg["inter"], cfg["head_dim"], cfg["n_heads"], cfg["n_kv"], cfg["vocab"]
+
+    def rn(*s):
+        return (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * 0.02).to(dtype)
+
+    W = dict(embed=rn(V, H), norm=torch.ones(H, device=device, dtype=dtype), lm_head=rn(V, H), layers=[])
+    for _ in range(cfg["n_layers"]):
+        W["layers"].append(dict(ln1=torch.ones(H, device=device, dtype=dtype), ln2=torch.ones(H, device=device, dtype=dtype),
+                                wq=rn(nq * d, H), wk=rn(nk * d, H), wv=rn(nk * d, H), wo=rn(H, nq * d),
+                                wg=rn(I, H), wu=rn(I, H), wd=rn(H, I)))
+    return W
+
+
+def cpu_baseline(cfg, S, budget_s=30.0):
+    """time the oracle (CPU port) on ONE decoder layer + head of the same shape, fp32, all host
+    cores; extrapolate to the full depth.  Bounded: a single timed pass after one warm-up if it fits
+    the budget."""
+    from oracle import llama as ol
+    c1 = dict(cfg, n_layers=1, vocab=min(cfg["vocab"], 32768))
+    W = ol.random_weights(c1, seed=0)
+    ids = torch.randint(0, c1["vocab"], (S,), generator=torch.Generator().manual_seed(1234))
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    ol.explain(c1, W, ids=ids, mode="efficient", dtype=torch.float32)
+    t_first = time.time() - t0
+    t_layer = t_first
+    if t_first < budget_s / 2:
+        t0 = time.time()
+        ol.explain(c1, W, ids=ids, mode="efficient", dtype=torch.float32)
+        t_layer = time.time() - t0
+    total = t_layer * cfg["n_layers"]
+    return dict(value=1.0 / total, unit="explanations/s", cores=cores, kind="port",
+                sample=f"oracle/llama.py, 1 of {cfg['n_layers']} decoder layers + last-token head at S={S}, fp32, "
+                       f"{t_layer:.2f} s measured, extrapolated x{cfg['n_layers']}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="prompts per step per GPU")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--mode", default="efficient", choices=["efficient", "explicit"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import lxt_amd.dist as D
+    import lxt_amd.engine as E
+    import lxt_amd.ops as ops
+    import torch.distributed as dist
+
+    rank, world, local = D.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = dict(LLAMA3_8B, n_layers=args.layers)
+
+    W = synth_weights(cfg, dev, dtype, seed=0)
+    eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=args.seq)
+    del W
+    torch.cuda.empty_cache()
+    if world > 1:
+        # weights are generated from the same seed on every rank; the broadcast from rank 0 makes
+        # the replica identity explicit (C1 of SURVEY.md 8e) -- outside the timed region
+        flat = [eng.embed, eng.norm, eng.lm_head] + [t for L in eng.layers for t in L.values()]
+        D.broadcast_weights(flat, src=0)
+
+    B, S = args.batch, args.seq
+    n_total = world * B
+    gen = torch.Generator().manual_seed(1234)
+    ids_all = torch.randint(0, cfg["vocab"], (n_total * (args.steps + args.warmup), S), generator=gen).to(dev)
+
+    def step(i):
+        chunk = ids_all[i * n_total: (i + 1) * n_total]
+        lo, hi = D.shard_range(n_total, rank, world)
+        out = eng.explain(chunk[lo:hi])
+        return D.gather_relevance(out["R_tok"], n_total)      # C2: all-gather of token relevances
+
+    for i in range(args.warmup):
+        R = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        R = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    assert torch.isfinite(R).all()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+
+    if rank == 0:
+        n_launch, flops, secs = timer.summary()
+        achieved = flops / secs / 1e12
+        peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+        line = {
+            "metric": "explanations/sec (full AttnLRP backward) Llama-3-8B seq=2048",
+            "value": n_total * args.steps / elapsed, "unit": "explanations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Llama-3-8B shape ({cfg['n_layers']} layers, H4096, I14336, 32/8 heads, V128256), "
+                                   f"random init, lxt.{args.mode} rule placement, seq={S}, causal, last-position arg-max logit",
+                       "seq_len": S, "prompts_per_gpu_per_step": B, "global_batch": n_total, "mode": args.mode,
+                       "parallelism": f"dp{world} (prompt sharding, no data-path collective)"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (Linear forward + eps-rule dgrad)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
+                         "gemm_time_frac_of_step": secs / elapsed, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, S)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

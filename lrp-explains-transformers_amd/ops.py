@@ -81,12 +81,39 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=None):
     return out
 
 
+class KernelTimer:
+    """HIP-event timing of every launch of one kernel family on the launching stream (bench.py's
+    roofline leg).  Enabled by assigning an instance to ops.GEMM_TIMER; records (flops, ev0, ev1)."""
+
+    def __init__(self):
+        self.records = []
+
+    def span(self, flops):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((flops, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        """-> (launches, total_flops, total_seconds) ; call after a device synchronise"""
+        tot_f = sum(r[0] for r in self.records)
+        tot_t = sum(r[1].elapsed_time(r[2]) for r in self.records) * 1e-3
+        return len(self.records), tot_f, tot_t
+
+
+GEMM_TIMER = None
+
+
 def gemm_nt_2d(a, b, out, bias=None):
     """strict 2-D fast path used by the engine: no reshapes, no copies; row strides may exceed K."""
     M, K = a.shape
     N = b.shape[0]
+    ev = GEMM_TIMER.span(2.0 * M * N * K) if GEMM_TIMER is not None else None
+    if ev:
+        ev[0].record()
     rc = lib.lrp_gemm_nt(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(bias), M, N, K, a.stride(0), b.stride(0),
                          out.stride(0), 1, 0, 0, 0, dt(a), _DT[out.dtype], stream())
+    if ev:
+        ev[1].record()
     check(rc, "lrp_gemm_nt")
     return out
 

@@ -1,0 +1,55 @@
+"""N>1 path on CPU: world_size-2 gloo run of the prompt sharding / relevance all-gather /
+weight broadcast (lxt_amd.dist).  The per-prompt work is replaced by a pure function of the
+ids so the test pins exactly what the collectives must preserve: global prompt order and
+rank-sharded == single-process results."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %r)
+    import lxt_amd.dist as D
+    import torch.distributed as dist
+    rank, world, _ = D.init(backend="gloo")
+    assert world == 2
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 1000, (7, 16), generator=g)          # 7 prompts: uneven shards (4 + 3)
+    fake = lambda x: (x.float() * 0.5 + x.float().cumsum(1))     # stands in for engine.explain
+    R = D.explain_sharded(fake, ids, batch=2)
+    assert R.shape == (7, 16) and torch.equal(R, fake(ids)), "sharded != single-process"
+    w = [torch.full((5, 3), float(rank + 1)), torch.arange(4.0) * (rank + 1)]
+    D.broadcast_weights(w, src=0)
+    assert torch.equal(w[0], torch.full((5, 3), 1.0)) and torch.equal(w[1], torch.arange(4.0))
+    lo, hi = D.shard_range(7, rank, world)
+    assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+    dist.barrier()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_sharding_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_shard_range_partitions():
+    import lxt_amd.dist as D
+    for n in (0, 1, 7, 8, 1024):
+        for world in (1, 2, 4, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
