@@ -17,6 +17,7 @@
 // ds_read_b128 / ds_read_b64 for every pitch used here.  One LDS buffer + register prefetch of the
 // next tile (global loads are issued before the MFMAs of the current tile).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -279,13 +280,40 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
     }
 }
 
-// the LRP score-gradient modifier shared by both backward kernels
+// the LRP score-gradient modifier shared by the backward kernels
 LRP_DEVICE float lrp_ds(float s_raw, float p, float dp, float Dq, float scale, float eps_mask, float eps_qk) {
     float ds = p * (dp - Dq) * scale;
     if (eps_mask != 0.f) { const float s2 = s_raw * scale; ds *= s2 / (s2 + eps_mask); }
     ds *= (eps_qk == 0.f) ? 0.5f : s_raw / (2.f * s_raw + eps_qk);
     return ds;
 }
+// branch-free form for the v2 kernels.  EXPL=false: lxt.efficient (factor 1/2).  EXPL=true: both
+// explicit stabilisers folded into ONE reciprocal:  s2/(s2+e1) * s/(2s+e2) = s2*s / ((s2+e1)(2s+e2))
+// (v_rcp_f32, 1 ulp; the pole at s = -e is the reference's own).
+template <bool EXPL>
+LRP_DEVICE float lrp_ds2(float s_raw, float p, float dp, float Dq, float scale, float eps_mask, float eps_qk) {
+    const float ds = p * (dp - Dq) * scale;
+    if constexpr (!EXPL) return ds * 0.5f;
+    else {
+        const float s2 = s_raw * scale;
+        return ds * (s2 * s_raw) * __builtin_amdgcn_rcpf((s2 + eps_mask) * (2.f * s_raw + eps_qk));
+    }
+}
+
+// XCD-aware 1-D grid decode.  Workgroups that share column-side tiles (same kv head for forward /
+// dQ, same query head for dK/dV) must sit on ONE XCD so those tiles are served by its 4 MiB L2
+// instead of being pulled through the fabric by all eight: linear id L runs on XCD L % 8, so the
+// sharing group index goes into the low bits.  ngroups sharing groups, per_group work items each;
+// returns false for the padding ids of a partially filled last round of 8 groups.
+LRP_DEVICE bool xcd_group_decode(int L, int ngroups, int per_group, int& group, int& item) {
+    const int rounds = (ngroups + 7) >> 3;
+    const int xcd = L & 7, i = L >> 3;
+    item = i % per_group;
+    group = xcd + 8 * (i / per_group);
+    (void)rounds;
+    return group < ngroups;
+}
+inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
 
 // =================================================================================================
 // backward dQ: row side = queries (registers); column side = keys (K, V row-major + K^T in LDS)
@@ -476,6 +504,377 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dkv_kernel(
     store_rows<T, D>(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, lane);
 }
 
+
+// =================================================================================================
+// v2 kernels: 8 waves, direct-to-LDS staging (global_load_lds_dwordx4: 1 KiB per wave instruction,
+// lane l -> LDS byte 16 l), TWO LDS stages, one barrier per tile.  The tile of step t+1 streams
+// into the other stage while the MFMAs of step t run; no staging VGPRs, no ds_write pass, and a
+// tile is shared by 8 waves instead of 4 (half the LDS-fill and L2 traffic per MFMA).
+// The XOR swizzle is applied to the SOURCE address (the LDS image of a wave instruction is
+// lane-linear), the fragment reads use the same involution -- identical LDS image to v1.
+// No per-lane predication: row indices are clamped to S-1 (duplicates are masked by `visible`),
+// transposed operands are read up to the zero padded ldt (ldt % CT == 0 required).
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// row-major tile [CT rows][D*SZ bytes] of a token-major operand (row stride ld elements)
+template <typename T, int D, int NW>
+LRP_DEVICE void glds_rowmajor(const T* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
+    constexpr int SZ = sizeof(T), EPC = 16 / SZ, KP = D * SZ, CPR = KP / 16, CT = 128 / SZ;
+    constexpr int SW = (CPR >= 16 ? 16 : CPR) - 1;
+    constexpr int RPG = 64 / CPR;                 // rows per 1-KiB group (CPR <= 64)
+    constexpr int NG = CT * KP / 1024;
+#pragma unroll
+    for (int g = 0; g < (NG + NW - 1) / NW; ++g) {
+        const int grp = g * NW + wave;
+        if (grp < NG) {
+            const int row = grp * RPG + lane / CPR, slot = lane % CPR;
+            const int chunk = slot ^ (row & SW);
+            int gr = row0 + row;
+            gr = gr < S ? gr : S - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)gr * ld + chunk * EPC), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
+        }
+    }
+}
+// transposed tile [D rows][128 B] of a head-transposed operand (row stride ldt), columns c0..c0+CT
+template <typename T, int D, int NW>
+LRP_DEVICE void glds_transposed(const T* base, int64_t ldt, int c0, char* lds, int wave, int lane) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int NG = D / 8;
+#pragma unroll
+    for (int g = 0; g < (NG + NW - 1) / NW; ++g) {
+        const int grp = g * NW + wave;
+        if (grp < NG) {
+            const int row = grp * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (lane >> 3);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)row * ldt + c0 + chunk * EPC), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
+        }
+    }
+}
+// 64 fp32 row statistics (lse or D) of rows r0..r0+63 (clamped) -> lds[0..63]
+LRP_DEVICE void glds_stats(const float* base, int r0, int S, char* lds, int lane) {
+    int r = r0 + lane;
+    r = r < S ? r : S - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + r), (lds_ptr_t)lds, 4, 0, 0);
+}
+
+template <typename T, int D, bool EXPL>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
+    const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
+    T* __restrict__ dk, T* __restrict__ dv, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt,
+    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int B) {
+    typedef AT<T> A;
+    typedef typename Mma16<T>::frag frag_t;
+    constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
+    constexpr int NW = 8, BK = 16 * NW;
+    constexpr int TILE = 128 * D;                   // bytes of one staged tile (both layouts)
+    constexpr int STAGE = 4 * TILE + 512;           // Q, G, Qt, Gt, lse[64], D[64]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // sharing group = (batch, query head): all its key blocks read the same Q/Gho tiles -> one XCD
+    int bh, kblk;
+    if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+    const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
+    const int k0 = kblk * BK, ki = k0 + wave * 16 + (lane & 15);
+    const T* qb = q + (int64_t)b * S * ldq + (int64_t)h * D;
+    const T* gb = gho + (int64_t)b * S * ldg + (int64_t)h * D;
+    const T* qtb = qt + ((int64_t)b * Hq + h) * D * ldt;
+    const T* gtb = ghot + ((int64_t)b * Hq + h) * D * ldt;
+    const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
+    const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
+
+    frag_t kf[NDC], vf[NDC];
+    load_row_frags<T, D>(kf, k + (int64_t)b * S * ldk + (int64_t)hk * D, ldk, ki, S, lane);
+    load_row_frags<T, D>(vf, v + (int64_t)b * S * ldv + (int64_t)hk * D, ldv, ki, S, lane);
+
+    f32x4 dkacc[ND16], dvacc[ND16];
+#pragma unroll
+    for (int dt = 0; dt < ND16; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    int qbeg = 0, qend = S;
+    if (causal) qbeg = (k0 / CT) * CT;
+    if (window > 0) qend = min(S, k0 + BK - 1 + window);
+
+    auto stage = [&](int qt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        glds_rowmajor<T, D, NW>(qb, ldq, qt0, S, sb, wave, lane);
+        glds_rowmajor<T, D, NW>(gb, ldg, qt0, S, sb + TILE, wave, lane);
+        glds_transposed<T, D, NW>(qtb, ldt, qt0, sb + 2 * TILE, wave, lane);
+        glds_transposed<T, D, NW>(gtb, ldt, qt0, sb + 3 * TILE, wave, lane);
+        if (wave == 0) glds_stats(lse_b, qt0, S, sb + 4 * TILE, lane);
+        if (wave == 1) glds_stats(D_b, qt0, S, sb + 4 * TILE + 256, lane);
+    };
+    if (qbeg < qend) stage(qbeg, 0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int qt0 = qbeg; qt0 < qend; qt0 += CT) {
+        if (qt0 + CT < qend) stage(qt0 + CT, cur ^ 1);
+        const char* sQ = smem + cur * STAGE;
+        const char* sG = sQ + TILE;
+        const char* sQt = sQ + 2 * TILE;
+        const char* sGt = sQ + 3 * TILE;
+        const float* sL = reinterpret_cast<const float*>(sQ + 4 * TILE);
+        const float* sD = sL + 64;
+
+        f32x4 st[NC16], dp[NC16];
+#pragma unroll
+        for (int t = 0; t < NC16; ++t) { st[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int t = 0; t < NC16; ++t)
+#pragma unroll
+            for (int c = 0; c < NDC; ++c) {
+                st[t] = Mma16<T>::mma(rm_frag<T, D>(sQ, t, c, lane), kf[c], st[t]);
+                dp[t] = Mma16<T>::mma(rm_frag<T, D>(sG, t, c, lane), vf[c], dp[t]);
+            }
+        f32x4 pp[NC16];
+#pragma unroll
+        for (int t = 0; t < NC16; ++t) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + t * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = qt0 + t * 16 + g * 4 + r;
+                const bool ok = (qi < S) && visible(qi, ki, S, causal, window);
+                const float s_raw = st[t][r];
+                const float p = ok ? __expf(s_raw * scale - l4[r]) : 0.f;
+                pp[t][r] = p;
+                st[t][r] = lrp_ds2<EXPL>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
+            }
+        }
+        frag_t pf[2], df[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) { pf[kc] = PackCols<T>::pack(pp, kc); df[kc] = PackCols<T>::pack(st, kc); }
+#pragma unroll
+        for (int dt = 0; dt < ND16; ++dt)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                dvacc[dt] = Mma16<T>::mma(tr_frag<T>(sGt, dt, kc, lane), pf[kc], dvacc[dt]);
+                dkacc[dt] = Mma16<T>::mma(tr_frag<T>(sQt, dt, kc, lane), df[kc], dkacc[dt]);
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_rows<T, D>(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, 1.f, lane);
+    store_rows<T, D>(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, lane);
+}
+
+
+// ---- v2 forward: 8 waves x (16*QSUB) queries, K + V^T tiles, two LDS stages -----------------------
+template <typename T, int D, int QSUB>
+__global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int B) {
+    typedef AT<T> A;
+    typedef typename Mma16<T>::frag frag_t;
+    constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
+    constexpr int NW = 8, BQ = NW * 16 * QSUB;
+    constexpr int TILE = 128 * D, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;      // sharing group = (batch, kv head): its rep*nqb workgroups read the same K/V tiles
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;           // heavy (late) causal blocks first
+    const int q0 = qblk * BQ, qw = q0 + wave * 16 * QSUB;
+    const T* qb = q + (int64_t)b * S * ldq + (int64_t)h * D;
+    const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
+    const T* vtb = vt + ((int64_t)b * Hkv + hk) * D * ldt;
+
+    frag_t qf[QSUB][NDC];
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) load_row_frags<T, D>(qf[s], qb, ldq, qw + s * 16 + (lane & 15), S, lane);
+    float m_run[QSUB], l_run[QSUB];
+    f32x4 oacc[QSUB][ND16];
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) {
+        m_run[s] = -INFINITY; l_run[s] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < ND16; ++dt) oacc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        glds_rowmajor<T, D, NW>(kb, ldk, kt0, S, sb, wave, lane);
+        glds_transposed<T, D, NW>(vtb, ldt, kt0, sb + TILE, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
+        if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + TILE;
+        f32x4 st[QSUB][NC16];
+#pragma unroll
+        for (int s = 0; s < QSUB; ++s)
+#pragma unroll
+            for (int t = 0; t < NC16; ++t) st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NC16; ++t)
+#pragma unroll
+            for (int c = 0; c < NDC; ++c) {
+                const frag_t kf = rm_frag<T, D>(sK, t, c, lane);
+#pragma unroll
+                for (int s = 0; s < QSUB; ++s) st[s][t] = Mma16<T>::mma(kf, qf[s][c], st[s][t]);
+            }
+        const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0);
+#pragma unroll
+        for (int s = 0; s < QSUB; ++s) {
+            const int qi = qw + s * 16 + (lane & 15);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NC16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = st[s][t][r] * scale;
+                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window)) v = -INFINITY;
+                    st[s][t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[s], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(m_run[s] - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < NC16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(st[s][t][r] - m_use);
+                    st[s][t][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[s] = l_run[s] * alpha + rs;
+            m_run[s] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < ND16; ++dt) oacc[s][dt] *= alpha;
+        }
+        frag_t pf[QSUB][2];
+#pragma unroll
+        for (int s = 0; s < QSUB; ++s)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) pf[s][kc] = PackCols<T>::pack(st[s], kc);
+#pragma unroll
+        for (int dt = 0; dt < ND16; ++dt)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const frag_t vf = tr_frag<T>(sV, dt, kc, lane);
+#pragma unroll
+                for (int s = 0; s < QSUB; ++s) oacc[s][dt] = Mma16<T>::mma(vf, pf[s][kc], oacc[s][dt]);
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+    T* ob = o + (int64_t)b * S * ldo + (int64_t)h * D;
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) {
+        const int qi = qw + s * 16 + (lane & 15);
+        const float inv = (l_run[s] > 0.f) ? 1.f / l_run[s] : 0.f;
+        store_rows<T, D>(ob, ldo, qi, S, oacc[s], inv, lane);
+        if (g == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run[s] + __logf(l_run[s]);
+    }
+}
+
+// ---- v2 dQ: 8 waves x 16 queries, K + V + K^T tiles, two LDS stages --------------------------------
+template <typename T, int D, bool EXPL>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
+    const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddq,
+    float scale, float eps_mask, float eps_qk, int causal, int window, int B) {
+    typedef AT<T> A;
+    typedef typename Mma16<T>::frag frag_t;
+    constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
+    constexpr int NW = 8, BQ = NW * 16;
+    constexpr int TILE = 128 * D, STAGE = 3 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;
+    const int q0 = qblk * BQ, qi = q0 + wave * 16 + (lane & 15);
+    const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
+    const T* vb = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+    const T* ktb = kt + ((int64_t)b * Hkv + hk) * D * ldt;
+
+    frag_t qf[NDC], gf[NDC];
+    load_row_frags<T, D>(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, lane);
+    load_row_frags<T, D>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, lane);
+    const float lse_q = (qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    const float D_q = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    f32x4 acc[ND16];
+#pragma unroll
+    for (int dt = 0; dt < ND16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        glds_rowmajor<T, D, NW>(kb, ldk, kt0, S, sb, wave, lane);
+        glds_rowmajor<T, D, NW>(vb, ldv, kt0, S, sb + TILE, wave, lane);
+        glds_transposed<T, D, NW>(ktb, ldt, kt0, sb + 2 * TILE, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
+        if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + TILE;
+        const char* sKt = sK + 2 * TILE;
+        f32x4 st[NC16], dp[NC16];
+#pragma unroll
+        for (int t = 0; t < NC16; ++t) { st[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int t = 0; t < NC16; ++t)
+#pragma unroll
+            for (int c = 0; c < NDC; ++c) {
+                st[t] = Mma16<T>::mma(rm_frag<T, D>(sK, t, c, lane), qf[c], st[t]);
+                dp[t] = Mma16<T>::mma(rm_frag<T, D>(sV, t, c, lane), gf[c], dp[t]);
+            }
+#pragma unroll
+        for (int t = 0; t < NC16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt0 + t * 16 + g * 4 + r;
+                const float s_raw = st[t][r];
+                const float p = visible(qi, key, S, causal, window) ? __expf(s_raw * scale - lse_q) : 0.f;
+                st[t][r] = lrp_ds2<EXPL>(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
+            }
+        frag_t df[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) df[kc] = PackCols<T>::pack(st, kc);
+#pragma unroll
+        for (int dt = 0; dt < ND16; ++dt)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) acc[dt] = Mma16<T>::mma(tr_frag<T>(sKt, dt, kc, lane), df[kc], acc[dt]);
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_rows<T, D>(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, 1.f, lane);
+}
+
 // ---- helpers: head transpose and GQA group reduction --------------------------------------------------
 template <typename T>
 __global__ void transpose_heads_kernel(const T* x, T* xt, int S, int H, int d, int64_t ldx, int64_t ldt) {
@@ -545,6 +944,31 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
                       int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window,
                       hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
+    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
+    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
+        ATT_DISPATCH_D(T, d, {
+            if constexpr (DD <= 128) {
+                const size_t lds = 2 * (2 * (size_t)128 * DD);
+                const int rep = Hq / Hkv;
+                // 256-query workgroups (two 16-row sub-tiles per wave: every K/V fragment read feeds two
+                // MFMAs) once that still leaves >= 2 workgroups per CU, else 128-query workgroups
+                if ((int64_t)B * Hq * ((S + 255) / 256) >= 512) {
+                    auto kern = attn_fwd_v2_kernel<T, DD, 2>;
+                    set_lds(kern, lds);
+                    dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 255) / 256)));
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B);
+                } else {
+                    auto kern = attn_fwd_v2_kernel<T, DD, 1>;
+                    set_lds(kern, lds);
+                    dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 127) / 128)));
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B);
+                }
+            }
+        })
+        return lrp_check_launch();
+    }
     ATT_DISPATCH_D(T, d, {
         constexpr int QSUB = (DD >= 256) ? 1 : 2;
         const size_t lds = (size_t)CT * DD * SZ + (size_t)DD * 128;
@@ -585,6 +1009,29 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                      int64_t ldt, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
                      hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
+    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
+    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
+        ATT_DISPATCH_D(T, d, {
+            if constexpr (DD <= 128) {
+                const size_t lds = 2 * (3 * (size_t)128 * DD);
+                dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
+                if (eps_mask != 0.f || eps_qk != 0.f) {
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, true>;
+                    set_lds(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
+                                       (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
+                                       eps_qk, causal, window, B);
+                } else {
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false>;
+                    set_lds(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
+                                       (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
+                                       eps_qk, causal, window, B);
+                }
+            }
+        })
+        return lrp_check_launch();
+    }
     ATT_DISPATCH_D(T, d, {
         const size_t lds = 2 * (size_t)CT * DD * SZ + (size_t)DD * 128;
         auto kern = attn_bwd_dq_kernel<T, DD>;
@@ -618,6 +1065,29 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                       int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddk, int64_t lddv, float scale,
                       float eps_mask, float eps_qk, int causal, int window, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
+    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
+    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128 && S >= 1) {
+        ATT_DISPATCH_D(T, d, {
+            if constexpr (DD <= 128) {
+                const size_t lds = 2 * (4 * (size_t)128 * DD + 512);
+                dim3 grid(xcd_group_grid(B * Hq, (S + 127) / 128));
+                if (eps_mask != 0.f || eps_qk != 0.f) {
+                    auto kern = attn_bwd_dkv_v2_kernel<T, DD, true>;
+                    set_lds(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
+                                       (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B);
+                } else {
+                    auto kern = attn_bwd_dkv_v2_kernel<T, DD, false>;
+                    set_lds(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
+                                       (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B);
+                }
+            }
+        })
+        return lrp_check_launch();
+    }
     ATT_DISPATCH_D(T, d, {
         const size_t lds = 2 * (size_t)CT * DD * SZ + 2 * (size_t)DD * 128;
         auto kern = attn_bwd_dkv_kernel<T, DD>;

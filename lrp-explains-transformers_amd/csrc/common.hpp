@@ -127,6 +127,20 @@ template <> struct Mma16<float> {
     }
 };
 
+// Grouped tile order: consecutive ids sweep GROUP_M tile-rows of one tile-column, then the next
+// column, so the ~32-64 workgroups resident on one XCD cover a compact GROUP_M x n block of output
+// tiles and share A/B panels through that XCD's L2 instead of each pulling its own from HBM/MALL.
+LRP_DEVICE void grouped_tile(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = id / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int in_group = id - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+}
+
 // XCD-aware bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
 // consecutive remapped ids land on the same XCD so neighbouring tiles share that XCD's L2.
 LRP_DEVICE int xcd_remap(int bid, int nwg) {

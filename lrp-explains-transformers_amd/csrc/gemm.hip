@@ -14,6 +14,7 @@
 //     the MFMAs of tile t and written to the other buffer after them; one barrier per K step;
 //   * 64 KiB LDS/block -> 2 blocks per CU; XCD-aware block remap keeps a B panel in one L2.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -143,6 +144,172 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(
     }
 }
 
+
+// =================================================================================================
+// Fast path: direct-to-LDS staging (global_load_lds_dwordx4, no VGPR round trip, no ds_write pass).
+// One wave instruction deposits 1 KiB = 8 tile rows x 128 B, lane l -> LDS byte l*16, i.e. row
+// (l>>3), slot (l&7).  The XOR swizzle therefore goes on the SOURCE address: lane l fetches global
+// chunk (l&7)^(l>>3) of its row, and the fragment reads apply the same involution (slot = c ^ (row&7)).
+// Tile BM x BN x (128 B of K), WM x WN waves, two LDS stages, one barrier per K step: the loads of
+// step t+1 are in flight under the MFMAs of step t (__syncthreads drains the LDS-DMA queue).
+// Requires K to be a multiple of the 128-byte K step; M, N arbitrary (row indices are clamped, the
+// duplicated rows only feed outputs that are never stored).
+// =================================================================================================
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_nt_glds_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+    int tiles_m, int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
+    constexpr int SM = TBM / WM, SN = TBN / WN;      // wave sub-tile
+    constexpr int FM = SM / 16, FN = SN / 16;        // 16x16 MFMA tiles per wave
+    constexpr int GA = TBM / 8 / NW, GB = TBN / 8 / NW;   // 1-KiB row groups per wave per operand
+    static_assert(TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile rows must split over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (TBM + TBN) * KB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntile = tiles_m * tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntile);
+    int tm, tn;
+    grouped_tile(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int bz = blockIdx.y;
+    A += (int64_t)bz * sA;
+    B += (int64_t)bz * sB;
+    C += (int64_t)bz * sC;
+    const int nkt = K / KE;
+
+    // per-lane source pointers for the row groups this wave stages (row clamp = bounds handling)
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    const T* pa[GA];
+    const T* pb[GB];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        int r = m0 + (wave * GA + i) * 8 + lrow;
+        r = r < M ? r : M - 1;
+        pa[i] = A + (int64_t)r * lda + lchunk * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        int r = n0 + (wave * GB + i) * 8 + lrow;
+        r = r < N ? r : N - 1;
+        pb[i] = B + (int64_t)r * ldb + lchunk * EPC;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE + (wave * GA) * 1024;
+        char* sb = smem + buf * STAGE + TBM * KB + (wave * GB) * 1024;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)kt * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)kt * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef typename Mma16<T>::frag frag_t;
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+        const char* pas = smem + cur * STAGE + (wm * SM) * KB;
+        const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag_t fa[FM], fb[FN];
+            const int off = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * KB + off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(pbs + (j * 16 + frow) * KB + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int gm = m0 + wm * SM + i * 16 + frow;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int gn = n0 + wn * SN + j * 16 + fq * 4;
+            if (gn >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+            }
+            TO* dst = C + (int64_t)gm * ldc + gn;
+            if (vec_ok && gn + 3 < N) {
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) dst[r] = from_f32<TO>(v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
+    dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
+    const size_t lds = 2 * (size_t)(TBM + TBN) * KB;
+    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
+                       sA, sB, sC, tiles_m, tiles_n);
+    return lrp_check_launch();
+}
+
+// tile selection: the largest tile that still gives ~one workgroup per CU (256 CUs)
+template <typename T, typename TO>
+int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st, int force) {
+    auto ntiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+    int cfg = force;
+    // measured on MI355X (profiles/r01_gemm_tiles.txt): 256x256 wins once it yields >= ~190 tiles
+    // (every CU busy), 128x128 below that; 256x128 never wins and is kept as a dev knob only
+    if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 3 : 1;
+    if (cfg == 3) return launch_glds<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 2) return launch_glds<T, TO, 256, 128, 4, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    return launch_glds<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+}
+
 template <typename T, typename TO>
 int launch_gemm(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, int batch, int64_t sA, int64_t sB,
@@ -174,6 +341,19 @@ extern "C" int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bi
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return LRP_EALIGN;
     if (batch > 65535) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    // fast path (direct-to-LDS staging) when K is a whole number of 128-byte steps; LRP_GEMM_TILE=
+    // 1|2|3 forces a tile (dev knob), 9 forces the generic register-staged kernel
+    static const int force = [] { const char* e = getenv("LRP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const int ke = (dtype == LRP_F32) ? 32 : 64;
+    if (force != 9 && (K % ke) == 0 && M >= 1 && N >= 1) {
+        if (dtype == LRP_F32) {
+            if (out_dtype != LRP_F32) return LRP_EINVAL;
+            return launch_fast<float, float>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st, force);
+        }
+        if (out_dtype == LRP_F32) return launch_fast<bf16_t, float>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st, force);
+        if (out_dtype == LRP_BF16) return launch_fast<bf16_t, bf16_t>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st, force);
+        return LRP_EINVAL;
+    }
     if (dtype == LRP_F32) {
         if (out_dtype != LRP_F32) return LRP_EINVAL;
         return launch_gemm<float, float>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
