@@ -26,7 +26,7 @@ def parse_header(path=HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(lrp_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(lrp_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":
@@ -56,7 +56,7 @@ def _load():
             fn = getattr(lib, name)
         except AttributeError as e:
             raise LrpLibraryError(f"liblrp_hip.so does not export {name} declared in lrp_hip.h") from e
-        fn.restype = ctypes.c_char_p if ret != "int" else ctypes.c_int
+        fn.restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_char_p)
         fn.argtypes = [_CTYPE[t] for t in types]
     return lib, decls
 

@@ -5,15 +5,18 @@
 // single pass over W must be N-blocked: a WAVE owns one row of W at a time, keeps it in registers
 // (K*sizeof/1 KiB x 16-byte chunks per lane), computes z_n for every m with a wave reduction,
 // forms s_n, and immediately re-uses the registers for the axpy into per-lane partial c.  Rows are
-// streamed straight to VGPRs (no LDS round trip: nothing is shared between waves), x sits in LDS,
-// and the split-N partial sums are combined with fp32 atomics into the zeroed output.
+// streamed straight to VGPRs (no LDS round trip: nothing is shared between waves), x sits in LDS.
+// Split-N reduction WITHOUT atomics (fp32 atomics cap at ~15 G/s: 16 M of them cost 1 ms where the
+// W stream costs 6 us): the 4 waves of a workgroup fold their partial c through LDS, the workgroup
+// writes one fp32 slab [M,K] to a caller-provided workspace, and a second tiny kernel sums the
+// <= 256 slabs (L2-resident, just written) and applies the optional (*) x.
 // Algorithmic HBM bytes = sizeof(T)*(N*K + 2*M*K + M*N): W is read exactly once.
 #include "common.hpp"
 
 namespace {
 
-template <typename T, int KCH, int MM>
-__global__ __launch_bounds__(256) void linear_eps_smallm_kernel(
+template <typename T, int KCH, int MM, int NWV>
+__global__ __launch_bounds__(64 * NWV) void linear_eps_smallm_kernel(
     const T* __restrict__ x, const T* __restrict__ W, const T* __restrict__ bias, const T* __restrict__ g,
     float* __restrict__ out, float* __restrict__ z_out, int M, int N, int K, float eps, int rel_in, int rel_out) {
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -35,9 +38,8 @@ __global__ __launch_bounds__(256) void linear_eps_smallm_kernel(
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[m][j][e] = 0.f;
 
-    const int nwave = gridDim.x * 4;
-    for (int n = blockIdx.x * 4 + wave; n < N; n += nwave) {
-        Vec16<T> w[KCH];
+    const int nwave = gridDim.x * NWV;
+    auto load_row = [&](Vec16<T>(&w)[KCH], int n) {
 #pragma unroll
         for (int j = 0; j < KCH; ++j) {
             const int k = (j * 64 + lane) * EPC;
@@ -47,6 +49,8 @@ __global__ __launch_bounds__(256) void linear_eps_smallm_kernel(
                 for (int e = 0; e < EPC; ++e) w[j].set(e, 0.f);
             }
         }
+    };
+    auto process = [&](const Vec16<T>(&w)[KCH], int n) {
         float s[MM];
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
@@ -72,67 +76,134 @@ __global__ __launch_bounds__(256) void linear_eps_smallm_kernel(
             for (int j = 0; j < KCH; ++j)
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) acc[m][j][e] += s[m] * w[j].get(e);
-    }
-#pragma unroll
-    for (int m = 0; m < MM; ++m) {
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int k = (j * 64 + lane) * EPC;
-            if (k >= K) continue;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float v = acc[m][j][e];
-                if (rel_out) v *= to_f32(sx[m * KP + k + e]);
-                atomicAdd(out + (int64_t)m * K + k + e, v);
-            }
+    };
+    // two register sets: the row after next streams in while the current one is reduced / axpy'd
+    // (only when the workgroup is small; 16-wave workgroups hide the latency by occupancy instead)
+    constexpr bool DBUF = (NWV <= 8) && (MM * KCH * EPC <= 64);
+    int n = blockIdx.x * NWV + wave;
+    if constexpr (DBUF) {
+        Vec16<T> w0[KCH], w1[KCH];
+        if (n < N) load_row(w0, n);
+        while (n < N) {
+            const int n1 = n + nwave, n2 = n1 + nwave;
+            if (n1 < N) load_row(w1, n1);
+            process(w0, n);
+            if (n1 >= N) break;
+            if (n2 < N) load_row(w0, n2);
+            process(w1, n1);
+            n = n2;
         }
+    } else {
+        Vec16<T> w0[KCH];
+        for (; n < N; n += nwave) { load_row(w0, n); process(w0, n); }
+    }
+    // fold the waves' partial sums through LDS (x is no longer needed there), one wave at a time
+    float* red = reinterpret_cast<float*>(smem);                      // [MM][KP] fp32 (host sizes LDS for it)
+    for (int w = 0; w < NWV; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+#pragma unroll
+                for (int j = 0; j < KCH; ++j) {
+                    float* dst = red + m * KP + (j * 64 + lane) * EPC;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) dst[e] = (w == 0) ? acc[m][j][e] : dst[e] + acc[m][j][e];
+                }
+        }
+    }
+    __syncthreads();
+    float* slab = out + (int64_t)blockIdx.x * M * K;                  // `out` is the workspace here
+    for (int i = threadIdx.x; i < M * K; i += blockDim.x) {
+        const int m = i / K, k = i - m * K;
+        slab[i] = red[m * KP + k];
     }
 }
 
+// out[i] = sum_b ws[b][i] (*x[i]) : 256 threads = 16 slab groups x 16 float4 columns; every thread sums
+// nslab/16 independent float4 loads, the 16 groups fold through LDS (MK % 4 == 0 is guaranteed by K % EPC)
+template <typename T>
+__global__ void smallm_reduce_kernel(const float* __restrict__ ws, const T* __restrict__ x, float* __restrict__ out,
+                                     int nslab, int MK, int rel_out) {
+    __shared__ f32x4 part[16][16];
+    const int ql = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int i = (blockIdx.x * 16 + ql) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < MK) {
+#pragma unroll 4
+        for (int b = sg; b < nslab; b += 16) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)b * MK + i);
+    }
+    part[sg][ql] = s;
+    __syncthreads();
+    if (sg == 0 && i < MK) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += part[k][ql];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[i + e] = rel_out ? s[e] * to_f32(x[i + e]) : s[e];
+    }
+}
+
+inline int smallm_blocks(int N) {
+    int nb = (N + 15) / 16;
+    return nb > 256 ? 256 : (nb < 1 ? 1 : nb);
+}
+
 template <typename T, int KCH, int MM>
-int launch(const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, int M, int N, int K,
-           float eps, int rel_in, int rel_out, hipStream_t st) {
+int launch(const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, float* ws, int M, int N,
+           int K, float eps, int rel_in, int rel_out, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
-    const size_t lds = (size_t)MM * KCH * 64 * EPC * sizeof(T);
-    auto kern = linear_eps_smallm_kernel<T, KCH, MM>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int nb = (N + 3) / 4;
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, (const T*)x, (const T*)W, (const T*)bias, (const T*)g, out, z_out,
+    // bytes of W in flight per CU must cover HBM latency x 6 TB/s / 256 CUs (~50 KiB): 16 waves per
+    // workgroup when the per-lane state fits 128 VGPRs, 8 waves + a second register set (row n+2 streams
+    // in under row n's reduction) at 256 VGPRs, 4 waves for the largest K
+    constexpr int STATE = MM * KCH * EPC;
+    constexpr int NWV = (STATE <= 32) ? 16 : ((STATE <= 64) ? 8 : 4);
+    const size_t kp = (size_t)KCH * 64 * EPC;
+    const size_t lds = (size_t)MM * kp * 4;                            // x (T) first, fp32 fold buffer afterwards
+    auto kern = linear_eps_smallm_kernel<T, KCH, MM, NWV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nb = smallm_blocks(N);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NWV), lds, st, (const T*)x, (const T*)W, (const T*)bias, (const T*)g, ws, z_out,
                        M, N, K, eps, rel_in, rel_out);
+    const int MK = M * K;
+    hipLaunchKernelGGL((smallm_reduce_kernel<T>), dim3((MK + 63) / 64), dim3(256), 0, st, ws, (const T*)x, out, nb, MK, rel_out);
     return lrp_check_launch();
 }
 
 template <typename T, int MM>
-int launch_k(int kch, const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, int M, int N,
-             int K, float eps, int rel_in, int rel_out, hipStream_t st) {
+int launch_k(int kch, const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, float* ws, int M,
+             int N, int K, float eps, int rel_in, int rel_out, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
-    if (kch <= 1) return launch<T, 1, MM>(x, W, bias, g, out, z_out, M, N, K, eps, rel_in, rel_out, st);
-    if (kch <= 2) return launch<T, 2, MM>(x, W, bias, g, out, z_out, M, N, K, eps, rel_in, rel_out, st);
-    if (kch <= 4) return launch<T, 4, MM>(x, W, bias, g, out, z_out, M, N, K, eps, rel_in, rel_out, st);
+    if (kch <= 1) return launch<T, 1, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
+    if (kch <= 2) return launch<T, 2, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
+    if (kch <= 4) return launch<T, 4, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
     if constexpr (MM * 8 * EPC <= 128) {
-        if (kch <= 8) return launch<T, 8, MM>(x, W, bias, g, out, z_out, M, N, K, eps, rel_in, rel_out, st);
+        if (kch <= 8) return launch<T, 8, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
     }
     if constexpr (MM * 16 * EPC <= 128) {
-        if (kch <= 16) return launch<T, 16, MM>(x, W, bias, g, out, z_out, M, N, K, eps, rel_in, rel_out, st);
+        if (kch <= 16) return launch<T, 16, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
     }
     return LRP_ESHAPE;
 }
 
 }  // namespace
 
+extern "C" int64_t lrp_linear_eps_smallm_ws(int M, int N, int K) { return (int64_t)smallm_blocks(N) * M * K; }
+
 extern "C" int lrp_linear_eps_smallm(const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out,
-                                     int M, int N, int K, float eps, int relevance_in, int relevance_out, int dtype,
-                                     void* stream) {
-    if (!x || !W || !g || !out || M < 1 || N < 1 || K < 1) return LRP_EINVAL;
+                                     float* workspace, int M, int N, int K, float eps, int relevance_in, int relevance_out,
+                                     int dtype, void* stream) {
+    if (!x || !W || !g || !out || !workspace || M < 1 || N < 1 || K < 1) return LRP_EINVAL;
     if (dtype != LRP_F32 && dtype != LRP_BF16) return LRP_EINVAL;
     const int epc = dtype == LRP_F32 ? 4 : 8;
     if ((K % epc) || (reinterpret_cast<uintptr_t>(W) & 15)) return LRP_EALIGN;
     if (M > 4) return LRP_ESHAPE;
     const int kch = (K + 64 * epc - 1) / (64 * epc);
     hipStream_t st = (hipStream_t)stream;
-#define GO(T, MM) return launch_k<T, MM>(kch, x, W, bias, g, out, z_out, M, N, K, eps, relevance_in, relevance_out, st)
+#define GO(T, MM) return launch_k<T, MM>(kch, x, W, bias, g, out, z_out, workspace, M, N, K, eps, relevance_in, relevance_out, st)
     if (dtype == LRP_F32) {
         if (M == 1) GO(float, 1);
         if (M == 2) GO(float, 2);

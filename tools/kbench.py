@@ -86,7 +86,8 @@ def bench_smallm(dtype, M, N, K):
     g = torch.randn(M, N, device="cuda").to(dtype)
     es = x.element_size()
     try:
-        t = timeit(lambda: ops.linear_eps_smallm(x, W, None, g, 1e-6))
+        ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(M, N, K), device="cuda")
+        t = timeit(lambda: ops.linear_eps_smallm(x, W, None, g, 1e-6, workspace=ws))
         print(f"linear_eps_smallm {str(dtype)[6:]} M={M} N={N} K={K}: {t*1e6:8.1f} us  {es*(N*K+2*M*K+M*N)/t/1e9:7.1f} GB/s algorithmic", flush=True)
     except RuntimeError as e:
         print("linear_eps_smallm", M, N, K, "->", e)
@@ -104,6 +105,7 @@ if __name__ == "__main__":
         bench_gemm(torch.float32, [(2048, 4096, 4096), (2048, 14336, 4096)])
     if "attn" in a.what:
         bench_attn(torch.bfloat16, 1, 2048, 32, 8, 128)
+        bench_attn(torch.bfloat16, 4, 2048, 32, 8, 128)
         bench_attn(torch.float32, 1, 2048, 32, 8, 128)
     if "row" in a.what:
         bench_row(torch.bfloat16, 2048, 4096, 14336)
