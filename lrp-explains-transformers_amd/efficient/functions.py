@@ -1,0 +1,129 @@
+"""Fused autograd Functions used by the patched forwards (lxt_amd.efficient.patches): each wraps one
+forward kernel + the matching LRP-rule backward kernel of liblrp_hip.so.  These have no counterpart
+file in the reference -- there the same arithmetic is spread over ATen ops; see the kernel
+inventory in SURVEY.md 2.3 (K1-K8)."""
+import torch
+from torch.autograd import Function
+
+from .. import ops
+
+
+class RMSNormFn(Function):
+    """K2: y = w' * x * rsqrt(mean(x^2)+eps) ; backward = identity rule (rsqrt detached):
+    G_x = G_y * w' * rstd.   ref: lxt/efficient/patches.py:111-123, lxt/efficient/models/gemma3.py:11-12"""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps, w_offset):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        y, rstd = ops.add_rmsnorm_fwd(x2, None, weight, eps, w_offset)
+        ctx.save_for_backward(weight, rstd)
+        ctx.w_offset = w_offset
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, rstd = ctx.saved_tensors
+        shp = gy.shape
+        g2 = gy.reshape(-1, shp[-1]).contiguous()
+        gx = torch.empty_like(g2)
+        ops.rmsnorm_bwd_add2(None, g2, weight, rstd, None, None, gx, None, None, ctx.w_offset, 0.0, 0.0)
+        return gx.view(shp), None, None, None
+
+
+class LayerNormFn(Function):
+    """K7: LayerNorm with std detached.  ref: lxt/efficient/patches.py:126-142"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, _, rstd = ops.layernorm_fwd(x, weight, bias, eps)
+        ctx.save_for_backward(weight, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, rstd = ctx.saved_tensors
+        return ops.layernorm_bwd(gy, None, weight, rstd, 0.0), None, None, None
+
+
+class GatedActFn(Function):
+    """K3: m = act(g) * u with the identity rule on act and the uniform rule on the product:
+    G_g = 1/2 G_m u act(g)/(g+1e-10) ; G_u = 1/2 G_m act(g).   ref: lxt/efficient/patches.py:145-157"""
+
+    @staticmethod
+    def forward(ctx, g, u, act):
+        shp = g.shape
+        g2, u2 = g.reshape(-1, shp[-1]).contiguous(), u.reshape(-1, shp[-1]).contiguous()
+        ctx.save_for_backward(g2, u2)
+        ctx.act = act
+        return ops.gated_act_fwd(g2, u2, None, act).view(shp)
+
+    @staticmethod
+    def backward(ctx, gm):
+        g2, u2 = ctx.saved_tensors
+        shp = gm.shape
+        gm2 = gm.reshape(-1, shp[-1]).contiguous()
+        Ag, Au = torch.empty_like(g2), torch.empty_like(u2)
+        ops.gated_act_bwd(gm2, g2, u2, Ag, Au, 1e-10, 0.0, ctx.act)
+        return Ag.view(shp), Au.view(shp), None
+
+
+class LinearFn(Function):
+    """K1 (efficient form, eps = 0): z = x W^T + b on the MFMA GEMM, backward G_x = G_z W on the same
+    kernel with the cached W^T copy (weights are frozen in the LRP protocol, quickstart.rst:84-86)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, weight_t):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        z = ops.gemm_nt(x2, weight, bias)
+        ctx.save_for_backward(weight_t)
+        return z.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gz):
+        (weight_t,) = ctx.saved_tensors
+        shp = gz.shape
+        gx = ops.gemm_nt(gz.reshape(-1, shp[-1]), weight_t)
+        return gx.view(*shp[:-1], weight_t.shape[0]), None, None, None
+
+
+class AttentionFn(Function):
+    """K4: flash attention forward + the AttnLRP backward (softmax Prop. 3.1, uniform rule on both
+    matmuls == the reference's divide_gradient(q,4),(k,4),(v,2); ref: lxt/efficient/patches.py:193-203).
+    q [B,S,Hq,d], k/v [B,S,Hkv,d] (token-major views), returns o [B,S,Hq,d]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, causal, window, cp):
+        B, S, Hq, d = q.shape
+        Hkv = k.shape[2]
+        q2, k2, v2 = (t.reshape(B * S, -1).contiguous() for t in (q, k, v))
+        v_t = ops.transpose_heads(v2, B, S, Hkv, d)
+        o = torch.empty_like(q2)
+        lse = torch.empty(B, Hq, S, device=q.device, dtype=torch.float32)
+        ops.attn_fwd(q2, k2, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
+        ctx.save_for_backward(q2, k2, v2, o, lse)
+        ctx.meta = (B, S, Hq, Hkv, d, scale, causal, window, cp)
+        return o.view(B, S, Hq, d)
+
+    @staticmethod
+    def backward(ctx, go):
+        q2, k2, v2, o, lse = ctx.saved_tensors
+        B, S, Hq, Hkv, d, scale, causal, window, cp = ctx.meta
+        rep = Hq // Hkv
+        go2 = go.reshape(B * S, Hq * d).contiguous()
+        Gho = torch.empty_like(go2)
+        D = torch.empty(B, Hq, S, device=go.device, dtype=torch.float32)
+        # AttnLRP: uniform rule halves the relevance into P.V; CP-LRP (cp=True) keeps all of it on V
+        ops.attn_bwd_prep(go2, o, Gho, D, B, S, Hq, d, 0.0, 1.0 if cp else 0.5)
+        q_t, Gho_t = ops.transpose_heads(q2, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)
+        dk_h, dv_h = torch.empty_like(q2), torch.empty_like(q2)
+        ops.attn_bwd_dkv(q2, k2, v2, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window)
+        dv = ops.gqa_reduce(dv_h, torch.empty_like(v2), B * S, Hkv, rep, d)
+        if cp:      # CP-LRP: q and k are detached (ref: lxt/efficient/patches.py:245-255)
+            return None, None, dv.view(B, S, Hkv, d), None, None, None, None
+        k_t = ops.transpose_heads(k2, B, S, Hkv, d)
+        dq = torch.empty_like(q2)
+        ops.attn_bwd_dq(q2, k2, v2, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window)
+        dk = ops.gqa_reduce(dk_h, torch.empty_like(k2), B * S, Hkv, rep, d)
+        return dq.view(B, S, Hq, d), dk.view(B, S, Hkv, d), dv.view(B, S, Hkv, d), None, None, None, None

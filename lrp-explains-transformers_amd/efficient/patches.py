@@ -1,0 +1,195 @@
+"""Replacement forwards + patch plumbing: the drop-in surface of lxt.efficient.patches, HIP-backed.
+
+Plumbing keeps the reference's contract (ref: lxt/efficient/patches.py:22-104): patching is
+class-level and process-global, double patching is detected by comparing __module__ and answered
+with a warning + False, there is no un-patch.  The forwards route every LRP-relevant op through
+liblrp_hip.so (efficient/functions.py); they raise if handed CPU tensors (no fallback).
+"""
+from warnings import warn
+
+import torch
+
+from .rules import stop_gradient, divide_gradient, identity_rule_implicit, _act_name
+from .functions import RMSNormFn, LayerNormFn, GatedActFn, LinearFn, AttentionFn
+
+
+def check_already_patched(target_fn, new_fn):
+    """True (with a warning) if target_fn already comes from this package's patch module"""
+    if getattr(target_fn, "__module__", None) == getattr(new_fn, "__module__", object()):
+        warn(f"{getattr(target_fn, '__name__', target_fn)} already patched.")
+        return True
+    return False
+
+
+def patch_method(fn, module, method_name="forward", keep_original=False):
+    """setattr(module, method_name, fn) unless already patched; returns success"""
+    if check_already_patched(getattr(module, method_name), fn):
+        return False
+    if keep_original:
+        setattr(module, f"original_{method_name}", getattr(module, method_name))
+    setattr(module, method_name, fn)
+    return True
+
+
+def replace_module(patched_module, original_module):
+    """copy every public attribute of patched_module onto original_module"""
+    if original_module == patched_module:
+        return False
+    for attr in dir(patched_module):
+        if not attr.startswith("__"):
+            setattr(original_module, attr, getattr(patched_module, attr))
+    return True
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: lxt_amd runs on the HIP device only (no CPU fallback); got a CPU tensor")
+
+
+# ----------------------------------------------------------------------------------- AttnLRP patches
+def rms_norm_forward(self, hidden_states):
+    """identity rule on RMSNorm (ref: lxt/efficient/patches.py:111-123) -- fused HIP row kernel"""
+    _need_cuda(hidden_states, "rms_norm_forward")
+    eps = getattr(self, "variance_epsilon", None)
+    if eps is None:
+        eps = self.eps
+    return RMSNormFn.apply(hidden_states, self.weight, float(eps), 0.0)
+
+
+def gemma3_rms_norm_forward(self, x):
+    """Gemma3RMSNorm: y = x*rstd*(1+w) (ref: lxt/efficient/models/gemma3.py:11-12 patches `_norm`;
+    here the whole forward is one kernel with w_offset = 1)"""
+    _need_cuda(x, "gemma3_rms_norm_forward")
+    return RMSNormFn.apply(x, self.weight, float(self.eps), 1.0)
+
+
+def layer_norm_forward(self, x):
+    """identity rule on LayerNorm's 1/std (ref: lxt/efficient/patches.py:126-142)"""
+    _need_cuda(x, "layer_norm_forward")
+    return LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))
+
+
+def linear_forward(self, x):
+    """nn.Linear on the MFMA GEMM; the W^T copy for the dgrad is cached on the module (frozen
+    weights).  Not patched by the reference (ATen mm there); part of the default maps here so the
+    whole backward runs on liblrp_hip.so."""
+    _need_cuda(x, "linear_forward")
+    wt = getattr(self, "_lrp_weight_t", None)
+    if wt is None or wt.device != self.weight.device or wt.dtype != self.weight.dtype or \
+            getattr(self, "_lrp_weight_ver", None) != self.weight._version:
+        from .. import ops
+        wt = ops.transpose(self.weight.detach())
+        self._lrp_weight_t, self._lrp_weight_ver = wt, self.weight._version
+    return LinearFn.apply(x, self.weight.detach(), self.bias.detach() if self.bias is not None else None, wt)
+
+
+def gated_mlp_forward(self, x):
+    """identity rule on the activation, uniform rule on the product (ref: patches.py:145-157)"""
+    act = _act_name(self.act_fn)
+    if act is None:      # unknown activation: compose from the primitives
+        gate = identity_rule_implicit(self.act_fn, self.gate_proj(x))
+        return self.down_proj(divide_gradient(gate * self.up_proj(x), 2))
+    return self.down_proj(GatedActFn.apply(self.gate_proj(x), self.up_proj(x), act))
+
+
+def mlp_forward(self, x):
+    """identity rule on the activation of a plain 2-layer MLP (ref: patches.py:160-168)"""
+    return self.down_proj(identity_rule_implicit(self.act_fn, self.up_proj(x)))
+
+
+def non_linear_forward(self, x):
+    """ref: patches.py:206-211"""
+    return identity_rule_implicit(self.original_forward, x)
+
+
+def dropout_forward(self, x):
+    """Dropout is the identity while explaining (ref: patches.py:214-220)"""
+    return x
+
+
+def _mask_kind(attention_mask, q_len, module):
+    """-> 'causal' | 'full'.  HF hands either None (sdpa/flash decide by is_causal) or an additive
+    4-D mask; pure causal and all-visible masks are recognised, anything else (padding) is refused."""
+    if attention_mask is None:
+        return "causal" if (getattr(module, "is_causal", False) and q_len > 1) else "full"
+    m = attention_mask
+    if m.dtype == torch.bool:
+        vis_upper = bool(m[..., 0, -1].all()) if m.shape[-1] > 1 else True
+        all_vis = bool(m.all())
+    else:
+        vis_upper = bool((m[..., 0, -1] == 0).all()) if m.shape[-1] > 1 else True
+        all_vis = bool((m == 0).all())
+    if all_vis:
+        return "full"
+    if not vis_upper:
+        tri = torch.ones(m.shape[-2], m.shape[-1], dtype=torch.bool, device=m.device).tril()
+        vis = m if m.dtype == torch.bool else (m == 0)
+        if bool((vis == tri).all()):
+            return "causal"
+    raise NotImplementedError("lxt_amd attention supports causal or all-visible masks (no padding masks yet)")
+
+
+def _make_attention_forward(cp):
+    def attention_forward(module, query, key, value, attention_mask=None, scaling=None, dropout=0.0, **kwargs):
+        # HF contract: query [B,Hq,S,d], key/value [B,Hkv,S,d] -> (attn_output [B,S,Hq,d], None)
+        _need_cuda(query, "attention_forward")
+        B, Hq, S, d = query.shape
+        if key.shape[2] != S:
+            raise NotImplementedError("lxt_amd attention: kv cache / cross attention is outside the explained path")
+        kind = _mask_kind(attention_mask, S, module)
+        window = int(kwargs.get("sliding_window") or 0)
+        if kwargs.get("softcap"):
+            raise NotImplementedError("attention logit soft-capping is not supported")
+        scale = float(scaling) if scaling is not None else d ** -0.5
+        out = AttentionFn.apply(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2), scale,
+                                kind == "causal", window, cp)
+        return out, None
+    return attention_forward
+
+
+def wrap_attention_forward(forward_fn):
+    """kept for API compatibility (ref: patches.py:193-203): the returned callable ignores forward_fn
+    and runs the fused HIP attention whose backward already contains the 1/4, 1/4, 1/2 factors."""
+    return _make_attention_forward(cp=False)
+
+
+def cp_wrap_attention_forward(forward_fn):
+    return _make_attention_forward(cp=True)
+
+
+def _patch_attention(module, cp):
+    new_forward = _make_attention_forward(cp)
+    if hasattr(module, "eager_attention_forward"):
+        if check_already_patched(module.eager_attention_forward, new_forward):
+            return False
+        module.eager_attention_forward = new_forward
+    registry = getattr(module, "ALL_ATTENTION_FUNCTIONS", None)
+    if registry is not None:
+        for key, value in list(registry.items()):
+            if check_already_patched(value, new_forward):
+                return False
+            registry[key] = new_forward
+    return True
+
+
+def patch_attention(module):
+    """replace eager_attention_forward and every entry of HF's process-wide attention registry
+    (ref: patches.py:171-190 wraps them; here they are replaced by the HIP kernel)"""
+    return _patch_attention(module, cp=False)
+
+
+# ------------------------------------------------------------------------------------- CP-LRP patches
+def patch_cp_attention(module):
+    """CP-LRP: no relevance through softmax, i.e. q and k detached (ref: patches.py:228-255)"""
+    return _patch_attention(module, cp=True)
+
+
+def cp_multi_head_attention_forward(self, query, key, value, *args, **kwargs):
+    """ref: patches.py:258-266"""
+    return self.original_forward(stop_gradient(query), stop_gradient(key), value, *args, **kwargs)
+
+
+def cp_gated_mlp_forward(self, x):
+    """CP-LRP: the gate is detached, everything flows through up_proj (ref: patches.py:269-280)"""
+    gate = self.act_fn(stop_gradient(self.gate_proj(x)))
+    return self.down_proj(gate * self.up_proj(x))

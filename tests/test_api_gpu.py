@@ -1,0 +1,229 @@
+"""GPU: the drop-in API surface (lxt_amd.explicit / lxt_amd.efficient) against the reference's own
+test formulas (ref: tests/test_functional.py, tests/test_rules.py, tests/test_modules.py -- restated,
+seeded, on the device) and against the golden fixtures captured from the real reference."""
+import math
+import warnings
+from functools import partial
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.util import nmax, load, t, llama_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lf():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.explicit.functional as m
+    return m
+
+
+def rn(*s, seed=0, rg=True):
+    x = torch.randn(*s, generator=torch.Generator().manual_seed(seed)).cuda()
+    return x.requires_grad_() if rg else x
+
+
+# ------------------------------------------------------------------ ref: tests/test_functional.py
+def test_softmax(lf):
+    x, R = rn(16, 10, 32, seed=1), rn(16, 10, 32, seed=2, rg=False)
+    y_gt = F.softmax(x, -1)
+    gt = x.float() * (R - y_gt * R.sum(-1, keepdim=True))
+    for inplace in (False, True):
+        y = lf.softmax(x, -1, torch.float32, 1.0, inplace)
+        assert torch.allclose(y, y_gt, atol=1e-6)
+        rel, = torch.autograd.grad(y, x, R)
+        assert torch.allclose(gt, rel, rtol=0, atol=1e-5)
+    # non-last dim + temperature
+    y = lf.softmax(x, 1, None, 2.0)
+    assert torch.allclose(y, F.softmax(x / 2.0, 1), atol=1e-6)
+
+
+def test_matmul(lf):
+    eps = 1e-9
+    a, b, R = rn(2, 10, 32, seed=1), rn(2, 32, 5, seed=2), rn(2, 10, 5, seed=3, rg=False)
+    y_gt = torch.matmul(a, b)
+    ga = torch.einsum("bji, bip, bjp -> bji", a, b, R / (2 * y_gt + eps))
+    gb = torch.einsum("bji, bip, bjp -> bip", a, b, R / (2 * y_gt + eps))
+    y = lf.matmul(a, b, False, eps)
+    assert torch.allclose(y, y_gt, atol=1e-5)
+    ra, rb = torch.autograd.grad(y, (a, b), R)
+    # same z on both sides is what makes this comparison well conditioned: use the kernel's own z
+    ga2 = torch.einsum("bji, bip, bjp -> bji", a, b, R / (2 * y.detach() + eps))
+    gb2 = torch.einsum("bji, bip, bjp -> bip", a, b, R / (2 * y.detach() + eps))
+    assert nmax(ra, ga2) < 1e-5 and nmax(rb, gb2) < 1e-5
+    assert nmax(ra, ga) < 1e-2 and nmax(rb, gb) < 1e-2          # random R: ill-conditioned wrt z (SURVEY finding 5)
+
+
+def test_linear(lf):
+    eps = 1e-9
+    x, bias, W, R = rn(16, 10, seed=1), rn(5, seed=2, rg=False), rn(5, 10, seed=3), rn(16, 5, seed=4, rg=False)
+    y = lf.linear_epsilon(x, W, bias, eps)
+    assert torch.allclose(y, F.linear(x, W, bias), atol=1e-5)
+    rel, = torch.autograd.grad(y, x, R)
+    gt = torch.einsum("ji, bi, bj -> bi", W, x, R / (y.detach() + eps))
+    assert nmax(rel, gt) < 1e-5
+
+
+def test_sum_mean_normalize(lf):
+    eps = 1e-9
+    a, b, R = rn(16, 10, 32, seed=1), rn(16, 10, 32, seed=2), rn(16, 10, 32, seed=3, rg=False)
+    y = lf.add2(a, b, False, eps)
+    ra, rb = torch.autograd.grad(y, (a, b), R)
+    assert nmax(ra, a * (R / (a + b + eps))) < 1e-5 and nmax(rb, b * (R / (a + b + eps))) < 1e-5
+    m = rn(1, 8, 32, seed=4)
+    Rm = rn(1, 8, seed=5, rg=False)
+    gt = m * (Rm.unsqueeze(-1) / (m.sum(-1).unsqueeze(-1) + eps))
+    r1, = torch.autograd.grad(lf.mean(m, -1, True, eps), m, Rm.unsqueeze(-1))
+    r2, = torch.autograd.grad(lf.mean(m, -1, False, eps), m, Rm)
+    assert nmax(r1, gt) < 1e-5 and nmax(r2, gt) < 1e-5
+    x, r = rn(1, 4, 32, seed=6), rn(1, 4, 32, seed=7, rg=False)
+    lf.rms_norm_identity(x, rn(32, seed=8, rg=False), 1e-9).backward(r)
+    assert torch.allclose(x.grad, r)
+    x.grad = None
+    lf.normalize(x, p=2, dim=1).backward(r)
+    assert torch.allclose(x.grad, r)
+    # mul2: uniform split over the operands that require grad
+    Ra, Rb = torch.autograd.grad(lf.mul2(a, b), (a, b), R)
+    assert torch.allclose(Ra, R / 2) and torch.allclose(Rb, R / 2)
+    Ra, = torch.autograd.grad(lf.mul2(a, b.detach()), (a,), R)
+    assert torch.allclose(Ra, R)
+
+
+def test_layernorm_golden(lf):
+    fx = load("rules.npz")
+    x, w, b, g = (t(fx[k]).cuda() for k in ("ln_x", "ln_w", "ln_b", "ln_g"))
+    x.requires_grad_()
+    y = lf.layer_norm(x, w, b, 1e-12)
+    assert nmax(y, fx["ln_y"]) < 1e-5
+    rel, = torch.autograd.grad(y, x, y.detach() * g)
+    assert nmax(rel, fx["ln_Rin"]) < 5e-5
+
+
+# ---------------------------------------------------------------------- ref: tests/test_rules.py
+def test_epsilon_rule_equals_functional(lf):
+    import lxt_amd.explicit.rules as rules
+    x, W, bias, R = rn(1, 8, seed=1), rn(8, 8, seed=2, rg=False), rn(8, seed=3, rg=False), rn(1, 8, seed=4, rg=False)
+    y = lf.linear_epsilon(x, W, bias)
+    gt, = torch.autograd.grad(y, x, R)
+    y2 = rules.EpsilonRule(partial(F.linear, weight=W, bias=bias))(x)       # generic VJP path
+    r2, = torch.autograd.grad(y2, x, R)
+    assert torch.allclose(gt, r2, rtol=0, atol=1e-3)
+    lin = nn.Linear(8, 8).cuda()
+    y3 = rules.EpsilonRule(lin, 1e-6)(x)                                    # fused nn.Linear path
+    y4 = lf.linear_epsilon(x, lin.weight, lin.bias, 1e-6)
+    assert torch.equal(y3, y4)
+    # uniform / identity / stop rules
+    a, b = rn(4, 6, seed=5), rn(4, 6, seed=6)
+
+    class Mul(nn.Module):
+        def forward(self, p, q):
+            return p * q
+    Ra, Rb = torch.autograd.grad(rules.UniformRule(Mul())(a, b), (a, b), R[:, :6].expand(4, 6).contiguous())
+    assert torch.allclose(Ra, Rb)
+    z = rules.IdentityRule(nn.SiLU())(a)
+    ri, = torch.autograd.grad(z, a, torch.ones_like(z))
+    assert torch.equal(ri, torch.ones_like(z))
+
+
+def test_uniform_epsilon_golden(lf):
+    import lxt_amd.explicit.rules as rules
+    fx = load("rules.npz")
+    p, v, g = (t(fx[k]).cuda().requires_grad_() for k in ("pv_p", "pv_v", "pv_g"))
+
+    class AV(nn.Module):
+        def forward(self, a_, v_):
+            return torch.matmul(a_, v_)
+    o = rules.UniformEpsilonRule(AV())(p, v)
+    Rp, Rv = torch.autograd.grad(o, (p, v), o.detach() * g.detach())
+    assert nmax(Rp, fx["pv_Rp"]) < 2e-5 and nmax(Rv, fx["pv_Rv"]) < 2e-5
+
+
+# -------------------------------------------------------------------- ref: tests/test_modules.py
+def test_modules_and_composite(lf):
+    import lxt_amd.explicit.modules as lm
+    from lxt_amd.explicit import Composite
+    x = rn(4, 50, 96, seed=1, rg=False)
+    ln = nn.LayerNorm(96).cuda()
+    nn.init.normal_(ln.weight); nn.init.normal_(ln.bias)
+    new = lm.INIT_MODULE_MAPPING[lm.LayerNormEpsilon](ln, lm.LayerNormEpsilon)
+    assert torch.allclose(new(x), ln(x), atol=1e-5)
+    lin = nn.Linear(96, 40).cuda()
+    newl = lm.INIT_MODULE_MAPPING[lm.LinearEpsilon](lin, lm.LinearEpsilon)
+    assert torch.allclose(newl(x), lin(x), atol=1e-5) and newl.weight is lin.weight
+    model = nn.Sequential(nn.Linear(96, 64), nn.LayerNorm(64), nn.Linear(64, 8)).cuda()
+    ref_out = model(x)
+    comp = Composite({nn.Linear: lm.LinearEpsilon, nn.LayerNorm: lm.LayerNormEpsilon})
+    comp.register(model)
+    assert isinstance(model[0], lm.LinearEpsilon) and all(not p.requires_grad for p in model.parameters())
+    xin = x.clone().requires_grad_()
+    out = model(xin)
+    assert torch.allclose(out, ref_out, atol=1e-4)
+    out[0, 0, 3].backward(out[0, 0, 3].detach())          # explicit protocol: seed with the logit
+    assert torch.isfinite(xin.grad).all() and xin.grad[1:].abs().max() == 0
+    comp.remove()
+    assert type(model[0]) is nn.Linear
+
+
+# --------------------------------------------------------------------------- efficient drop-in path
+def _hf_llama(cfg, W, attn_impl):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    hc = LlamaConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["inter"], num_hidden_layers=cfg["n_layers"],
+                     num_attention_heads=cfg["n_heads"], num_key_value_heads=cfg["n_kv"], head_dim=cfg["head_dim"],
+                     vocab_size=cfg["vocab"], rms_norm_eps=cfg["rms_eps"], max_position_embeddings=4096,
+                     rope_parameters=dict(rope_type="default", rope_theta=cfg["rope_theta"]), tie_word_embeddings=False,
+                     attn_implementation=attn_impl)
+    model = LlamaForCausalLM(hc).eval()
+    with torch.no_grad():
+        model.model.embed_tokens.weight.copy_(W["embed"]); model.model.norm.weight.copy_(W["norm"])
+        model.lm_head.weight.copy_(W["lm_head"])
+        for L, Lw in zip(model.model.layers, W["layers"]):
+            L.input_layernorm.weight.copy_(Lw["ln1"]); L.post_attention_layernorm.weight.copy_(Lw["ln2"])
+            L.self_attn.q_proj.weight.copy_(Lw["wq"]); L.self_attn.k_proj.weight.copy_(Lw["wk"])
+            L.self_attn.v_proj.weight.copy_(Lw["wv"]); L.self_attn.o_proj.weight.copy_(Lw["wo"])
+            L.mlp.gate_proj.weight.copy_(Lw["wg"]); L.mlp.up_proj.weight.copy_(Lw["wu"]); L.mlp.down_proj.weight.copy_(Lw["wd"])
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.cuda()
+
+
+@pytest.mark.parametrize("name", ["mid", "d128"])
+def test_monkey_patch_llama_user_protocol(name):
+    """the reference's quickstart protocol, unchanged, on a HF model patched by lxt_amd:
+    model(inputs_embeds=e.requires_grad_()).logits[0,-1,i].backward(); R = (e*e.grad).sum(-1)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from transformers.models.llama import modeling_llama
+    from lxt_amd.efficient import monkey_patch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_llama)
+        monkey_patch(modeling_llama)                           # idempotent: warns, does not raise
+    cfg, W, ids, fx = llama_case(name)
+    for impl in ("eager", "sdpa"):                             # both dispatch to the HIP attention now
+        model = _hf_llama(cfg, W, impl)
+        e = model.get_input_embeddings()(ids[None].cuda()).requires_grad_()
+        logits = model(inputs_embeds=e, use_cache=False).logits
+        idx = int(logits[0, -1].argmax())
+        assert idx == int(fx["idx"])
+        logits[0, -1, idx].backward()
+        R = (e * e.grad).float().sum(-1)[0]
+        err = nmax(R, fx["eff_R_tok"])
+        print(f"[monkey_patch {name}/{impl}] tok vs reference lxt.efficient {err:.2e}")
+        assert err < 1e-4
+        # engine == drop-in path (same kernels, different host sequencing)
+    import lxt_amd.engine as E
+    eng = E.LlamaLRP.from_hf(model, mode="efficient", max_seq=512)
+    out = eng.explain(ids[None])
+    assert nmax(out["R_tok"][0], R) < 1e-5
+
+
+def test_unsupported_module_raises():
+    import types
+    from lxt_amd.efficient import monkey_patch
+    with pytest.raises(ValueError, match="not yet supported"):
+        monkey_patch(types.ModuleType("some.random.module"))
