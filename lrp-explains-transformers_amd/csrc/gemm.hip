@@ -296,6 +296,175 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
     return lrp_check_launch();
 }
 
+
+// =================================================================================================
+// Deep-pipelined variant: K step = 64 BYTES per row (32 bf16 / 16 fp32, ONE MFMA macro step), FOUR
+// LDS stages, loads issued three stages ahead and retired with a COUNTED s_waitcnt vmcnt(N) + raw
+// s_barrier (a __syncthreads() would drain the LDS-DMA queue to zero at every barrier and leave only
+// one K step of latency cover -- the PMC profile of the 2-stage kernel shows 37 % of wave cycles
+// parked in waitcnt/barrier).  64-byte rows: swizzle slot = chunk ^ ((row>>2)&3), conflict-free for
+// ds_read_b128 (rows r, r+4, r+8, r+12 share a 16-bank group and get four distinct chunks).
+// One wave instruction of global_load_lds deposits 16 rows x 64 B; lane l -> row l>>2, slot l&3.
+// =================================================================================================
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+    int tiles_m, int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int RB = 64;                            // bytes of K per stage and per row
+    constexpr int EPC = 16 / sizeof(T), KE = RB / sizeof(T);
+    constexpr int SM = TBM / WM, SN = TBN / WN, FM = SM / 16, FN = SN / 16;
+    constexpr int GA = TBM / 16 / NW, GB = TBN / 16 / NW;     // 1-KiB groups (16 rows) per wave per operand
+    constexpr int NST = 4, STAGE = (TBM + TBN) * RB;
+    constexpr int LPS = GA + GB;                      // loads per stage per wave
+    static_assert(TBM % (16 * NW) == 0 && TBN % (16 * NW) == 0, "tile rows must split over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    grouped_tile(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    A += (int64_t)blockIdx.y * sA;
+    B += (int64_t)blockIdx.y * sB;
+    C += (int64_t)blockIdx.y * sC;
+    const int nst = K / KE;
+
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const T* pa[GA];
+    const T* pb[GB];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        int r = m0 + (wave * GA + i) * 16 + lrow;
+        r = r < M ? r : M - 1;
+        pa[i] = A + (int64_t)r * lda + lchunk * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        int r = n0 + (wave * GB + i) * 16 + lrow;
+        r = r < N ? r : N - 1;
+        pb[i] = B + (int64_t)r * ldb + lchunk * EPC;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto stage = [&](int st) {
+        char* sa = smem + (st & (NST - 1)) * STAGE + (wave * GA) * 1024;
+        char* sb = smem + (st & (NST - 1)) * STAGE + TBM * RB + (wave * GB) * 1024;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)st * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)st * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: stages 0..2 issued, stages 0 and 1 retired (only stage 2 may still be in flight)
+    stage(0);
+    if (nst > 1) stage(1);
+    if (nst > 2) stage(2);
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef typename Mma16<T>::frag frag_t;
+    const int foff = (fq ^ ((frow >> 2) & 3)) << 4;
+    auto read_frags = [&](frag_t(&fa)[FM], frag_t(&fb)[FN], int st) {
+        const char* pas = smem + (st & (NST - 1)) * STAGE + (wm * SM) * RB;
+        const char* pbs = smem + (st & (NST - 1)) * STAGE + TBM * RB + (wn * SN) * RB;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * RB + foff);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(pbs + (j * 16 + frow) * RB + foff);
+    };
+    auto mma_all = [&](const frag_t(&fa)[FM], const frag_t(&fb)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+    };
+    // end of stage st: retire everything through stage st+2 (only st+3 may stay in flight), then barrier
+    auto retire = [&](int st) {
+        if (st + 3 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // software pipeline over two register sets: the fragments of stage st+1 are read from LDS while the
+    // MFMAs of stage st run, so the matrix pipe never waits for ds_read latency at a stage boundary
+    frag_t a0[FM], b0[FN], a1[FM], b1[FN];
+    read_frags(a0, b0, 0);
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 3 < nst) stage(st + 3);
+        if (st + 1 < nst) read_frags(a1, b1, st + 1);
+        mma_all(a0, b0);
+        retire(st);
+        if (st + 1 >= nst) break;
+        if (st + 4 < nst) stage(st + 4);
+        if (st + 2 < nst) read_frags(a0, b0, st + 2);
+        mma_all(a1, b1);
+        retire(st + 1);
+    }
+
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int gm = m0 + wm * SM + i * 16 + frow;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int gn = n0 + wn * SN + j * 16 + fq * 4;
+            if (gn >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+            }
+            TO* dst = C + (int64_t)gm * ldc + gn;
+            if (vec_ok && gn + 3 < N) {
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) dst[r] = from_f32<TO>(v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+int launch_pipe(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
+    dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
+    const size_t lds = 4 * (size_t)(TBM + TBN) * 64;
+    auto kern = gemm_nt_pipe_kernel<T, TO, TBM, TBN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
+                       sA, sB, sC, tiles_m, tiles_n);
+    return lrp_check_launch();
+}
+
 // tile selection: the largest tile that still gives ~one workgroup per CU (256 CUs)
 template <typename T, typename TO>
 int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -305,6 +474,8 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // measured on MI355X (profiles/r01_gemm_tiles.txt): 256x256 wins once it yields >= ~190 tiles
     // (every CU busy), 128x128 below that; 256x128 never wins and is kept as a dev knob only
     if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 3 : 1;
+    if (cfg == 4) return launch_pipe<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 5) return launch_pipe<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 3) return launch_glds<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 2) return launch_glds<T, TO, 256, 128, 4, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     return launch_glds<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);

@@ -107,26 +107,39 @@ def dropout_forward(self, x):
     return x
 
 
-def _mask_kind(attention_mask, q_len, module):
-    """-> 'causal' | 'full'.  HF hands either None (sdpa/flash decide by is_causal) or an additive
-    4-D mask; pure causal and all-visible masks are recognised, anything else (padding) is refused."""
+_MASK_VERDICTS = {}
+
+
+def _mask_kind(attention_mask, q_len, module, window=0):
+    """-> 'causal' | 'full'.  HF hands either None (sdpa/flash decide by is_causal) or an additive / boolean
+    4-D mask; the mask is checked ONCE per tensor against the pattern the kernel implements (all-visible,
+    causal, or causal with the layer's sliding window); anything else (padding) is refused.  The verdict
+    is cached by tensor identity so a forward costs one host sync per distinct mask, not one per layer."""
     if attention_mask is None:
         return "causal" if (getattr(module, "is_causal", False) and q_len > 1) else "full"
     m = attention_mask
-    if m.dtype == torch.bool:
-        vis_upper = bool(m[..., 0, -1].all()) if m.shape[-1] > 1 else True
-        all_vis = bool(m.all())
+    key = (m.data_ptr(), tuple(m.shape), m._version, int(window))
+    hit = _MASK_VERDICTS.get(key)
+    if hit is not None:
+        return hit
+    vis = m if m.dtype == torch.bool else (m == 0)
+    S, Sk = m.shape[-2], m.shape[-1]
+    i = torch.arange(S, device=m.device)[:, None]
+    j = torch.arange(Sk, device=m.device)[None, :]
+    causal = j <= i
+    if window > 0:
+        causal = causal & (j > i - window)
+    if bool(vis.all()) and not window:
+        kind = "full"
+    elif bool((vis == causal).all()):
+        kind = "causal"
     else:
-        vis_upper = bool((m[..., 0, -1] == 0).all()) if m.shape[-1] > 1 else True
-        all_vis = bool((m == 0).all())
-    if all_vis:
-        return "full"
-    if not vis_upper:
-        tri = torch.ones(m.shape[-2], m.shape[-1], dtype=torch.bool, device=m.device).tril()
-        vis = m if m.dtype == torch.bool else (m == 0)
-        if bool((vis == tri).all()):
-            return "causal"
-    raise NotImplementedError("lxt_amd attention supports causal or all-visible masks (no padding masks yet)")
+        raise NotImplementedError("lxt_amd attention supports all-visible, causal and sliding-window-causal masks "
+                                  "(no padding masks yet)")
+    if len(_MASK_VERDICTS) > 64:
+        _MASK_VERDICTS.clear()
+    _MASK_VERDICTS[key] = kind
+    return kind
 
 
 def _make_attention_forward(cp):
@@ -136,8 +149,10 @@ def _make_attention_forward(cp):
         B, Hq, S, d = query.shape
         if key.shape[2] != S:
             raise NotImplementedError("lxt_amd attention: kv cache / cross attention is outside the explained path")
-        kind = _mask_kind(attention_mask, S, module)
         window = int(kwargs.get("sliding_window") or 0)
+        if window >= S:
+            window = 0
+        kind = _mask_kind(attention_mask, S, module, window)
         if kwargs.get("softcap"):
             raise NotImplementedError("attention logit soft-capping is not supported")
         scale = float(scaling) if scaling is not None else d ** -0.5

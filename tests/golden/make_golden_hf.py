@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the DROP-IN path on HuggingFace models, generated FROM THE REAL REFERENCE
+(build container only):   python tests/golden/make_golden_hf.py
+
+  bert_base.npz    BASELINE config 2: HF BertForSequenceClassification(BertConfig(num_labels=2)),
+                   random init (manual_seed 0), S=128, fp32; relevance from the reference's own
+                   primitives (lxt.efficient.rules / patches) spliced into HF's modeling_bert with a
+                   custom patch_map -- the reference's vendored BERT does not run under transformers 5.x
+                   (SURVEY.md finding 9), its marked edit lines are lxt/efficient/models/bert.py:
+                   339,380,476-488,581,790,806.
+  gemma3_tiny.npz  Gemma3ForCausalLM (text tower, sliding + global layers, q/k-norm, (1+w) RMSNorm,
+                   gelu-tanh) through the reference's own default map lxt/efficient/models/gemma3.py.
+Each model is built from a seed (weights are not stored; a checksum is), the oracle
+oracle/hf_efficient.py is asserted against the reference here.
+"""
+import os
+import sys
+import warnings
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+sys.path.insert(0, "/root/reference")
+warnings.simplefilter("ignore")
+
+from oracle import hf_efficient as oh          # noqa: E402
+from tests.golden.hf_models import build_bert, build_gemma3, wsum  # noqa: E402
+
+
+def nmax(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def bert():
+    import lxt.efficient.patches as lp
+    from lxt.efficient.rules import identity_rule_implicit
+    from lxt.efficient import monkey_patch
+    from transformers.models.bert import modeling_bert
+    from transformers.models.bert.modeling_bert import BertIntermediate, BertPooler
+    ids = torch.randint(0, 30522, (128,), generator=torch.Generator().manual_seed(1234))
+    # ---- oracle first (instance level, nothing global yet)
+    m_or = oh.patch_instance(build_bert(seed=0, attn="eager"))
+    o32 = oh.explain_classifier(m_or, ids)
+    m64 = oh.patch_instance(build_bert(seed=0, attn="eager").double())
+    o64 = oh.explain_classifier(m64, ids, target=o32["idx"])
+    # ---- the real reference primitives, custom patch map on HF's own BERT
+    def inter_fwd(self, h):
+        return identity_rule_implicit(self.intermediate_act_fn, self.dense(h))
+
+    def pool_fwd(self, h):
+        return identity_rule_implicit(self.activation, self.dense(h[:, 0]))
+    pm = {torch.nn.LayerNorm: partial(lp.patch_method, lp.layer_norm_forward),
+          torch.nn.Dropout: partial(lp.patch_method, lp.dropout_forward),
+          BertIntermediate: partial(lp.patch_method, inter_fwd), BertPooler: partial(lp.patch_method, pool_fwd),
+          modeling_bert: lp.patch_attention}
+    monkey_patch(modeling_bert, pm)
+    out = {}
+    for impl in ("eager", "sdpa"):
+        model = build_bert(seed=0, attn=impl)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        e = model.get_input_embeddings()(ids[None]).requires_grad_()
+        logits = model(inputs_embeds=e).logits[0]
+        idx = int(logits.argmax())
+        logits[idx].backward()
+        out[impl] = dict(idx=idx, logit=float(logits[idx]), R=(e * e.grad)[0].sum(-1).detach())
+    ref = out["eager"]
+    print(f"  [bert] idx={ref['idx']} logit={ref['logit']:.6f} sumR={float(ref['R'].sum()):.6f}  eager-vs-sdpa {nmax(out['sdpa']['R'], ref['R']):.2e}")
+    print(f"     oracle fp32 vs reference {nmax(o32['R_tok'], ref['R']):.2e} ; oracle fp64 vs reference {nmax(o64['R_tok'], ref['R']):.2e}")
+    assert o32["idx"] == ref["idx"] and nmax(o32["R_tok"], ref["R"]) < 2e-5
+    np.savez_compressed(os.path.join(HERE, "bert_base.npz"), ids=ids.numpy(), idx=ref["idx"], logit=ref["logit"],
+                        R_tok=ref["R"].numpy(), R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build_bert(seed=0)), seed=0, S=128)
+
+
+def gemma3():
+    from lxt.efficient import monkey_patch
+    from transformers.models.gemma3 import modeling_gemma3
+    ids = torch.randint(0, 512, (96,), generator=torch.Generator().manual_seed(77))
+    m_or = oh.patch_instance(build_gemma3(seed=3, attn="eager"))
+    o32 = oh.explain_causal_lm(m_or, ids)
+    m64 = oh.patch_instance(build_gemma3(seed=3, attn="eager").double())
+    o64 = oh.explain_causal_lm(m64, ids, target=o32["idx"])
+    monkey_patch(modeling_gemma3)
+    model = build_gemma3(seed=3, attn="eager")
+    for p in model.parameters():
+        p.requires_grad_(False)
+    e = model.get_input_embeddings()(ids[None]).requires_grad_()
+    last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+    idx = int(last.argmax())
+    last[idx].backward()
+    R = (e * e.grad)[0].sum(-1).detach()
+    print(f"  [gemma3] idx={idx} logit={float(last[idx]):.6f} sumR={float(R.sum()):.6f}")
+    print(f"     oracle fp32 vs reference {nmax(o32['R_tok'], R):.2e} ; oracle fp64 vs reference {nmax(o64['R_tok'], R):.2e}")
+    assert o32["idx"] == idx and nmax(o32["R_tok"], R) < 2e-5
+    np.savez_compressed(os.path.join(HERE, "gemma3_tiny.npz"), ids=ids.numpy(), idx=idx, logit=float(last[idx]), R_tok=R.numpy(),
+                        R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build_gemma3(seed=3)), seed=3, S=96)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    # lxt's patches are process-global: one model family per process
+    if which == "all":
+        import subprocess
+        for w in ("bert", "gemma3"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
+    elif which == "bert":
+        bert()
+    else:
+        gemma3()

@@ -36,9 +36,13 @@ WORKER = textwrap.dedent("""
 def test_sharding_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
+    import socket
+    with socket.socket() as sk:                       # a free port: a fixed one collides with TIME_WAIT leftovers
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script)]
+           "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -100,7 +100,9 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
     L = [(2048, 6144, 4096), (2048, 4096, 4096), (2048, 28672, 4096), (2048, 4096, 14336), (2048, 14336, 4096), (2048, 4096, 28672),
          (2048, 4096, 6144), (8192, 4096, 4096), (8192, 28672, 4096)]
-    if "gemm" in a.what:
+    if "onegemm" in a.what:
+        bench_gemm(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
+    elif "gemm" in a.what:
         bench_gemm(torch.bfloat16, L)
         bench_gemm(torch.float32, [(2048, 4096, 4096), (2048, 14336, 4096)])
     if "attn" in a.what:
