@@ -99,6 +99,12 @@ def _dropout_forward(self, x):
     return x
 
 
+def _linear_forward(self, x):
+    # nn.Linear is untouched by the reference (plain F.linear); pinned per instance so the oracle model stays
+    # on the host even after lxt_amd's class-level Linear patch (HIP GEMM) is active in the same process
+    return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
 def lrp_eager_attention(module, query, key, value, attention_mask=None, scaling=None, dropout=0.0, **kwargs):
     """HF eager attention with the AttnLRP factors: grad(q)/4, grad(k)/4, grad(v)/2."""
     query, key, value = divide_gradient(query, 4), divide_gradient(key, 4), divide_gradient(value, 2)
@@ -131,7 +137,9 @@ def patch_instance(model):
         cfg._attn_implementation = "lrp_oracle"
     for m in model.modules():
         name = type(m).__name__
-        if isinstance(m, nn.Dropout):
+        if isinstance(m, nn.Linear):
+            m.forward = types.MethodType(_linear_forward, m)
+        elif isinstance(m, nn.Dropout):
             m.forward = types.MethodType(_dropout_forward, m)
         elif isinstance(m, nn.LayerNorm):
             m.forward = types.MethodType(_layer_norm_forward, m)
