@@ -71,6 +71,18 @@ def cpu_baseline(cfg, S, budget_s=30.0):
                        f"{t_layer:.2f} s measured, extrapolated x{cfg['n_layers']}")
 
 
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r01_gemm_traffic.json); None if absent.
+    PMC counters cannot be collected inside the timed run itself."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +168,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (Linear forward + eps-rule dgrad)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
-                         "gemm_time_frac_of_step": secs / elapsed, "traffic": None},
+                         "gemm_time_frac_of_step": secs / elapsed, "traffic": pmc_traffic()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
