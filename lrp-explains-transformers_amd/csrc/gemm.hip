@@ -155,8 +155,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(
 // Requires K to be a multiple of the 128-byte K step; M, N arbitrary (row indices are clamped, the
 // duplicated rows only feed outputs that are never stored).
 // =================================================================================================
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_nt_glds_kernel(
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt_glds_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
     int tiles_m, int tiles_n) {
@@ -236,10 +236,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_nt_
             for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * KB + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(pbs + (j * 16 + frow) * KB + off);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         cur ^= 1;
@@ -279,13 +281,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 2)) void gemm_nt_
     }
 }
 
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false>
 int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
     dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
     const size_t lds = 2 * (size_t)(TBM + TBN) * KB;
-    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN>;
+    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN, PRIO>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -472,8 +474,13 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     auto ntiles = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     int cfg = force;
     // measured on MI355X (profiles/r01_gemm_tiles.txt): 256x256 wins once it yields >= ~190 tiles
-    // (every CU busy), 128x128 below that; 256x128 never wins and is kept as a dev knob only
-    if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 3 : 1;
+    // (every CU busy), 128x128 below that; 256x128 never wins and is kept as a dev knob only.
+    // 7 = 256x256 with 16 waves (4x4, 64x64 per wave, 4 waves/SIMD): +1..5 % over the 8-wave form (3) --
+    // the PMC profile shows the 8-wave kernel parked in waitcnt/barrier 37 % of its wave cycles while the
+    // LDS is only 21 % busy, so more resident waves buy more than the larger wave tile saves.
+    if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 7 : 1;
+    if (cfg == 6) return launch_glds<T, TO, 256, 256, 2, 4, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 7) return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 4) return launch_pipe<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 5) return launch_pipe<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 3) return launch_glds<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);

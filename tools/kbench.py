@@ -36,6 +36,17 @@ def bench_gemm(dtype, shapes):
               f"   | hipBLASLt (torch) {tt*1e6:9.1f} us {2*M*N*K/tt/1e12:8.1f} TF/s", flush=True)
 
 
+def bench_gemm_hot(dtype, shapes):
+    """cache-hot variant: every row of A and B aliases row 0 (row stride 0) -> all global loads hit L1/L2;
+    isolates the in-CU efficiency (LDS + MFMA + barriers) from the memory system"""
+    for (M, N, K) in shapes:
+        a = torch.randn(1, K, device="cuda").to(dtype).expand(M, K)
+        b = (torch.randn(1, K, device="cuda") * K ** -0.5).to(dtype).expand(N, K)
+        out = torch.empty(M, N, device="cuda", dtype=dtype)
+        t = timeit(lambda: ops.gemm_nt_2d(a, b, out))
+        print(f"gemm-hot {str(dtype)[6:]:8s} M={M:5d} N={N:6d} K={K:6d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+
+
 def bench_attn(dtype, B, S, Hq, Hkv, d):
     q = torch.randn(B * S, Hq * d, device="cuda").to(dtype)
     k = torch.randn(B * S, Hkv * d, device="cuda").to(dtype)
@@ -100,6 +111,9 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
     L = [(2048, 6144, 4096), (2048, 4096, 4096), (2048, 28672, 4096), (2048, 4096, 14336), (2048, 14336, 4096), (2048, 4096, 28672),
          (2048, 4096, 6144), (8192, 4096, 4096), (8192, 28672, 4096)]
+    if "hot" in a.what:
+        bench_gemm(torch.bfloat16, [(8192, 4096, 4096)])
+        bench_gemm_hot(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
     if "onegemm" in a.what:
         bench_gemm(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
     elif "gemm" in a.what:
