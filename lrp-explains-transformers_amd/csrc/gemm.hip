@@ -155,7 +155,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(
 // Requires K to be a multiple of the 128-byte K step; M, N arbitrary (row indices are clamped, the
 // duplicated rows only feed outputs that are never stored).
 // =================================================================================================
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false>
+// PF = L2 prefetch: all the workgroups of an XCD walk K in lockstep, so every staging load either
+// misses the XCD's L2 or merges with a miss in flight -- the whole K step pays fabric latency (~2 us)
+// with only one K step (~1.7 us) of cover.  With PF each wave also issues ONE 4-byte-per-lane LDS-DMA
+// load that touches every 128-byte line of the tile AFTER next (result dumped in a scratch LDS row,
+// never read): the line is pulled into L2 a full K step before its real staging load, which then
+// hits.  The wait at the end of a K step is a counted vmcnt(1) (the prefetch stays in flight) + raw
+// s_barrier instead of __syncthreads() (which would drain it).
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt_glds_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
@@ -218,14 +225,43 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // L2 prefetch: thread i touches the 128-byte line of tile row (i mod (TBM+TBN)) -- one K step of one
+    // row IS one line when lda*sizeof(T) is a multiple of 128 (else it merely prefetches a neighbour)
+    const T* ppf = nullptr;
+    char* pf_scratch = smem + 2 * STAGE + wave * 256;
+    if constexpr (PF) {
+        const int r = tid % (TBM + TBN);
+        if (r < TBM) { int gr = m0 + r; gr = gr < M ? gr : M - 1; ppf = A + (int64_t)gr * lda; }
+        else { int gr = n0 + r - TBM; gr = gr < N ? gr : N - 1; ppf = B + (int64_t)gr * ldb; }
+    }
+    auto prefetch = [&](int kt) {
+        if constexpr (PF) {
+            const int k = kt < nkt ? kt : nkt - 1;      // always issue exactly one (keeps the vmcnt arithmetic uniform)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ppf + (int64_t)k * KE), (lds_ptr_t)pf_scratch, 4, 0, 0);
+        }
+    };
+    auto step_sync = [&]() {
+        if constexpr (PF) {
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+
     stage(0, 0);
-    __syncthreads();
+    prefetch(1);
+    step_sync();
 
     const int frow = lane & 15, fq = lane >> 4;
     typedef typename Mma16<T>::frag frag_t;
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+        else if constexpr (PF) {                        // keep the in-order queue shape: the older prefetch must retire
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        prefetch(kt + 2);
         const char* pas = smem + cur * STAGE + (wm * SM) * KB;
         const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
 #pragma unroll
@@ -243,9 +279,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
                 for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();
+        step_sync();
         cur ^= 1;
     }
+    if constexpr (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
@@ -281,13 +318,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     }
 }
 
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false>
 int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
     dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
-    const size_t lds = 2 * (size_t)(TBM + TBN) * KB;
-    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN, PRIO>;
+    const size_t lds = 2 * (size_t)(TBM + TBN) * KB + (PF ? 256 * WM * WN : 0);
+    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN, PRIO, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -479,6 +516,9 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // the PMC profile shows the 8-wave kernel parked in waitcnt/barrier 37 % of its wave cycles while the
     // LDS is only 21 % busy, so more resident waves buy more than the larger wave tile saves.
     if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 7 : 1;
+    if (cfg == 8) return launch_glds<T, TO, 256, 256, 4, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 10) return launch_glds<T, TO, 256, 256, 2, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 11) return launch_glds<T, TO, 128, 128, 2, 2, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 6) return launch_glds<T, TO, 256, 256, 2, 4, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 7) return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 4) return launch_pipe<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);

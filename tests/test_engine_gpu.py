@@ -77,3 +77,43 @@ def test_conservation_large(eng_mod):
     assert torch.isfinite(out["R_tok"]).all()
     assert nmax(out["R_tok"].sum(1), out["layer_R"][0]) < 1e-4
     assert (out["R_tok"].sum(1).abs() < 10 * out["logit"].abs() + 1).all()
+
+
+@pytest.mark.parametrize("S,B", [(37, 1), (100, 3), (333, 2)])
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_llama_ragged_lengths(eng_mod, S, B, mode):
+    """sequence lengths that are not multiples of any tile (attention tails, GEMM M tails), batches > 1"""
+    cfg = dict(hidden=256, inter=512, n_layers=2, n_heads=8, n_kv=2, head_dim=32, vocab=512, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=302)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512)
+    ids = torch.randint(0, 512, (B, S), generator=torch.Generator().manual_seed(S))
+    out = eng.explain(ids)
+    for b in range(B):
+        ref = ol.explain(cfg, W, ids=ids[b], target=int(out["idx"][b]), mode=mode, dtype=torch.float64)
+        ref32 = ol.explain(cfg, W, ids=ids[b], target=int(out["idx"][b]), mode=mode, dtype=torch.float32)
+        gap = nmax(ref32["R_tok"], ref["R_tok"])             # the oracle's own fp32-vs-fp64 conditioning on this instance
+        err = nmax(out["R_tok"][b], ref["R_tok"])
+        assert err < max(1e-4, 20 * gap), (S, b, err, gap)
+
+
+def test_full_width_properties_bf16(eng_mod):
+    """BASELINE-size layer width (H 4096, I 14336, 32/8 heads, d 128, S 2048, bf16), 2 layers: no oracle at this
+    size, so size-independent properties: finite, batched == single (bit for bit), sum of token relevance ==
+    latent relevance at the embedding, target override honoured."""
+    cfg = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=4096, rope_theta=5e5, rms_eps=1e-5)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rn = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.02).bfloat16()  # noqa: E731
+    H, I, d = 4096, 14336, 128
+    W = dict(embed=rn(4096, H), norm=torch.ones(H, device="cuda").bfloat16(), lm_head=rn(4096, H),
+             layers=[dict(ln1=torch.ones(H, device="cuda").bfloat16(), ln2=torch.ones(H, device="cuda").bfloat16(), wq=rn(32 * d, H),
+                          wk=rn(8 * d, H), wv=rn(8 * d, H), wo=rn(H, 32 * d), wg=rn(I, H), wu=rn(I, H), wd=rn(H, I)) for _ in range(2)])
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="efficient", max_seq=2048)
+    ids = torch.randint(0, 4096, (2, 2048), generator=torch.Generator().manual_seed(1))
+    both = eng.explain(ids, layer_relevance=True)
+    assert torch.isfinite(both["R_tok"]).all()
+    for b in range(2):
+        one = eng.explain(ids[b:b + 1])
+        assert torch.equal(one["R_tok"][0], both["R_tok"][b])
+    assert nmax(both["R_tok"].sum(1), both["layer_R"][0]) < 2e-2        # bf16 G read-out vs fp32 row sums
+    forced = eng.explain(ids[:1], target=torch.tensor([7]))
+    assert int(forced["idx"][0]) == 7
