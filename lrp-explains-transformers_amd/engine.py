@@ -84,6 +84,9 @@ class LlamaLRP:
         self.cos = emb.cos().to(dtype).to(torch.float32).to(dev).contiguous()
         self.sin = emb.sin().to(dtype).to(torch.float32).to(dev).contiguous()
         self.max_seq = max_seq
+        # second HIP stream: the dQ kernel runs beside the dK/dV kernel (both only read the forward stash;
+        # their causal tails interleave instead of leaving CUs idle)
+        self.side_stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
 
     @classmethod
@@ -183,9 +186,15 @@ class LlamaLRP:
             q_t = ops.transpose_heads(q, B, S, nq, d)
             Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dqk = new(M, nqk)
-            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"])
             dk_h, dv_h = new(M, nq * d), new(M, nq * d)
+            main = torch.cuda.current_stream(dev)
+            self.side_stream.wait_stream(main)
+            with torch.cuda.stream(self.side_stream):
+                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"])
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"])
+            main.wait_stream(self.side_stream)
+            for t_ in (q, k, v, k_t, Gho, D, dqk):
+                t_.record_stream(self.side_stream)
             ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
             Aqkv = new(M, nqkv)
             if E["lin"] == 0.0:

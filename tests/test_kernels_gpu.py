@@ -276,7 +276,8 @@ def _tm(x):      # [B,H,S,d] -> token-major [B*S, H*d]
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,Hq,Hkv,d,causal,window", [
     (1, 16, 4, 2, 16, True, 0), (2, 100, 4, 2, 32, True, 0), (1, 192, 4, 1, 128, True, 0),
-    (1, 130, 2, 2, 64, False, 0), (1, 200, 2, 1, 64, True, 48), (1, 300, 8, 2, 128, True, 0)])
+    (1, 130, 2, 2, 64, False, 0), (1, 200, 2, 1, 64, True, 48), (1, 300, 8, 2, 128, True, 0),
+    (1, 150, 2, 1, 256, True, 0), (1, 150, 2, 1, 256, True, 64)])
 @pytest.mark.parametrize("mode", ["efficient", "explicit"])
 def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     if dtype == torch.bfloat16 and d < 32:
