@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--mode", default="efficient", choices=["efficient", "explicit"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     args = ap.parse_args()
 
     import lxt_amd.dist as D
@@ -109,7 +110,7 @@ def main():
     cfg = dict(LLAMA3_8B, n_layers=args.layers)
 
     W = synth_weights(cfg, dev, dtype, seed=0)
-    eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=args.seq)
+    eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=args.seq, sparse_top=not args.dense_top)
     del W
     torch.cuda.empty_cache()
     if world > 1:

@@ -152,7 +152,7 @@ LRP_DEVICE bool visible(int q, int key, int S, int causal, int window) {
 template <typename T, int D, int QSUB>
 __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
-    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window) {
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (Hq / Hkv);
     const int qblk = gridDim.x - 1 - blockIdx.x;     // heavy (late) causal blocks first
     const int q0 = qblk * BQ, qw = q0 + wave * 16 * QSUB;
+    if (q0 + BQ <= q_begin) return;                  // rows below q_begin are not needed (top-layer sparsity)
     const T* qb = q + (int64_t)b * S * ldq + (int64_t)h * D;
     const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
     const T* vtb = vt + ((int64_t)b * Hkv + hk) * D * ldt;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dq_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
     int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddq,
-    float scale, float eps_mask, float eps_qk, int causal, int window) {
+    float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dq_kernel(
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (Hq / Hkv);
     const int qblk = gridDim.x - 1 - blockIdx.x;
     const int q0 = qblk * BQ, qi = q0 + wave * 16 + (lane & 15);
+    if (q0 + BQ <= q_begin) return;
     const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
     const T* vb = v + (int64_t)b * S * ldv + (int64_t)hk * D;
     const T* ktb = kt + ((int64_t)b * Hkv + hk) * D * ldt;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dkv_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
     T* __restrict__ dk, T* __restrict__ dv, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt,
-    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window) {
+    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dkv_kernel(
     int qbeg = 0, qend = S;
     if (causal) qbeg = (k0 / CT) * CT;
     if (window > 0) qend = min(S, k0 + BK - 1 + window);
+    if (q_begin > qbeg) qbeg = (q_begin / CT) * CT;      // queries below q_begin carry no relevance
 
     for (int qt0 = qbeg; qt0 < qend; qt0 += CT) {
         __syncthreads();
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
     T* __restrict__ dk, T* __restrict__ dv, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt,
-    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int B) {
+    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
     int qbeg = 0, qend = S;
     if (causal) qbeg = (k0 / CT) * CT;
     if (window > 0) qend = min(S, k0 + BK - 1 + window);
+    if (q_begin > qbeg) qbeg = (q_begin / CT) * CT;      // queries below q_begin carry no relevance
 
     auto stage = [&](int qt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
 template <typename T, int D, int QSUB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
-    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int B) {
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int B, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -684,6 +688,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
     const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
     const int qblk = nqb - 1 - item / rep;           // heavy (late) causal blocks first
     const int q0 = qblk * BQ, qw = q0 + wave * 16 * QSUB;
+    if (q0 + BQ <= q_begin) return;
     const T* qb = q + (int64_t)b * S * ldq + (int64_t)h * D;
     const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
     const T* vtb = vt + ((int64_t)b * Hkv + hk) * D * ldt;
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
     int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddq,
-    float scale, float eps_mask, float eps_qk, int causal, int window, int B) {
+    float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
     const int qblk = nqb - 1 - item / rep;
     const int q0 = qblk * BQ, qi = q0 + wave * 16 + (lane & 15);
+    if (q0 + BQ <= q_begin) return;
     const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
     const T* vb = v + (int64_t)b * S * ldv + (int64_t)hk * D;
     const T* ktb = kt + ((int64_t)b * Hkv + hk) * D * ldt;
@@ -942,7 +948,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 template <typename T>
 static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int S, int Hq, int Hkv,
                       int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window,
-                      hipStream_t st) {
+                      int q_begin, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
@@ -957,13 +963,13 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
                     set_lds(kern, lds);
                     dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 255) / 256)));
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
-                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B);
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin);
                 } else {
                     auto kern = attn_fwd_v2_kernel<T, DD, 1>;
                     set_lds(kern, lds);
                     dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 127) / 128)));
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
-                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B);
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin);
                 }
             }
         })
@@ -977,7 +983,7 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
         const int BQ = 64 * QSUB;
         dim3 grid((S + BQ - 1) / BQ, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq, Hkv,
-                           ldq, ldk, ldt, ldo, scale, causal, window);
+                           ldq, ldk, ldt, ldo, scale, causal, window, q_begin);
     })
     return lrp_check_launch();
 }
@@ -991,7 +997,7 @@ static int attn_common_check(int B, int S, int Hq, int Hkv, int d, int dtype) {
 
 extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse, int B, int S, int Hq,
                             int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal,
-                            int window, int dtype, void* stream) {
+                            int window, int q_begin, int dtype, void* stream) {
     if (!q || !k || !v_t || !o || !lse) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -999,15 +1005,15 @@ extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void*
     const int epc = dtype == LRP_F32 ? 4 : 8;
     if (!al16(q) || !al16(k) || !al16(v_t) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldt % epc) || (ldo % 4) || ldt < S) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_fwd_t<float>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, st);
-    return attn_fwd_t<bf16_t>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, st);
+    if (dtype == LRP_F32) return attn_fwd_t<float>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, st);
+    return attn_fwd_t<bf16_t>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, st);
 }
 
 template <typename T>
 static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt, const void* gho, const float* lse,
                      const float* D, void* dq, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
                      int64_t ldt, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
-                     hipStream_t st) {
+                     int q_begin, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
@@ -1020,13 +1026,13 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
-                                       eps_qk, causal, window, B);
+                                       eps_qk, causal, window, B, q_begin);
                 } else {
                     auto kern = attn_bwd_dq_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
-                                       eps_qk, causal, window, B);
+                                       eps_qk, causal, window, B, q_begin);
                 }
             }
         })
@@ -1038,7 +1044,7 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
         set_lds(kern, lds);
         dim3 grid((S + 63) / 64, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt, (const T*)gho,
-                           lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask, eps_qk, causal, window);
+                           lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask, eps_qk, causal, window, q_begin);
     })
     return lrp_check_launch();
 }
@@ -1046,7 +1052,7 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
 extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t, const void* Gho,
                                const float* lse, const float* D, void* dq, int B, int S, int Hq, int Hkv, int d,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho, int64_t lddq, float scale,
-                               float eps_mask, float eps_qk, int causal, int window, int dtype, void* stream) {
+                               float eps_mask, float eps_qk, int causal, int window, int q_begin, int dtype, void* stream) {
     if (!q || !k || !v || !k_t || !Gho || !lse || !D || !dq) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -1055,15 +1061,15 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
     if (!al16(q) || !al16(k) || !al16(v) || !al16(k_t) || !al16(Gho) || !al16(dq) || (ldq % epc) || (ldk % epc) ||
         (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddq % 4) || ldt < S) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, st);
-    return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, st);
+    if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, st);
+    return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, st);
 }
 
 template <typename T>
 static int attn_dkv_t(const void* q, const void* k, const void* v, const void* qt, const void* gho, const void* ghot,
                       const float* lse, const float* D, void* dk, void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq,
                       int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddk, int64_t lddv, float scale,
-                      float eps_mask, float eps_qk, int causal, int window, hipStream_t st) {
+                      float eps_mask, float eps_qk, int causal, int window, int q_begin, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128 && S >= 1) {
@@ -1076,13 +1082,13 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
-                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B);
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin);
                 } else {
                     auto kern = attn_bwd_dkv_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
-                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B);
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin);
                 }
             }
         })
@@ -1095,7 +1101,7 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
         dim3 grid((S + 63) / 64, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt, (const T*)gho,
                            (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddk, lddv, scale,
-                           eps_mask, eps_qk, causal, window);
+                           eps_mask, eps_qk, causal, window, q_begin);
     })
     return lrp_check_launch();
 }
@@ -1104,7 +1110,7 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
                                 const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h, int B, int S,
                                 int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho,
                                 int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window,
-                                int dtype, void* stream) {
+                                int q_begin, int dtype, void* stream) {
     if (!q || !k || !v || !q_t || !Gho || !Gho_t || !lse || !D || !dk_h || !dv_h) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -1114,8 +1120,8 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
         (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddk % 4) || (lddv % 4) || ldt < S)
         return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, st);
-    return attn_dkv_t<bf16_t>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, st);
+    if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, st);
+    return attn_dkv_t<bf16_t>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, st);
 }
 
 extern "C" int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int64_t ldx, int64_t ldt,

@@ -57,11 +57,15 @@ def weights_from_hf(model):
 class LlamaLRP:
     """Device-resident weights (both layouts) + explain()."""
 
-    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096):
+    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096, sparse_top=True):
         if not torch.cuda.is_available():
             raise RuntimeError("LlamaLRP needs a HIP device: the LRP kernels have no CPU fallback")
         self.cfg, self.dtype, self.device = dict(cfg), dtype, torch.device(device)
         self.set_mode(mode)
+        # top-layer sparsity: above the last attention layer only the LAST token of a prompt feeds the
+        # explained logit and carries relevance, so the last layer's o-proj / MLP (forward and backward) and
+        # its attention rows are evaluated for one row per prompt (M = B instead of B*S)
+        self.sparse_top = bool(sparse_top)
         self.act = cfg.get("act", "silu")
         dev = self.device
 
@@ -114,8 +118,10 @@ class LlamaLRP:
         new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
         stash = []
         h_prev, branch = emb, None
-        for Lw in self.layers:
+        last = torch.arange(B, device=dev) * S + (S - 1)
+        for li, Lw in enumerate(self.layers):
             st = {}
+            top = self.sparse_top and li == len(self.layers) - 1
             if branch is None:
                 st["h"] = h_prev
                 x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"])
@@ -128,6 +134,19 @@ class LlamaLRP:
             v_t = ops.transpose_heads(v, B, S, nk, d)
             o = new(M, nq * d)
             lse = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+            if top:
+                ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1)
+                o_l, h_l = o.index_select(0, last), st["h"].index_select(0, last)
+                a_l = ops.gemm_nt_2d(o_l, Lw["wo"], new(B, H))
+                h1_l = new(B, H)
+                x2_l, rstd2_l = ops.add_rmsnorm_fwd(h_l, a_l, Lw["ln2"], c["rms_eps"], hsum_out=h1_l)
+                gu_l = ops.gemm_nt_2d(x2_l, Lw["wgu"], new(B, 2 * I))
+                m_l = ops.gated_act_fwd(gu_l[:, :I], gu_l[:, I:], new(B, I), self.act)
+                dn_l = ops.gemm_nt_2d(m_l, Lw["wd"], new(B, H))
+                st.update(top=True, qkv=qkv, qkr=qkr, lse=lse, o_l=o_l, a_l=a_l, h1_l=h1_l, rstd2_l=rstd2_l, gu_l=gu_l, dn_l=dn_l)
+                stash.append(st)
+                h_prev, branch = h1_l, dn_l
+                break
             ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0)
             a = ops.gemm_nt_2d(o, Lw["wo"], new(M, H))
             h1 = new(M, H)
@@ -139,8 +158,10 @@ class LlamaLRP:
             stash.append(st)
             h_prev, branch = h1, dn
         # last token only: final residual add + norm + LM head
-        last = torch.arange(B, device=dev) * S + (S - 1)
-        h1_last, dn_last = h_prev.index_select(0, last), branch.index_select(0, last)
+        if h_prev.shape[0] == B and self.sparse_top and len(self.layers) > 0:
+            h1_last, dn_last = h_prev, branch
+        else:
+            h1_last, dn_last = h_prev.index_select(0, last), branch.index_select(0, last)
         hL_last = new(B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h1_last, dn_last, self.norm, c["rms_eps"], hsum_out=hL_last)
         logits = ops.gemm_nt_2d(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
@@ -162,36 +183,63 @@ class LlamaLRP:
         rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
         ops.rmsnorm_bwd_add2(Gh_last, None, None, None, fw["hL_last"], fw["dn_last"], Gs_last, A_last, rel_last,
                              0.0, E["add"], E["lin"])
-        Gs = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, fw["last"], Gs_last)
-        Adn = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, fw["last"], A_last)
+        last = fw["last"]
+        top_sparse = bool(fw["stash"]) and fw["stash"][-1].get("top", False)
+        if not top_sparse:
+            Gs = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, Gs_last)
+            Adn = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, A_last)
         layer_R = [rel_last] if layer_relevance else None
 
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
-            gu, qkv, qkr = st["gu"], st["qkv"], st["qkr"]
-            # ---- MLP
-            Gm = ops.gemm_nt_2d(Adn, Lw["wd_t"], new(M, I))
-            Agu = new(M, 2 * I)
-            ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-            Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(M, H))
-            Gs1, Aa = new(M, H), new(M, H)
-            ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
-            # ---- attention
-            Gof = ops.gemm_nt_2d(Aa, Lw["wo_t"], new(M, nq * d))
-            Gho = new(M, nq * d)
-            D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
-            ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
+            qkv, qkr = st["qkv"], st["qkr"]
+            q_begin = 0
+            if st.get("top", False):
+                # ---- one row per prompt through MLP, norm/add2 and o-proj; scatter into the dense attention inputs
+                gu_l = st["gu_l"]
+                Gm = ops.gemm_nt_2d(A_last, Lw["wd_t"], new(B, I))
+                Agu = new(B, 2 * I)
+                ops.gated_act_bwd(Gm, gu_l[:, :I], gu_l[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
+                Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(B, H))
+                Gs1_l, Aa_l = new(B, H), new(B, H)
+                ops.rmsnorm_bwd_add2(Gs_last, Gx2, Lw["ln2"], st["rstd2_l"], st["h1_l"], st["a_l"], Gs1_l, Aa_l, None, 0.0,
+                                     E["add"], E["lin"])
+                Gof_l = ops.gemm_nt_2d(Aa_l, Lw["wo_t"], new(B, nq * d))
+                Gho_l = new(B, nq * d)
+                D_l = torch.empty(B, nq, 1, device=dev, dtype=torch.float32)
+                ops.attn_bwd_prep(Gof_l, st["o_l"], Gho_l, D_l, B, 1, nq, d, E["pv"], 0.5)
+                Gho = torch.zeros(M, nq * d, device=dev, dtype=dt).index_copy_(0, last, Gho_l)
+                D = torch.zeros(B, nq, S, device=dev, dtype=torch.float32)
+                D[:, :, S - 1] = D_l[:, :, 0]
+                Gs1 = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, Gs1_l)
+                q_begin = S - 1
+            else:
+                gu = st["gu"]
+                # ---- MLP
+                Gm = ops.gemm_nt_2d(Adn, Lw["wd_t"], new(M, I))
+                Agu = new(M, 2 * I)
+                ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
+                Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(M, H))
+                Gs1, Aa = new(M, H), new(M, H)
+                ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
+                # ---- attention
+                Gof = ops.gemm_nt_2d(Aa, Lw["wo_t"], new(M, nq * d))
+                Gho = new(M, nq * d)
+                D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+                ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
             q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
             k_t = ops.transpose_heads(k, B, S, nk, d)
             q_t = ops.transpose_heads(q, B, S, nq, d)
             Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
-            dqk = new(M, nqk)
+            dqk = new(M, nqk) if q_begin == 0 else torch.zeros(M, nqk, device=dev, dtype=dt)
             dk_h, dv_h = new(M, nq * d), new(M, nq * d)
             main = torch.cuda.current_stream(dev)
             self.side_stream.wait_stream(main)
             with torch.cuda.stream(self.side_stream):
-                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"])
-            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"])
+                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                                q_begin=q_begin)
+            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                             q_begin=q_begin)
             main.wait_stream(self.side_stream)
             for t_ in (q, k, v, k_t, Gho, D, dqk):
                 t_.record_stream(self.side_stream)

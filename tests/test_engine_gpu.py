@@ -117,3 +117,15 @@ def test_full_width_properties_bf16(eng_mod):
     assert nmax(both["R_tok"].sum(1), both["layer_R"][0]) < 2e-2        # bf16 G read-out vs fp32 row sums
     forced = eng.explain(ids[:1], target=torch.tensor([7]))
     assert int(forced["idx"][0]) == 7
+
+
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_top_layer_sparsity_equals_dense(eng_mod, mode):
+    """evaluating the last layer's o-proj / MLP / attention rows only for the last token of each prompt
+    (M = B) must give the same relevance as the dense evaluation"""
+    cfg, W, ids, fx = llama_case("mid")
+    ids2 = torch.stack([ids, ids.flip(0)])
+    dense = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512, sparse_top=False).explain(ids2, layer_relevance=True)
+    sparse = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512, sparse_top=True).explain(ids2, layer_relevance=True)
+    assert torch.equal(dense["idx"], sparse["idx"])
+    assert nmax(sparse["R_tok"], dense["R_tok"]) < 1e-5 and nmax(sparse["layer_R"], dense["layer_R"]) < 1e-5
