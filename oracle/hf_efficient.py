@@ -126,15 +126,45 @@ def lrp_eager_attention(module, query, key, value, attention_mask=None, scaling=
     return out.transpose(1, 2).contiguous(), w
 
 
-def patch_instance(model):
-    """Apply the efficient AttnLRP rule placement to ONE model instance (instance-level forwards +
-    a private attention interface).  Returns the model."""
+def cp_eager_attention(module, query, key, value, attention_mask=None, scaling=None, dropout=0.0, **kwargs):
+    """CP-LRP (ref: lxt/efficient/patches.py:245-255): q and k detached, no uniform-rule factors"""
+    class _Plain:   # reuse the arithmetic of lrp_eager_attention without its divide_gradient calls
+        pass
+    query, key = query.detach(), key.detach()
+    rep = query.shape[1] // key.shape[1]
+    if rep > 1:
+        key = key.repeat_interleave(rep, dim=1)
+        value = value.repeat_interleave(rep, dim=1)
+    if scaling is None:
+        scaling = query.shape[-1] ** -0.5
+    w = torch.matmul(query, key.transpose(2, 3)) * scaling
+    if attention_mask is not None:
+        w = w + attention_mask[:, :, :, : key.shape[-2]]
+    elif getattr(module, "is_causal", False) and query.shape[2] > 1:
+        S = query.shape[2]
+        w = w.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=w.device).tril(), float("-inf"))
+    sm_dtype = torch.float64 if w.dtype == torch.float64 else torch.float32
+    w = torch.softmax(w, dim=-1, dtype=sm_dtype).to(query.dtype)
+    return torch.matmul(w, value).transpose(1, 2).contiguous(), w
+
+
+def _cp_gated_mlp_forward(self, x):
+    """ref: lxt/efficient/patches.py:269-280"""
+    gate = self.act_fn(self.gate_proj(x).detach())
+    return self.down_proj(gate * self.up_proj(x))
+
+
+def patch_instance(model, variant="attnlrp"):
+    """Apply the efficient AttnLRP (variant="attnlrp") or CP-LRP (variant="cp") rule placement to ONE
+    model instance (instance-level forwards + a private attention interface).  Returns the model."""
     from transformers import AttentionInterface, AttentionMaskInterface
     from transformers.masking_utils import eager_mask
-    AttentionInterface.register("lrp_oracle", lrp_eager_attention)
-    AttentionMaskInterface.register("lrp_oracle", eager_mask)      # HF builds the per-layer (causal / sliding) additive masks
+    cp = variant == "cp"
+    name_attn = "lrp_oracle_cp" if cp else "lrp_oracle"
+    AttentionInterface.register(name_attn, cp_eager_attention if cp else lrp_eager_attention)
+    AttentionMaskInterface.register(name_attn, eager_mask)      # HF builds the per-layer (causal / sliding) additive masks
     for cfg in [model.config] + [getattr(model.config, k) for k in ("text_config", "vision_config") if hasattr(model.config, k)]:
-        cfg._attn_implementation = "lrp_oracle"
+        cfg._attn_implementation = name_attn
     for m in model.modules():
         name = type(m).__name__
         if isinstance(m, nn.Linear):
@@ -148,7 +178,7 @@ def patch_instance(model):
         elif name.endswith("RMSNorm"):
             m.forward = types.MethodType(_rms_forward, m)
         elif name.endswith("MLP") and hasattr(m, "gate_proj") and hasattr(m, "act_fn"):
-            m.forward = types.MethodType(_gated_mlp_forward, m)
+            m.forward = types.MethodType(_cp_gated_mlp_forward if cp else _gated_mlp_forward, m)
         elif name == "GPT2MLP":
             m.forward = types.MethodType(_gpt2_mlp_forward, m)
         elif name == "BertIntermediate":

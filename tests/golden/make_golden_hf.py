@@ -100,15 +100,49 @@ def gemma3():
                         R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build_gemma3(seed=3)), seed=3, S=96)
 
 
+def family(which):
+    """tiny causal LMs through the reference's own default maps: qwen2, qwen3, gpt2 (attnLRP) and llama (cp_LRP)"""
+    import importlib
+    from lxt.efficient import monkey_patch
+    from tests.golden.hf_models import BUILDERS
+    build = BUILDERS[which]
+    ids = torch.randint(0, 256, (80,), generator=torch.Generator().manual_seed(99))
+    variant = "cp" if which.endswith("_cp") else "attnlrp"
+    o32 = oh.explain_causal_lm(oh.patch_instance(build(attn="eager"), variant), ids)
+    o64 = oh.explain_causal_lm(oh.patch_instance(build(attn="eager").double(), variant), ids, target=o32["idx"])
+    fam = which.replace("_cp", "")
+    mod = importlib.import_module(f"transformers.models.{fam}.modeling_{fam}")
+    if variant == "cp":
+        lmap = importlib.import_module(f"lxt.efficient.models.{fam}").cp_LRP
+        monkey_patch(mod, lmap)
+    else:
+        monkey_patch(mod)
+    model = build(attn="eager")
+    for p in model.parameters():
+        p.requires_grad_(False)
+    e = model.get_input_embeddings()(ids[None]).requires_grad_()
+    last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+    idx = int(last.argmax())
+    last[idx].backward()
+    R = (e * e.grad)[0].sum(-1).detach()
+    print(f"  [{which}] idx={idx} logit={float(last[idx]):.6f} sumR={float(R.sum()):.6f}")
+    print(f"     oracle fp32 vs reference {nmax(o32['R_tok'], R):.2e} ; oracle fp64 vs reference {nmax(o64['R_tok'], R):.2e}")
+    assert o32["idx"] == idx and nmax(o32["R_tok"], R) < 2e-5
+    np.savez_compressed(os.path.join(HERE, f"hf_{which}.npz"), ids=ids.numpy(), idx=idx, logit=float(last[idx]), R_tok=R.numpy(),
+                        R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build()), S=80)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     # lxt's patches are process-global: one model family per process
     if which == "all":
         import subprocess
-        for w in ("bert", "gemma3"):
+        for w in ("bert", "gemma3", "llama_cp", "qwen2", "qwen3", "gpt2"):
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
     elif which == "bert":
         bert()
-    else:
+    elif which == "gemma3":
         gemma3()
+    else:
+        family(which)

@@ -72,3 +72,16 @@ def test_gemma3_text_full_model_relevance():
         e1, e2 = nmax(R, fx["R_tok"]), nmax(R, ref64["R_tok"])
         print(f"[gemma3/{impl}] tok vs reference {e1:.2e} | vs oracle fp64 {e2:.2e}")
         assert e1 < 1e-4 and e2 < 1e-4
+
+
+@pytest.mark.parametrize("which", ["llama_cp", "qwen2", "qwen3", "gpt2"])
+def test_model_family_maps(which):
+    """CP-LRP map (llama) and the qwen2 / qwen3 / gpt2 AttnLRP maps against fixtures captured from the
+    reference's own maps; one fresh process per family (class-level patches are process-global)."""
+    _need_gpu()
+    import os, subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "hf_family_worker.py"), which], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    print(r.stdout[-600:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -22,3 +22,13 @@ def test_gemma3_oracle_vs_reference():
     assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
     out = oh.explain_causal_lm(oh.patch_instance(model), t(fx["ids"]))
     assert out["idx"] == int(fx["idx"]) and nmax(out["R_tok"], fx["R_tok"]) < 5e-6
+
+
+@pytest.mark.parametrize("which", ["llama_cp", "qwen2", "qwen3", "gpt2"])
+def test_family_oracle_vs_reference(which):
+    from tests.golden.hf_models import BUILDERS
+    fx = load(f"hf_{which}.npz")
+    model = BUILDERS[which](attn="eager")
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    out = oh.explain_causal_lm(oh.patch_instance(model, "cp" if which.endswith("_cp") else "attnlrp"), t(fx["ids"]))
+    assert out["idx"] == int(fx["idx"]) and nmax(out["R_tok"], fx["R_tok"]) < 5e-6
