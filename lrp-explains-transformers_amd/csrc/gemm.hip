@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(
 // never read): the line is pulled into L2 a full K step before its real staging load, which then
 // hits.  The wait at the end of a K step is a counted vmcnt(1) (the prefetch stays in flight) + raw
 // s_barrier instead of __syncthreads() (which would drain it).
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt_glds_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     // L2 prefetch: thread i touches the 128-byte line of tile row (i mod (TBM+TBN)) -- one K step of one
     // row IS one line when lda*sizeof(T) is a multiple of 128 (else it merely prefetches a neighbour)
     const T* ppf = nullptr;
-    char* pf_scratch = smem + 2 * STAGE + wave * 256;
+    char* pf_scratch = smem + NST * STAGE + wave * 256;
     if constexpr (PF) {
         const int r = tid % (TBM + TBN);
         if (r < TBM) { int gr = m0 + r; gr = gr < M ? gr : M - 1; ppf = A + (int64_t)gr * lda; }
@@ -240,8 +240,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(ppf + (int64_t)k * KE), (lds_ptr_t)pf_scratch, 4, 0, 0);
         }
     };
-    auto step_sync = [&]() {
-        if constexpr (PF) {
+    constexpr int LPS = GA + GB;                        // staging loads per K step per wave
+    auto step_sync = [&](int kt) {
+        if constexpr (NST == 3) {
+            // three LDS stages: tile kt+1 must have landed, tile kt+2 (issued this step) may stay in flight
+            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else if constexpr (PF) {
             asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
@@ -250,18 +256,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     };
 
     stage(0, 0);
-    prefetch(1);
-    step_sync();
+    if constexpr (NST == 3) {
+        if (nkt > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        prefetch(1);
+        step_sync(-1);
+    }
 
     const int frow = lane & 15, fq = lane >> 4;
     typedef typename Mma16<T>::frag frag_t;
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-        else if constexpr (PF) {                        // keep the in-order queue shape: the older prefetch must retire
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NST == 3) {
+            if (kt + 2 < nkt) stage(kt + 2, (cur + 2) % 3);
+        } else {
+            if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+            else if constexpr (PF) {                        // keep the in-order queue shape: the older prefetch must retire
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            prefetch(kt + 2);
         }
-        prefetch(kt + 2);
         const char* pas = smem + cur * STAGE + (wm * SM) * KB;
         const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
 #pragma unroll
@@ -279,8 +295,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
                 for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        step_sync();
-        cur ^= 1;
+        step_sync(kt);
+        if constexpr (NST == 3) cur = (cur + 1) % 3; else cur ^= 1;
     }
     if constexpr (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -318,13 +334,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     }
 }
 
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false, int NST = 2>
 int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
     dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
-    const size_t lds = 2 * (size_t)(TBM + TBN) * KB + (PF ? 256 * WM * WN : 0);
-    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN, PRIO, PF>;
+    const size_t lds = NST * (size_t)(TBM + TBN) * KB + (PF ? 256 * WM * WN : 0);
+    auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN, PRIO, PF, NST>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -504,7 +520,177 @@ int launch_pipe(const void* A, const void* B, void* C, const void* bias, int M, 
     return lrp_check_launch();
 }
 
+
+// =================================================================================================
+// Depth-2 prefetch on a double-buffered LDS: the 3-stage experiments (256x128 and 128x256 tiles: +10..18 %
+// over their 2-stage forms at equal tile and barrier count, profiles/r01_gemm_tiles.txt) show that one K
+// step of flight time is not enough cover for the loaded L2/fabric latency.  A 256x256x(128 B) tile has
+// no room for a third LDS stage (3 x 64 KiB > 160 KiB), so the third stage lives in REGISTERS: tile
+// t+2 is fetched with ordinary global_load_dwordx4 into one of two 32-VGPR sets at the start of K step t,
+// stays in flight during steps t and t+1, and is written to the LDS buffer freed by step t (lane-linear
+// ds_write_b128: the same image the LDS-DMA path produces, swizzle on the source address) just before
+// the barrier that ends step t+1.  Compiler-counted vmcnt (plain loads) -- no hand-placed waits.
+// =================================================================================================
+template <typename T, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_nt_rs2_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+    int tiles_m, int tiles_n) {
+    constexpr int TBM = 256, TBN = 256, WM = 2, WN = 4, NW = 8;
+    constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
+    constexpr int SM = TBM / WM, SN = TBN / WN, FM = SM / 16, FN = SN / 16;
+    constexpr int GA = TBM / 8 / NW, GB = TBN / 8 / NW;            // 4 + 4 one-KiB groups per wave
+    constexpr int STAGE = (TBM + TBN) * KB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    grouped_tile(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    A += (int64_t)blockIdx.y * sA + (int64_t)m0 * lda;
+    B += (int64_t)blockIdx.y * sB + (int64_t)n0 * ldb;
+    C += (int64_t)blockIdx.y * sC;
+    const int nkt = K / KE;
+
+    // per-lane 32-bit element offsets relative to the (uniform) tile origin; rows clamped to the matrix
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    uint32_t oa[GA], ob[GB];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        int r = (wave * GA + i) * 8 + lrow;
+        r = (m0 + r < M) ? r : (M - 1 - m0);
+        oa[i] = (uint32_t)(r * lda + lchunk * EPC);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        int r = (wave * GB + i) * 8 + lrow;
+        r = (n0 + r < N) ? r : (N - 1 - n0);
+        ob[i] = (uint32_t)(r * ldb + lchunk * EPC);
+    }
+    auto gload = [&](u32x4(&ra)[GA], u32x4(&rb)[GB], int kt) {
+#pragma unroll
+        for (int i = 0; i < GA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(A + oa[i] + (uint32_t)(kt * KE));
+#pragma unroll
+        for (int i = 0; i < GB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(B + ob[i] + (uint32_t)(kt * KE));
+    };
+    auto swrite = [&](const u32x4(&ra)[GA], const u32x4(&rb)[GB], int buf) {
+        char* sa = smem + buf * STAGE + (wave * GA) * 1024 + lane * 16;
+        char* sb = smem + buf * STAGE + TBM * KB + (wave * GB) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) *reinterpret_cast<u32x4*>(sa + i * 1024) = ra[i];
+#pragma unroll
+        for (int i = 0; i < GB; ++i) *reinterpret_cast<u32x4*>(sb + i * 1024) = rb[i];
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef typename Mma16<T>::frag frag_t;
+    auto compute = [&](int buf) {
+        const char* pas = smem + buf * STAGE + (wm * SM) * KB;
+        const char* pbs = smem + buf * STAGE + TBM * KB + (wn * SN) * KB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+            frag_t fb[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(pbs + (j * 16 + frow) * KB + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {      // one A fragment live at a time: keeps the two staging sets in registers
+                const frag_t fa = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * KB + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa, acc[i][j]);
+            }
+        }
+    };
+
+    // Straight-line loop body (host guarantees nkt even, >= 2): NO conditional around any load, so the
+    // compiler's vmcnt scoreboard stays exact (a branch around a load block makes it merge the two
+    // paths conservatively and wait for the youngest set too, which silently removes the second K step
+    // of flight).  Tail steps re-fetch the last tile (clamped index) into a buffer nobody reads.
+    u32x4 a0[GA], b0[GB], a1[GA], b1[GB];
+    gload(a0, b0, 0);
+    gload(a1, b1, 1);
+    swrite(a0, b0, 0);
+    __syncthreads();
+    const int klast = nkt - 1;
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // even step: LDS[0] = tile kt ; set 1 = tile kt+1 (in flight) ; set 0 free
+        gload(a0, b0, (kt + 2 < klast) ? kt + 2 : klast);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(a1, b1, 1);
+        __syncthreads();
+        // odd step: LDS[1] = tile kt+1 ; set 0 = tile kt+2 (in flight) ; set 1 free
+        gload(a1, b1, (kt + 3 < klast) ? kt + 3 : klast);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(a0, b0, 0);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int gm = m0 + wm * SM + i * 16 + frow;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int gn = n0 + wn * SN + j * 16 + fq * 4;
+            if (gn >= N) continue;
+            f32x4 v = acc[i][j];
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+            }
+            TO* dst = C + (int64_t)gm * ldc + gn;
+            if (vec_ok && gn + 3 < N) {
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (gn + r < N) dst[r] = from_f32<TO>(v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, typename TO>
+int launch_rs2(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+               int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    dim3 grid(tiles_m * tiles_n, batch), block(512);
+    const size_t lds = 2 * (size_t)512 * KB;
+    auto kern = gemm_nt_rs2_kernel<T, TO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
+                       sA, sB, sC, tiles_m, tiles_n);
+    return lrp_check_launch();
+}
+
 // tile selection: the largest tile that still gives ~one workgroup per CU (256 CUs)
+template <typename T> constexpr bool dtype_is_f32() { return sizeof(T) == 4; }
+
 template <typename T, typename TO>
 int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st, int force) {
@@ -516,6 +702,16 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // the PMC profile shows the 8-wave kernel parked in waitcnt/barrier 37 % of its wave cycles while the
     // LDS is only 21 % busy, so more resident waves buy more than the larger wave tile saves.
     if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? 7 : 1;
+    if (cfg == 16) {   // 32-bit lane offsets: the clamped tile must span < 4 Gi elements
+        const int nkt16 = K / ((dtype_is_f32<T>()) ? 32 : 64);
+        if ((int64_t)256 * lda < (int64_t)1 << 31 && (int64_t)256 * ldb < (int64_t)1 << 31 && nkt16 >= 2 && (nkt16 % 2) == 0)
+            return launch_rs2<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+        cfg = 7;
+    }
+    if (cfg == 12) return launch_glds<T, TO, 256, 128, 4, 2, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 13) return launch_glds<T, TO, 128, 128, 2, 2, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 14) return launch_glds<T, TO, 128, 256, 2, 4, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 15) return launch_glds<T, TO, 128, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 8) return launch_glds<T, TO, 256, 256, 4, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 10) return launch_glds<T, TO, 256, 256, 2, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 11) return launch_glds<T, TO, 128, 128, 2, 2, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
