@@ -83,6 +83,32 @@ def pmc_traffic():
         return None
 
 
+def smallm_roofline(ops, dtype, device):
+    """secondary roofline: the Linear eps-rule in its HBM-bound regime (north star: ">= 60 % HBM roofline on the
+    Linear eps-rule kernel").  One row (M=1) through Llama-3-8B's gate/up-sized weight [14336, 4096]: W is
+    streamed ONCE (z recompute + relevance redistribution in one pass, lrp_linear_eps_smallm).  Algorithmic bytes
+    = sizeof*(N*K + 2*M*K + M*N); duration from HIP events over 20 launches on the launching stream."""
+    M, N, K = 1, 14336, 4096
+    g = torch.Generator(device=device).manual_seed(3)
+    x = torch.randn(M, K, generator=g, device=device).to(dtype)
+    W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
+    gg = torch.randn(M, N, generator=g, device=device).to(dtype)
+    ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(M, N, K), device=device)
+    for _ in range(3):
+        ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / 20
+    nbytes = x.element_size() * (N * K + 2 * M * K + M * N)
+    return {"bound": "hbm", "kernel": "linear_eps_smallm_kernel + slab reduce (M=1, W [14336,4096])", "achieved": nbytes / sec / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "frac": nbytes / sec / 1e9 / 8000.0, "avg_launch_us": sec * 1e6, "traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +197,7 @@ def main():
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
                          "gemm_time_frac_of_step": secs / elapsed, "traffic": pmc_traffic()},
         }
+        line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)
