@@ -98,26 +98,29 @@ __global__ __launch_bounds__(64 * NWV) void linear_eps_smallm_kernel(
         Vec16<T> w0[KCH];
         for (; n < N; n += nwave) { load_row(w0, n); process(w0, n); }
     }
-    // fold the waves' partial sums through LDS (x is no longer needed there), one wave at a time
-    float* red = reinterpret_cast<float*>(smem);                      // [MM][KP] fp32 (host sizes LDS for it)
-    for (int w = 0; w < NWV; ++w) {
-        __syncthreads();
-        if (wave == w) {
+    // fold the waves' partial sums through LDS in ONE step: every wave parks its partial c in its own
+    // [MM][KP] fp32 region (16-byte stores, lane-linear), one barrier, then each thread sums the NWV copies
+    // of its float4 columns and writes the workgroup's slab row directly (x is no longer needed in LDS).
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                      // [NWV][MM][KP] fp32 (host sizes LDS for it)
 #pragma unroll
-            for (int m = 0; m < MM; ++m)
+    for (int m = 0; m < MM; ++m)
 #pragma unroll
-                for (int j = 0; j < KCH; ++j) {
-                    float* dst = red + m * KP + (j * 64 + lane) * EPC;
+        for (int j = 0; j < KCH; ++j) {
+            float* dst = red + ((size_t)(wave * MM + m) * KP) + (j * 64 + lane) * EPC;
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) dst[e] = (w == 0) ? acc[m][j][e] : dst[e] + acc[m][j][e];
-                }
+            for (int e4 = 0; e4 < EPC / 4; ++e4)
+                *reinterpret_cast<f32x4*>(dst + e4 * 4) = f32x4{acc[m][j][e4 * 4], acc[m][j][e4 * 4 + 1], acc[m][j][e4 * 4 + 2], acc[m][j][e4 * 4 + 3]};
         }
-    }
     __syncthreads();
     float* slab = out + (int64_t)blockIdx.x * M * K;                  // `out` is the workspace here
-    for (int i = threadIdx.x; i < M * K; i += blockDim.x) {
-        const int m = i / K, k = i - m * K;
-        slab[i] = red[m * KP + k];
+    for (int i = threadIdx.x; i < MM * KP / 4; i += blockDim.x) {
+        const int m = (i * 4) / KP, k = (i * 4) - m * KP;
+        if (m >= M || k >= K) continue;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(red + (size_t)m * KP + k);
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * MM + m) * KP) + k);
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * K + k) = sum;
     }
 }
 
@@ -161,7 +164,7 @@ int launch(const void* x, const void* W, const void* bias, const void* g, float*
     constexpr int STATE = MM * KCH * EPC;
     constexpr int NWV = (STATE <= 32) ? 16 : ((STATE <= 64) ? 8 : 4);
     const size_t kp = (size_t)KCH * 64 * EPC;
-    const size_t lds = (size_t)MM * kp * 4;                            // x (T) first, fp32 fold buffer afterwards
+    const size_t lds = (size_t)NWV * MM * kp * 4;                      // x (T) first, then NWV fp32 fold regions
     auto kern = linear_eps_smallm_kernel<T, KCH, MM, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
