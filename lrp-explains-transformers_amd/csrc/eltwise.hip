@@ -177,6 +177,21 @@ __global__ void gated_bwd_kernel(const T* Gm, const T* g, const T* u, T* Ag, T* 
     }
 }
 
+// W consecutive fp32 table entries (16-byte loads when W is a multiple of 4: the tables are fp32 [seq, d], d even,
+// c a multiple of W, so the address is 16-byte aligned whenever d % 4 == 0 -- checked by the host)
+template <int W> LRP_DEVICE void load_tab(float (&t)[W], const float* p) {
+    if constexpr (W % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            t[4 * q] = v[0]; t[4 * q + 1] = v[1]; t[4 * q + 2] = v[2]; t[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = p[q];
+    }
+}
+
 // ---- RoPE: thread handles W consecutive i in [0, d/2) of one (row, head): pairs (i, i+d/2) -------
 template <typename T, int W>
 __global__ void rope_fwd_kernel(const T* x, T* xr, const float* cs, const float* sn, int rows, int seq,
@@ -194,12 +209,15 @@ __global__ void rope_fwd_kernel(const T* x, T* xr, const float* cs, const float*
         Chunk<T, W> a, b, oa, ob;
         a.load(px + c);
         b.load(px + c + hd);
+        float c1[W], c2[W], s1[W], s2[W];
+        load_tab<W>(c1, cs + (int64_t)pos * d + c);
+        load_tab<W>(c2, cs + (int64_t)pos * d + c + hd);
+        load_tab<W>(s1, sn + (int64_t)pos * d + c);
+        load_tab<W>(s2, sn + (int64_t)pos * d + c + hd);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float c1 = cs[(int64_t)pos * d + c + k], c2 = cs[(int64_t)pos * d + c + k + hd];
-            const float s1 = sn[(int64_t)pos * d + c + k], s2 = sn[(int64_t)pos * d + c + k + hd];
-            oa.v[k] = a.v[k] * c1 - b.v[k] * s1;
-            ob.v[k] = b.v[k] * c2 + a.v[k] * s2;
+            oa.v[k] = a.v[k] * c1[k] - b.v[k] * s1[k];
+            ob.v[k] = b.v[k] * c2[k] + a.v[k] * s2[k];
         }
         oa.store(po + c);
         ob.store(po + c + hd);
@@ -223,14 +241,17 @@ __global__ void rope_bwd_kernel(const T* Gr, const T* xr, const T* x, T* A, cons
         g2.load(Gr + r * ldg + ho + c + hd);
         if (eps_rope != 0.f) { r1.load(xr + r * ldxr + ho + c); r2.load(xr + r * ldxr + ho + c + hd); }
         if (eps_lin != 0.f) { x1.load(x + r * ldx + ho + c); x2.load(x + r * ldx + ho + c + hd); }
+        float c1[W], c2[W], s1[W], s2[W];
+        load_tab<W>(c1, cs + (int64_t)pos * d + c);
+        load_tab<W>(c2, cs + (int64_t)pos * d + c + hd);
+        load_tab<W>(s1, sn + (int64_t)pos * d + c);
+        load_tab<W>(s2, sn + (int64_t)pos * d + c + hd);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float c1 = cs[(int64_t)pos * d + c + k], c2 = cs[(int64_t)pos * d + c + k + hd];
-            const float s1 = sn[(int64_t)pos * d + c + k], s2 = sn[(int64_t)pos * d + c + k + hd];
             float p1 = g1.v[k], p2 = g2.v[k];
             if (eps_rope != 0.f) { p1 *= eps_ratio(r1.v[k], 1.f, eps_rope); p2 *= eps_ratio(r2.v[k], 1.f, eps_rope); }
-            float a1 = p1 * c1 + p2 * s2;
-            float a2 = p2 * c2 - p1 * s1;
+            float a1 = p1 * c1[k] + p2 * s2[k];
+            float a2 = p2 * c2[k] - p1 * s1[k];
             if (eps_lin != 0.f) { a1 *= eps_ratio(x1.v[k], 1.f, eps_lin); a2 *= eps_ratio(x2.v[k], 1.f, eps_lin); }
             o1.v[k] = a1;
             o2.v[k] = a2;
@@ -430,7 +451,7 @@ extern "C" int lrp_rope_fwd(const void* x, void* xr, const float* cos_t, const f
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
         constexpr int EPC = 16 / sizeof(T);
-        const bool v = al16(x) && al16(xr) && ((d / 2) % EPC == 0) && ld_ok(ldx, EPC) && ld_ok(ldxr, EPC);
+        const bool v = al16(x) && al16(xr) && al16(cos_t) && al16(sin_t) && ((d / 2) % EPC == 0) && ld_ok(ldx, EPC) && ld_ok(ldxr, EPC);
         const int64_t work = (int64_t)rows * n_heads * (d / 2);
         if (v) hipLaunchKernelGGL((rope_fwd_kernel<T, EPC>), dim3(grid_for(work / EPC)), dim3(ENT), 0, st, (const T*)x, (T*)xr, cos_t, sin_t, rows, seq, n_heads, d, ldx, ldxr);
         else hipLaunchKernelGGL((rope_fwd_kernel<T, 1>), dim3(grid_for(work)), dim3(ENT), 0, st, (const T*)x, (T*)xr, cos_t, sin_t, rows, seq, n_heads, d, ldx, ldxr);
@@ -448,7 +469,7 @@ extern "C" int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void*
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
         constexpr int EPC = 16 / sizeof(T);
-        const bool v = al16(Gr) && al16(A) && (!xr || al16(xr)) && (!x || al16(x)) && ((d / 2) % EPC == 0) &&
+        const bool v = al16(Gr) && al16(A) && al16(cos_t) && al16(sin_t) && (!xr || al16(xr)) && (!x || al16(x)) && ((d / 2) % EPC == 0) &&
                        ld_ok(ldg, EPC) && ld_ok(lda, EPC) && ld_ok(ldxr, EPC) && ld_ok(ldx, EPC);
         const int64_t work = (int64_t)rows * n_heads * (d / 2);
         if (v) hipLaunchKernelGGL((rope_bwd_kernel<T, EPC>), dim3(grid_for(work / EPC)), dim3(ENT), 0, st, (const T*)Gr, (const T*)xr, (const T*)x, (T*)A, cos_t, sin_t, rows, seq, n_heads, d, ldg, ldxr, ldx, lda, eps_rope, eps_lin);
