@@ -162,8 +162,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(
 // never read): the line is pulled into L2 a full K step before its real staging load, which then
 // hits.  The wait at the end of a K step is a counted vmcnt(1) (the prefetch stays in flight) + raw
 // s_barrier instead of __syncthreads() (which would drain it).
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false, int NST = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt_glds_kernel(
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, int PF = 0, int NST = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : ((TBM / WM) * (TBN / WN) > 128 * 64 ? 1 : 2))) void gemm_nt_glds_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
     int tiles_m, int tiles_n) {
@@ -229,15 +229,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     // row IS one line when lda*sizeof(T) is a multiple of 128 (else it merely prefetches a neighbour)
     const T* ppf = nullptr;
     char* pf_scratch = smem + NST * STAGE + wave * 256;
-    if constexpr (PF) {
+    // PF >= 2 = COOPERATIVE prefetch, distance PF K steps: the 32 workgroups co-resident on an XCD form an 8 (tm) x 4 (tn)
+    // block of tiles (grouped_tile + xcd_remap), so an A panel is shared by 4 of them and a B panel by 8 -- each
+    // workgroup touches only ITS share (64 A rows from wave 0, 32 B rows from wave 1): 96 line requests per K step
+    // per workgroup instead of 1024, and only two waves carry a touch in their (in-order) load queue.
+    constexpr bool COOP = PF >= 2;
+    constexpr int PFD = COOP ? PF : 2;
+    const bool pf_wave = !COOP || wave < 2;
+    if constexpr (COOP) {
+        const int a = t & 7, b = (t >> 3) & 3;
+        if (wave == 0) { int gr = m0 + b * (TBM / 4) + (lane % (TBM / 4)); gr = gr < M ? gr : M - 1; ppf = A + (int64_t)gr * lda; }
+        else { int gr = n0 + a * (TBN / 8) + (lane % (TBN / 8)); gr = gr < N ? gr : N - 1; ppf = B + (int64_t)gr * ldb; }
+    } else if constexpr (PF == 1) {
         const int r = tid % (TBM + TBN);
         if (r < TBM) { int gr = m0 + r; gr = gr < M ? gr : M - 1; ppf = A + (int64_t)gr * lda; }
         else { int gr = n0 + r - TBM; gr = gr < N ? gr : N - 1; ppf = B + (int64_t)gr * ldb; }
     }
     auto prefetch = [&](int kt) {
-        if constexpr (PF) {
-            const int k = kt < nkt ? kt : nkt - 1;      // always issue exactly one (keeps the vmcnt arithmetic uniform)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ppf + (int64_t)k * KE), (lds_ptr_t)pf_scratch, 4, 0, 0);
+        if constexpr (PF != 0) {
+            if (pf_wave) {
+                const int k = kt < nkt ? kt : nkt - 1;      // always issue exactly one (keeps the vmcnt arithmetic uniform)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(ppf + (int64_t)k * KE), (lds_ptr_t)pf_scratch, 4, 0, 0);
+            }
         }
     };
     constexpr int LPS = GA + GB;                        // staging loads per K step per wave
@@ -247,8 +260,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
             if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-        } else if constexpr (PF) {
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else if constexpr (PF != 0) {
+            if (pf_wave) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
             __syncthreads();
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     } else {
-        prefetch(1);
+        prefetch(PFD - 1);
         step_sync(-1);
     }
 
@@ -273,10 +287,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
             if (kt + 2 < nkt) stage(kt + 2, (cur + 2) % 3);
         } else {
             if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-            else if constexpr (PF) {                        // keep the in-order queue shape: the older prefetch must retire
+            else if constexpr (PF != 0) {                   // keep the in-order queue shape: the older prefetch must retire
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            prefetch(kt + 2);
+            prefetch(kt + PFD);
         }
         const char* pas = smem + cur * STAGE + (wm * SM) * KB;
         const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
         step_sync(kt);
         if constexpr (NST == 3) cur = (cur + 1) % 3; else cur ^= 1;
     }
-    if constexpr (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PF != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
     }
 }
 
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, bool PF = false, int NST = 2>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, bool PRIO = false, int PF = 0, int NST = 2>
 int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
@@ -712,9 +726,13 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     if (cfg == 13) return launch_glds<T, TO, 128, 128, 2, 2, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 14) return launch_glds<T, TO, 128, 256, 2, 4, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 15) return launch_glds<T, TO, 128, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
-    if (cfg == 8) return launch_glds<T, TO, 256, 256, 4, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
-    if (cfg == 10) return launch_glds<T, TO, 256, 256, 2, 4, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
-    if (cfg == 11) return launch_glds<T, TO, 128, 128, 2, 2, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 17) return launch_glds<T, TO, 256, 256, 4, 4, false, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 18) return launch_glds<T, TO, 256, 256, 4, 4, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 19) return launch_glds<T, TO, 256, 256, 2, 4, false, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 21) return launch_glds<T, TO, 256, 256, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 8) return launch_glds<T, TO, 256, 256, 4, 4, false, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 10) return launch_glds<T, TO, 256, 256, 2, 4, false, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 11) return launch_glds<T, TO, 128, 128, 2, 2, false, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 6) return launch_glds<T, TO, 256, 256, 2, 4, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 7) return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 4) return launch_pipe<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
