@@ -367,6 +367,172 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
 
 
 // =================================================================================================
+// PERSISTENT form of the 256x256 / 16-wave kernel.  One workgroup per CU (128 KiB of LDS) walks tiles
+// vb = blockIdx.x, += gridDim.x (gridDim.x a multiple of 8, so a workgroup keeps its XCD and the 32 workgroups of an
+// XCD still cover a compact 8 x 4 block of tiles in every round).  When a tile's K loop ends, the first K step of the
+// NEXT tile is issued (both LDS stages are free after the last barrier) BEFORE the accumulators are converted and
+// stored: the cold-start latency of the next tile (all 256 CUs miss at once) hides under the store burst of this one
+// instead of following it.  Measured motive: T(tile) = 13.9 us + 0.53 us per 64-byte K slice -- at K = 4096 the
+// per-tile prologue + epilogue is 17 % of the time (profiles/r01_gemm_experiments.txt).
+// =================================================================================================
+template <typename T, typename TO>
+__global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n) {
+    constexpr int TBM = 256, TBN = 256, WN = 4, NW = 16;
+    constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
+    constexpr int SM = 64, SN = 64, FM = 4, FN = 4;
+    constexpr int GA = TBM / 8 / NW, GB = TBN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (TBM + TBN) * KB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntile = tiles_m * tiles_n;
+    const int nkt = K / KE;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    typedef typename Mma16<T>::frag frag_t;
+
+    const T* pa[GA];
+    const T* pb[GB];
+    auto set_tile = [&](int vb, int& m0, int& n0) {
+        int tm, tn;
+        grouped_tile(xcd_remap(vb, ntile), tiles_m, tiles_n, tm, tn);
+        m0 = tm * TBM;
+        n0 = tn * TBN;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            int r = m0 + (wave * GA + i) * 8 + lrow;
+            r = r < M ? r : M - 1;
+            pa[i] = A + (int64_t)r * lda + lchunk * EPC;
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            int r = n0 + (wave * GB + i) * 8 + lrow;
+            r = r < N ? r : N - 1;
+            pb[i] = B + (int64_t)r * ldb + lchunk * EPC;
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE + (wave * GA) * 1024;
+        char* sb = smem + buf * STAGE + TBM * KB + (wave * GB) * 1024;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)kt * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)kt * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
+    };
+
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    int vb = blockIdx.x;
+    int m0, n0;
+    set_tile(vb, m0, n0);
+    stage(0, 0);
+    while (true) {
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                       // K step 0 of this tile has landed (and the previous tile's stores retired)
+        int cur = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+            const char* pas = smem + cur * STAGE + (wm * SM) * KB;
+            const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                frag_t fa[FM], fb[FN];
+                const int off = ((kk * 4 + fq) ^ (frow & 7)) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * KB + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const frag_t*>(pbs + (j * 16 + frow) * KB + off);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        // both stages are free: start the next tile's first K step, then store this tile under its flight time
+        const int em0 = m0, en0 = n0;
+        vb += gridDim.x;
+        const bool more = vb < ntile;
+        if (more) {
+            set_tile(vb, m0, n0);
+            stage(0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int gm = em0 + wm * SM + i * 16 + frow;
+            if (gm >= M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int gn = en0 + wn * SN + j * 16 + fq * 4;
+                if (gn >= N) continue;
+                f32x4 v = acc[i][j];
+                if (bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+                }
+                TO* dst = C + (int64_t)gm * ldc + gn;
+                if (vec_ok && gn + 3 < N) {
+                    if constexpr (sizeof(TO) == 4) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N) dst[r] = from_f32<TO>(v[r]);
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+template <typename T, typename TO>
+int launch_persist(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                   int64_t ldc, hipStream_t st) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRP_ELAUNCH;
+        ncu = prop.multiProcessorCount & ~7;
+        if (ncu < 8) ncu = 8;
+    }
+    const int ntile = tiles_m * tiles_n;
+    dim3 grid(ntile < ncu ? ((ntile + 7) & ~7) : ncu), block(1024);
+    if ((int)grid.x > ntile) grid.x = ntile;      // tiny problems: plain one-tile-per-workgroup launch
+    const size_t lds = 2 * (size_t)512 * KB;
+    auto kern = gemm_nt_persist_kernel<T, TO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
+                       tiles_m, tiles_n);
+    return lrp_check_launch();
+}
+
+
+// =================================================================================================
 // Deep-pipelined variant: K step = 64 BYTES per row (32 bf16 / 16 fp32, ONE MFMA macro step), FOUR
 // LDS stages, loads issued three stages ahead and retired with a COUNTED s_waitcnt vmcnt(N) + raw
 // s_barrier (a __syncthreads() would drain the LDS-DMA queue to zero at every barrier and leave only
@@ -375,18 +541,18 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
 // ds_read_b128 (rows r, r+4, r+8, r+12 share a 16-bank group and get four distinct chunks).
 // One wave instruction of global_load_lds deposits 16 rows x 64 B; lane l -> row l>>2, slot l&3.
 // =================================================================================================
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, int SCHED = 0>
+__global__ __launch_bounds__(64 * WM * WN, ((TBM / WM) * (TBN / WN) > 128 * 64 ? 1 : 2)) void gemm_nt_pipe_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
     int tiles_m, int tiles_n) {
     constexpr int NW = WM * WN;
-    constexpr int RB = 64;                            // bytes of K per stage and per row
+    constexpr int RB = 64;                            // bytes of K per sub-step and per row
     constexpr int EPC = 16 / sizeof(T), KE = RB / sizeof(T);
     constexpr int SM = TBM / WM, SN = TBN / WN, FM = SM / 16, FN = SN / 16;
     constexpr int GA = TBM / 16 / NW, GB = TBN / 16 / NW;     // 1-KiB groups (16 rows) per wave per operand
-    constexpr int NST = 4, STAGE = (TBM + TBN) * RB;
-    constexpr int LPS = GA + GB;                      // loads per stage per wave
+    constexpr int NSL = 4, SLOT = (TBM + TBN) * RB;
+    constexpr int LPS = GA + GB;                      // loads per sub-step per wave
     static_assert(TBM % (16 * NW) == 0 && TBN % (16 * NW) == 0, "tile rows must split over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -400,7 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
     A += (int64_t)blockIdx.y * sA;
     B += (int64_t)blockIdx.y * sB;
     C += (int64_t)blockIdx.y * sC;
-    const int nst = K / KE;
+    const int nst = K / KE;                           // host guarantees nst >= 4
 
     const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
     const T* pa[GA];
@@ -419,15 +585,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
     }
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    // slice st -> slot st%4.  Past the end of K the LAST slice is fetched again (into a slot nobody reads any more):
+    // every sub-step issues exactly LPS loads, so the loop is branch-free and the vmcnt arithmetic uniform.
     auto stage = [&](int st) {
-        char* sa = smem + (st & (NST - 1)) * STAGE + (wave * GA) * 1024;
-        char* sb = smem + (st & (NST - 1)) * STAGE + TBM * RB + (wave * GB) * 1024;
+        char* sa = smem + (st & (NSL - 1)) * SLOT + (wave * GA) * 1024;
+        char* sb = smem + (st & (NSL - 1)) * SLOT + TBM * RB + (wave * GB) * 1024;
+        const int64_t ko = (int64_t)(st < nst ? st : nst - 1) * KE;
 #pragma unroll
         for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)st * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + ko), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)st * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + ko), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
     };
 
     f32x4 acc[FM][FN];
@@ -436,20 +605,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: stages 0..2 issued, stages 0 and 1 retired (only stage 2 may still be in flight)
-    stage(0);
-    if (nst > 1) stage(1);
-    if (nst > 2) stage(2);
-    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
     const int frow = lane & 15, fq = lane >> 4;
     typedef typename Mma16<T>::frag frag_t;
     const int foff = (fq ^ ((frow >> 2) & 3)) << 4;
     auto read_frags = [&](frag_t(&fa)[FM], frag_t(&fb)[FN], int st) {
-        const char* pas = smem + (st & (NST - 1)) * STAGE + (wm * SM) * RB;
-        const char* pbs = smem + (st & (NST - 1)) * STAGE + TBM * RB + (wn * SN) * RB;
+        const char* pas = smem + (st & (NSL - 1)) * SLOT + (wm * SM) * RB;
+        const char* pbs = smem + (st & (NSL - 1)) * SLOT + TBM * RB + (wn * SN) * RB;
 #pragma unroll
         for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const frag_t*>(pas + (i * 16 + frow) * RB + foff);
 #pragma unroll
@@ -461,28 +622,108 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
     };
-    // end of stage st: retire everything through stage st+2 (only st+3 may stay in flight), then barrier
-    auto retire = [&](int st) {
-        if (st + 3 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Slot ring (4 slots of one 64-byte K slice).  While sub-step s runs its MFMAs on REGISTER fragments, the
+    // fragments of s+1 are read from slot (s+1)%4, and slot s%4 -- whose fragments were read during sub-step s-1,
+    // by every wave, before the barrier that opened sub-step s -- is refilled with slice s+4.  A staging load so
+    // has three sub-steps (1.5 x 128 B of K) of flight time before retire(s+2) needs it; only counted vmcnt waits.
+    auto interleave = [&]() {
+        if constexpr (SCHED != 0) {
+            constexpr int NM = FM * FN, NG = LPS, ND = FM + FN;
+            // NG groups of { 1 LDS-DMA load, ND/NG ds_reads, NM/NG MFMAs }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x100, ND / NG, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NG, 0);      // MFMA
+            }
+        }
+    };
+    auto substep = [&](frag_t(&ca)[FM], frag_t(&cb)[FN], frag_t(&na)[FM], frag_t(&nb)[FN], int s) {
+        if constexpr (SCHED == 2 && sizeof(T) == 2) {
+            // hand-placed schedule: FM groups of { <=1 LDS-DMA load, next-fragment ds_reads, FN MFMAs on accumulators pinned
+            // in AGPRs (inline asm, "+a") }, each group fenced by sched_barrier(0) so the source order IS the issue order.
+            // B fragments of s+1 are read in the first half of the groups, A fragments in the second half.
+            static_assert(FM == FN && (FM % 2) == 0 && LPS <= FM, "schedule assumes a square wave tile");
+            const int st = s + 4;
+            char* sa = smem + (st & (NSL - 1)) * SLOT + (wave * GA) * 1024;
+            char* sb = smem + (st & (NSL - 1)) * SLOT + TBM * RB + (wave * GB) * 1024;
+            const int64_t ko = (int64_t)(st < nst ? st : nst - 1) * KE;
+            const char* pas = smem + ((s + 1) & (NSL - 1)) * SLOT + (wm * SM) * RB;
+            const char* pbs = smem + ((s + 1) & (NSL - 1)) * SLOT + TBM * RB + (wn * SN) * RB;
+#pragma unroll
+            for (int g = 0; g < FM; ++g) {
+                if (g < GA) __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[g] + ko), (lds_ptr_t)(sa + g * 1024), 16, 0, 0);
+                else if (g - GA < GB)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[g - GA] + ko), (lds_ptr_t)(sb + (g - GA) * 1024), 16, 0, 0);
+                if (g < FM / 2) {
+                    nb[2 * g] = *reinterpret_cast<const frag_t*>(pbs + ((2 * g) * 16 + frow) * RB + foff);
+                    nb[2 * g + 1] = *reinterpret_cast<const frag_t*>(pbs + ((2 * g + 1) * 16 + frow) * RB + foff);
+                } else {
+                    const int h = g - FM / 2;
+                    na[2 * h] = *reinterpret_cast<const frag_t*>(pas + ((2 * h) * 16 + frow) * RB + foff);
+                    na[2 * h + 1] = *reinterpret_cast<const frag_t*>(pas + ((2 * h + 1) * 16 + frow) * RB + foff);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g][j]) : "v"(cb[j]), "v"(ca[g]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // all fragments of s+1 have had >= one MFMA group to land: retire them here (nearly free) so that the next
+            // sub-step's first MFMA does not also wait for ITS freshly issued ds_reads
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0), vmcnt / expcnt untouched
+        } else {
+            stage(s + 4);
+            read_frags(na, nb, s + 1);
+            mma_all(ca, cb);
+            interleave();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");      // slices <= s+2 landed
         __builtin_amdgcn_s_barrier();
     };
-    // software pipeline over two register sets: the fragments of stage st+1 are read from LDS while the
-    // MFMAs of stage st run, so the matrix pipe never waits for ds_read latency at a stage boundary
-    frag_t a0[FM], b0[FN], a1[FM], b1[FN];
-    read_frags(a0, b0, 0);
-    for (int st = 0; st < nst; st += 2) {
-        if (st + 3 < nst) stage(st + 3);
-        if (st + 1 < nst) read_frags(a1, b1, st + 1);
-        mma_all(a0, b0);
-        retire(st);
-        if (st + 1 >= nst) break;
-        if (st + 4 < nst) stage(st + 4);
-        if (st + 2 < nst) read_frags(a0, b0, st + 2);
-        mma_all(a1, b1);
-        retire(st + 1);
-    }
 
+    frag_t a0[FM], b0[FN], a1[FM], b1[FN];
+    stage(0); stage(1); stage(2); stage(3);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(a0, b0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot 0 is refilled in sub-step 0: every wave must have read it
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nst; s += 2) {     // host guarantees nst even, >= 4
+        substep(a0, b0, a1, b1, s);
+        substep(a1, b1, a0, b0, s + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // + MFMA -> accvgpr_read wait states
+
+    if constexpr (SCHED == 2) {
+        // lean read-out (host guarantees N % 4 == 0, ldc % 4 == 0, C 16-byte aligned): one fragment at a time, fenced,
+        // so the 256 AGPR accumulators drain through a handful of VGPRs and nothing spills
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int gm = m0 + wm * SM + i * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int gn = n0 + wn * SN + j * 16 + fq * 4;
+                if (gm < M && gn < N) {
+                    f32x4 v = acc[i][j];
+                    if (bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32(bias[gn + r]);
+                    }
+                    TO* dst = C + (int64_t)gm * ldc + gn;
+                    if constexpr (sizeof(TO) == 4) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -517,13 +758,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_nt_pipe_kernel(
     }
 }
 
-template <typename T, typename TO, int TBM, int TBN, int WM, int WN>
+template <typename T, typename TO, int TBM, int TBN, int WM, int WN, int SCHED = 0>
 int launch_pipe(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
     dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
     const size_t lds = 4 * (size_t)(TBM + TBN) * 64;
-    auto kern = gemm_nt_pipe_kernel<T, TO, TBM, TBN, WM, WN>;
+    auto kern = gemm_nt_pipe_kernel<T, TO, TBM, TBN, WM, WN, SCHED>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -726,6 +967,8 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     if (cfg == 13) return launch_glds<T, TO, 128, 128, 2, 2, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 14) return launch_glds<T, TO, 128, 256, 2, 4, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 15) return launch_glds<T, TO, 128, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 25 && batch == 1) return launch_persist<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
+    if (cfg == 25) cfg = 7;
     if (cfg == 17) return launch_glds<T, TO, 256, 256, 4, 4, false, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 18) return launch_glds<T, TO, 256, 256, 4, 4, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 19) return launch_glds<T, TO, 256, 256, 2, 4, false, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
@@ -735,8 +978,17 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     if (cfg == 11) return launch_glds<T, TO, 128, 128, 2, 2, false, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 6) return launch_glds<T, TO, 256, 256, 2, 4, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 7) return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 4 || cfg == 5 || (cfg >= 22 && cfg <= 24) || cfg == 26) {
+        const int nst = K / (dtype_is_f32<T>() ? 16 : 32);
+        if (nst < 4 || (nst & 1)) cfg = 7;
+        if (cfg == 26 && ((N & 3) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15))) cfg = 7;
+    }
     if (cfg == 4) return launch_pipe<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 5) return launch_pipe<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 22) return launch_pipe<T, TO, 256, 256, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 23) return launch_pipe<T, TO, 256, 256, 2, 2, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 26) return launch_pipe<T, TO, 256, 256, 2, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 24) return launch_pipe<T, TO, 256, 256, 2, 4, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 3) return launch_glds<T, TO, 256, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 2) return launch_glds<T, TO, 256, 128, 4, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     return launch_glds<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);

@@ -36,6 +36,18 @@ def bench_gemm(dtype, shapes):
               f"   | hipBLASLt (torch) {tt*1e6:9.1f} us {2*M*N*K/tt/1e12:8.1f} TF/s", flush=True)
 
 
+def bench_gemm_pad(dtype, shapes, pads=(0, 64, 128, 192, 256, 512)):
+    """leading-dimension sweep: rows of A, B (and C) padded by `pad` elements -- power-of-two row pitches map the
+    same K slice of every row to the same L2/HBM channel (channel camping)"""
+    for (M, N, K) in shapes:
+        for pad in pads:
+            a = torch.randn(M, K + pad, device="cuda").to(dtype)[:, :K]
+            b = (torch.randn(N, K + pad, device="cuda") * K ** -0.5).to(dtype)[:, :K]
+            out = torch.empty(M, N + pad, device="cuda", dtype=dtype)[:, :N]
+            t = timeit(lambda: ops.gemm_nt_2d(a, b, out))
+            print(f"gemm-pad {str(dtype)[6:]:8s} M={M:5d} N={N:6d} K={K:6d} pad={pad:4d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+
+
 def bench_gemm_hot(dtype, shapes):
     """cache-hot variant: every row of A and B aliases row 0 (row stride 0) -> all global loads hit L1/L2;
     isolates the in-CU efficiency (LDS + MFMA + barriers) from the memory system"""
@@ -114,6 +126,8 @@ if __name__ == "__main__":
     if "hot" in a.what:
         bench_gemm(torch.bfloat16, [(8192, 4096, 4096)])
         bench_gemm_hot(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
+    if "pad" in a.what:
+        bench_gemm_pad(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
     if "onegemm" in a.what:
         bench_gemm(torch.bfloat16, [(8192, 4096, 4096), (8192, 28672, 4096), (8192, 4096, 14336)])
     elif "gemm" in a.what:
