@@ -165,6 +165,12 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
  * q_begin (0 = everything): only query rows >= q_begin are needed / carry relevance -- query blocks
  *   entirely below it are skipped (top-layer sparsity: above the last attention layer only the last
  *   token of a prompt has a non-zero seed); rows below q_begin in outputs are unspecified (fwd, dq).
+ *   row_lo / row_hi (int32 [B*S], both or neither; NULL = none): per-query-row key interval -- key j is visible to
+ *   query (b, i) only if row_lo[b*S+i] <= j < row_hi[b*S+i], IN ADDITION to (causal, window), which keep describing
+ *   the mask's structure and bound the tiles visited.  Every mask HF builds for the supported families is of this
+ *   form (left / right padding, packed sequences, Gemma-3's bidirectional image blocks: causal = 0 there).  A row
+ *   with an empty interval yields o = 0, lse = -inf and contributes nothing to dQ / dK / dV
+ *   (ref: the additive-mask argument of HF eager_attention_forward, which lxt/efficient/patches.py:193-203 wraps).
  * backward (gradient form):
  *   Gho = f Go (*) o/(o+eps_pv), f = 1/2          [lrp_attn_bwd_prep, also D = rowsum(Gho*o)]
  *   dP = Gho V^T ; dV = P^T Gho ; dS3 = P (*) (dP - D)
@@ -177,7 +183,8 @@ int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int
                         int64_t ldt, int dtype, void* stream);
 int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse,
                  int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt,
-                 int64_t ldo, float scale, int causal, int window, int q_begin, int dtype, void* stream);
+                 int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
+                 const int* row_hi, int dtype, void* stream);
 int lrp_attn_bwd_prep(const void* Go, const void* o, void* Gho, float* D, int B, int S, int Hq,
                       int d, int64_t ldgo, int64_t ldo, int64_t ldgho, float eps_pv,
                       float factor, int dtype, void* stream);
@@ -185,13 +192,14 @@ int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t
                     const float* lse, const float* D, void* dq, int B, int S, int Hq, int Hkv,
                     int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho,
                     int64_t lddq, float scale, float eps_mask, float eps_qk, int causal,
-                    int window, int q_begin, int dtype, void* stream);
+                    int window, int q_begin, const int* row_lo, const int* row_hi, int dtype,
+                    void* stream);
 int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* q_t, const void* Gho,
                      const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h,
                      int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
                      int64_t ldt, int64_t ldgho, int64_t lddk, int64_t lddv, float scale,
-                     float eps_mask, float eps_qk, int causal, int window, int q_begin, int dtype,
-                     void* stream);
+                     float eps_mask, float eps_qk, int causal, int window, int q_begin,
+                     const int* row_lo, const int* row_hi, int dtype, void* stream);
 /* out[row, hk, :] = sum_{g<rep} in[row, hk*rep+g, :]   (in: Hkv*rep heads, out: Hkv heads) */
 int lrp_gqa_reduce(const void* in, void* out, int64_t rows, int Hkv, int rep, int d, int64_t ld_in,
                    int64_t ld_out, int dtype, void* stream);

@@ -142,8 +142,10 @@ LRP_DEVICE void store_rows(T* base, int64_t ld, int row, int rows_valid, const f
     }
 }
 
-LRP_DEVICE bool visible(int q, int key, int S, int causal, int window) {
-    return key < S && (!causal || key <= q) && (window <= 0 || key > q - window);
+// (causal, window) describe the STRUCTURE of the mask (they also bound which tiles are visited); [lo, hi) is the optional
+// per-query-row key interval (padding, packed sequences, bidirectional blocks) that refines it element-wise
+LRP_DEVICE bool visible(int q, int key, int S, int causal, int window, int lo, int hi) {
+    return key < S && (!causal || key <= q) && (window <= 0 || key > q - window) && key >= lo && key < hi;
 }
 
 // =================================================================================================
@@ -152,7 +154,8 @@ LRP_DEVICE bool visible(int q, int key, int S, int causal, int window) {
 template <typename T, int D, int QSUB>
 __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
-    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int q_begin) {
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -182,6 +185,13 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
         m_run[s] = -INFINITY; l_run[s] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < ND16; ++dt) oacc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int ivlo[QSUB], ivhi[QSUB];                      // per-row key interval (whole row when no interval arrays are given)
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) {
+        const int qi = qw + s * 16 + (lane & 15);
+        ivlo[s] = 0; ivhi[s] = S;
+        if (row_lo != nullptr && qi < S) { ivlo[s] = row_lo[(int64_t)b * S + qi]; ivhi[s] = row_hi[(int64_t)b * S + qi]; }
     }
 
     int kend = S;
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
                 for (int s = 0; s < QSUB; ++s) st[s][t] = Mma16<T>::mma(kf, qf[s][c], st[s][t]);
             }
 
-        const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0);
+        const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
 #pragma unroll
         for (int s = 0; s < QSUB; ++s) {
             const int qi = qw + s * 16 + (lane & 15);
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_fwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = st[s][t][r] * scale;
-                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window)) v = -INFINITY;
+                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) v = -INFINITY;
                     st[s][t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -324,7 +334,8 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dq_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
     int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddq,
-    float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin) {
+    float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -349,6 +360,8 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dq_kernel(
     load_row_frags<T, D>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, lane);
     const float lse_q = (qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f;
     const float D_q = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
 
     f32x4 acc[ND16];
 #pragma unroll
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dq_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int key = kt0 + t * 16 + g * 4 + r;
                 const float s_raw = st[t][r];
-                const float p = visible(qi, key, S, causal, window) ? __expf(s_raw * scale - lse_q) : 0.f;
+                const float p = visible(qi, key, S, causal, window, ivlo, ivhi) ? __expf(s_raw * scale - lse_q) : 0.f;
                 st[t][r] = lrp_ds(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
             }
         frag_t df[2];
@@ -415,7 +428,8 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dkv_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
     T* __restrict__ dk, T* __restrict__ dv, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt,
-    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin) {
+    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -484,7 +498,9 @@ __global__ __launch_bounds__(ANT, (D >= 256 ? 1 : 2)) void attn_bwd_dkv_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = qt0 + t * 16 + g * 4 + r;
-                const bool ok = (qi < S) && visible(qi, ki, S, causal, window);
+                int ivlo = 0, ivhi = S;
+                if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+                const bool ok = (qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi);
                 const float lq = (qi < S) ? lse_b[qi] : 0.f;
                 const float Dq = (qi < S) ? D_b[qi] : 0.f;
                 const float s_raw = st[t][r];
@@ -567,7 +583,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
     T* __restrict__ dk, T* __restrict__ dv, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt,
-    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin) {
+    int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -643,7 +660,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = qt0 + t * 16 + g * 4 + r;
-                const bool ok = (qi < S) && visible(qi, ki, S, causal, window);
+                int ivlo = 0, ivhi = S;
+                if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+                const bool ok = (qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi);
                 const float s_raw = st[t][r];
                 const float p = ok ? __expf(s_raw * scale - l4[r]) : 0.f;
                 pp[t][r] = p;
@@ -672,7 +691,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
 template <typename T, int D, int QSUB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt, T* __restrict__ o, float* __restrict__ lse,
-    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int B, int q_begin) {
+    int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window, int B, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -704,6 +724,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
 #pragma unroll
         for (int dt = 0; dt < ND16; ++dt) oacc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    int ivlo[QSUB], ivhi[QSUB];                      // per-row key interval (whole row when no interval arrays are given)
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) {
+        const int qi = qw + s * 16 + (lane & 15);
+        ivlo[s] = 0; ivhi[s] = S;
+        if (row_lo != nullptr && qi < S) { ivlo[s] = row_lo[(int64_t)b * S + qi]; ivhi[s] = row_hi[(int64_t)b * S + qi]; }
+    }
     int kend = S;
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
 #pragma unroll
                 for (int s = 0; s < QSUB; ++s) st[s][t] = Mma16<T>::mma(kf, qf[s][c], st[s][t]);
             }
-        const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0);
+        const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
 #pragma unroll
         for (int s = 0; s < QSUB; ++s) {
             const int qi = qw + s * 16 + (lane & 15);
@@ -744,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = st[s][t][r] * scale;
-                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window)) v = -INFINITY;
+                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) v = -INFINITY;
                     st[s][t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -801,7 +828,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
     int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddq,
-    float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin) {
+    float scale, float eps_mask, float eps_qk, int causal, int window, int B, int q_begin,
+    const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
@@ -827,6 +855,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     load_row_frags<T, D>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, lane);
     const float lse_q = (qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f;
     const float D_q = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
     f32x4 acc[ND16];
 #pragma unroll
     for (int dt = 0; dt < ND16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -865,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int key = kt0 + t * 16 + g * 4 + r;
                 const float s_raw = st[t][r];
-                const float p = visible(qi, key, S, causal, window) ? __expf(s_raw * scale - lse_q) : 0.f;
+                const float p = visible(qi, key, S, causal, window, ivlo, ivhi) ? __expf(s_raw * scale - lse_q) : 0.f;
                 st[t][r] = lrp_ds2<EXPL>(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
             }
         frag_t df[2];
@@ -948,7 +978,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 template <typename T>
 static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int S, int Hq, int Hkv,
                       int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window,
-                      int q_begin, hipStream_t st) {
+                      int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
@@ -963,13 +993,13 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
                     set_lds(kern, lds);
                     dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 255) / 256)));
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
-                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin);
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
                     auto kern = attn_fwd_v2_kernel<T, DD, 1>;
                     set_lds(kern, lds);
                     dim3 grid(xcd_group_grid(B * Hkv, rep * ((S + 127) / 128)));
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq,
-                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin);
+                                       Hkv, ldq, ldk, ldt, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
                 }
             }
         })
@@ -983,7 +1013,7 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
         const int BQ = 64 * QSUB;
         dim3 grid((S + BQ - 1) / BQ, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)vt, (T*)o, lse, S, Hq, Hkv,
-                           ldq, ldk, ldt, ldo, scale, causal, window, q_begin);
+                           ldq, ldk, ldt, ldo, scale, causal, window, q_begin, row_lo, row_hi);
     })
     return lrp_check_launch();
 }
@@ -997,7 +1027,8 @@ static int attn_common_check(int B, int S, int Hq, int Hkv, int d, int dtype) {
 
 extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse, int B, int S, int Hq,
                             int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal,
-                            int window, int q_begin, int dtype, void* stream) {
+                            int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
+    if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v_t || !o || !lse) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -1005,15 +1036,15 @@ extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void*
     const int epc = dtype == LRP_F32 ? 4 : 8;
     if (!al16(q) || !al16(k) || !al16(v_t) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldt % epc) || (ldo % 4) || ldt < S) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_fwd_t<float>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, st);
-    return attn_fwd_t<bf16_t>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, st);
+    if (dtype == LRP_F32) return attn_fwd_t<float>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
+    return attn_fwd_t<bf16_t>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
 }
 
 template <typename T>
 static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt, const void* gho, const float* lse,
                      const float* D, void* dq, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
                      int64_t ldt, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
-                     int q_begin, hipStream_t st) {
+                     int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
@@ -1026,13 +1057,13 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
-                                       eps_qk, causal, window, B, q_begin);
+                                       eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
                     auto kern = attn_bwd_dq_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
-                                       eps_qk, causal, window, B, q_begin);
+                                       eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 }
             }
         })
@@ -1044,7 +1075,7 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
         set_lds(kern, lds);
         dim3 grid((S + 63) / 64, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt, (const T*)gho,
-                           lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask, eps_qk, causal, window, q_begin);
+                           lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi);
     })
     return lrp_check_launch();
 }
@@ -1052,7 +1083,8 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
 extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t, const void* Gho,
                                const float* lse, const float* D, void* dq, int B, int S, int Hq, int Hkv, int d,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho, int64_t lddq, float scale,
-                               float eps_mask, float eps_qk, int causal, int window, int q_begin, int dtype, void* stream) {
+                               float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
+    if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v || !k_t || !Gho || !lse || !D || !dq) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -1061,15 +1093,15 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
     if (!al16(q) || !al16(k) || !al16(v) || !al16(k_t) || !al16(Gho) || !al16(dq) || (ldq % epc) || (ldk % epc) ||
         (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddq % 4) || ldt < S) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, st);
-    return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, st);
+    if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+    return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
 }
 
 template <typename T>
 static int attn_dkv_t(const void* q, const void* k, const void* v, const void* qt, const void* gho, const void* ghot,
                       const float* lse, const float* D, void* dk, void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq,
                       int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddk, int64_t lddv, float scale,
-                      float eps_mask, float eps_qk, int causal, int window, int q_begin, hipStream_t st) {
+                      float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
     static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
     if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128 && S >= 1) {
@@ -1082,13 +1114,13 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
-                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin);
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
                     auto kern = attn_bwd_dkv_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
-                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin);
+                                       ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 }
             }
         })
@@ -1101,7 +1133,7 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
         dim3 grid((S + 63) / 64, Hq, B);
         hipLaunchKernelGGL(kern, grid, dim3(ANT), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt, (const T*)gho,
                            (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddk, lddv, scale,
-                           eps_mask, eps_qk, causal, window, q_begin);
+                           eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi);
     })
     return lrp_check_launch();
 }
@@ -1110,7 +1142,8 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
                                 const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h, int B, int S,
                                 int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho,
                                 int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window,
-                                int q_begin, int dtype, void* stream) {
+                                int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
+    if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v || !q_t || !Gho || !Gho_t || !lse || !D || !dk_h || !dv_h) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
     if (rc) return rc;
@@ -1120,8 +1153,8 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
         (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddk % 4) || (lddv % 4) || ldt < S)
         return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, st);
-    return attn_dkv_t<bf16_t>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, st);
+    if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+    return attn_dkv_t<bf16_t>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
 }
 
 extern "C" int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int64_t ldx, int64_t ldt,

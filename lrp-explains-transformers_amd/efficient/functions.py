@@ -88,29 +88,42 @@ class LinearFn(Function):
         return gx.view(*shp[:-1], weight_t.shape[0]), None, None, None
 
 
+def _kernel_head_dim(d, dtype):
+    """smallest head dim the attention kernels are instantiated for that holds d (SigLIP's 72, Phi's 80/96 ...)"""
+    for cand in ((16, 32, 64, 128, 256) if dtype == torch.float32 else (32, 64, 128, 256)):
+        if d <= cand:
+            return cand
+    raise NotImplementedError(f"attention head_dim {d} > 256 is not supported")
+
+
 class AttentionFn(Function):
     """K4: flash attention forward + the AttnLRP backward (softmax Prop. 3.1, uniform rule on both
     matmuls == the reference's divide_gradient(q,4),(k,4),(v,2); ref: lxt/efficient/patches.py:193-203).
     q [B,S,Hq,d], k/v [B,S,Hkv,d] (token-major views), returns o [B,S,Hq,d]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale, causal, window, cp):
-        B, S, Hq, d = q.shape
+    def forward(ctx, q, k, v, scale, causal, window, cp, row_iv=None):
+        B, S, Hq, d0 = q.shape
         Hkv = k.shape[2]
+        d = _kernel_head_dim(d0, q.dtype)
+        if d != d0:     # zero-pad the head dim to the next size the kernels are built for: scores, softmax and the
+            q, k, v = (torch.nn.functional.pad(t, (0, d - d0)) for t in (q, k, v))       # real columns are unchanged
         q2, k2, v2 = (t.reshape(B * S, -1).contiguous() for t in (q, k, v))
         v_t = ops.transpose_heads(v2, B, S, Hkv, d)
         o = torch.empty_like(q2)
         lse = torch.empty(B, Hq, S, device=q.device, dtype=torch.float32)
-        ops.attn_fwd(q2, k2, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
+        ops.attn_fwd(q2, k2, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
         ctx.save_for_backward(q2, k2, v2, o, lse)
-        ctx.meta = (B, S, Hq, Hkv, d, scale, causal, window, cp)
-        return o.view(B, S, Hq, d)
+        ctx.meta = (B, S, Hq, Hkv, d, d0, scale, causal, window, cp, row_iv)
+        return o.view(B, S, Hq, d)[..., :d0]
 
     @staticmethod
     def backward(ctx, go):
         q2, k2, v2, o, lse = ctx.saved_tensors
-        B, S, Hq, Hkv, d, scale, causal, window, cp = ctx.meta
+        B, S, Hq, Hkv, d, d0, scale, causal, window, cp, row_iv = ctx.meta
         rep = Hq // Hkv
+        if d != d0:
+            go = torch.nn.functional.pad(go, (0, d - d0))
         go2 = go.reshape(B * S, Hq * d).contiguous()
         Gho = torch.empty_like(go2)
         D = torch.empty(B, Hq, S, device=go.device, dtype=torch.float32)
@@ -118,12 +131,14 @@ class AttentionFn(Function):
         ops.attn_bwd_prep(go2, o, Gho, D, B, S, Hq, d, 0.0, 1.0 if cp else 0.5)
         q_t, Gho_t = ops.transpose_heads(q2, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)
         dk_h, dv_h = torch.empty_like(q2), torch.empty_like(q2)
-        ops.attn_bwd_dkv(q2, k2, v2, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window)
+        ops.attn_bwd_dkv(q2, k2, v2, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window,
+                         row_iv=row_iv)
         dv = ops.gqa_reduce(dv_h, torch.empty_like(v2), B * S, Hkv, rep, d)
         if cp:      # CP-LRP: q and k are detached (ref: lxt/efficient/patches.py:245-255)
-            return None, None, dv.view(B, S, Hkv, d), None, None, None, None
+            return None, None, dv.view(B, S, Hkv, d)[..., :d0], None, None, None, None, None
         k_t = ops.transpose_heads(k2, B, S, Hkv, d)
         dq = torch.empty_like(q2)
-        ops.attn_bwd_dq(q2, k2, v2, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window)
+        ops.attn_bwd_dq(q2, k2, v2, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window, row_iv=row_iv)
         dk = ops.gqa_reduce(dk_h, torch.empty_like(k2), B * S, Hkv, rep, d)
-        return dq.view(B, S, Hq, d), dk.view(B, S, Hkv, d), dv.view(B, S, Hkv, d), None, None, None, None
+        return (dq.view(B, S, Hq, d)[..., :d0], dk.view(B, S, Hkv, d)[..., :d0], dv.view(B, S, Hkv, d)[..., :d0],
+                None, None, None, None, None)

@@ -110,36 +110,54 @@ def dropout_forward(self, x):
 _MASK_VERDICTS = {}
 
 
-def _mask_kind(attention_mask, q_len, module, window=0):
-    """-> 'causal' | 'full'.  HF hands either None (sdpa/flash decide by is_causal) or an additive / boolean
-    4-D mask; the mask is checked ONCE per tensor against the pattern the kernel implements (all-visible,
-    causal, or causal with the layer's sliding window); anything else (padding) is refused.  The verdict
-    is cached by tensor identity so a forward costs one host sync per distinct mask, not one per layer."""
+def _mask_plan(attention_mask, q_len, module, window=0):
+    """-> (causal, window, row_iv): how the fused attention kernel realises HF's mask.
+
+    HF hands either None (sdpa/flash decide by is_causal) or an additive / boolean 4-D mask [B,1,S,S].  Every mask HF
+    builds for the supported families gives each query row ONE contiguous run of visible keys: causal, sliding-window
+    causal, left/right padding, packed sequences, Gemma-3's bidirectional image blocks.  The mask is therefore reduced
+    ONCE per tensor to per-row intervals [lo, hi) (one pass + one host sync, cached by tensor identity so it is not
+    repeated per layer; the entry keeps the mask alive, at most four are held); the pure patterns go to the kernels' structural fast path (no interval arrays), everything
+    else passes the int32 interval arrays.  A row whose visible keys are NOT contiguous is refused loudly."""
     if attention_mask is None:
-        return "causal" if (getattr(module, "is_causal", False) and q_len > 1) else "full"
+        causal = bool(getattr(module, "is_causal", False)) and q_len > 1
+        return causal, (int(window) if causal else 0), None
     m = attention_mask
-    key = (m.data_ptr(), tuple(m.shape), m._version, int(window))
+    # the cache entry HOLDS the mask tensor: its memory cannot be recycled for a different mask while the key is live
+    key = (m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype, m._version, int(window))
     hit = _MASK_VERDICTS.get(key)
     if hit is not None:
-        return hit
-    vis = m if m.dtype == torch.bool else (m == 0)
-    S, Sk = m.shape[-2], m.shape[-1]
-    i = torch.arange(S, device=m.device)[:, None]
-    j = torch.arange(Sk, device=m.device)[None, :]
-    causal = j <= i
-    if window > 0:
-        causal = causal & (j > i - window)
-    if bool(vis.all()) and not window:
-        kind = "full"
-    elif bool((vis == causal).all()):
-        kind = "causal"
+        return hit[0]
+    if m.dim() != 4 or m.shape[1] != 1 or m.shape[-2] != m.shape[-1]:
+        raise NotImplementedError(f"lxt_amd attention: unsupported attention_mask shape {tuple(m.shape)}")
+    vis = (m if m.dtype == torch.bool else (m == 0))[:, 0]              # [B, S, S]
+    B, S, _ = vis.shape
+    i = torch.arange(S, device=m.device)
+    cnt = vis.sum(-1, dtype=torch.int32)
+    lo = torch.where(cnt > 0, vis.to(torch.int8).argmax(-1).to(torch.int32), torch.zeros_like(cnt))
+    hi = lo + cnt
+    j = i[None, None, :]
+    contiguous = (vis == ((j >= lo[..., None]) & (j < hi[..., None]))).all()
+    live = cnt > 0                                                       # rows with an empty interval constrain nothing
+    w_lo = (i - window + 1).clamp_min(0).to(torch.int32)[None] if window > 0 else torch.zeros(1, S, dtype=torch.int32, device=m.device)
+    causal_bounded = ((hi <= (i + 1)[None]) | ~live).all()
+    window_bounded = ((lo >= w_lo) | ~live).all() if window > 0 else contiguous
+    pure_causal = ((hi == (i + 1)[None]) & (lo == w_lo)).all()
+    pure_full = ((lo == 0) & (hi == S)).all()
+    flags = torch.stack([contiguous, causal_bounded, window_bounded, pure_causal, pure_full]).tolist()   # the one host sync
+    if not flags[0]:
+        raise NotImplementedError("lxt_amd attention: a query row of this attention_mask sees a non-contiguous set of keys; "
+                                  "supported: causal / sliding-window / padding / packed / block-bidirectional masks")
+    if flags[3]:
+        plan = (True, int(window), None)
+    elif flags[4] and not window:
+        plan = (False, 0, None)
     else:
-        raise NotImplementedError("lxt_amd attention supports all-visible, causal and sliding-window-causal masks "
-                                  "(no padding masks yet)")
-    if len(_MASK_VERDICTS) > 64:
-        _MASK_VERDICTS.clear()
-    _MASK_VERDICTS[key] = kind
-    return kind
+        plan = (bool(flags[1]), int(window) if (window > 0 and flags[2]) else 0, (lo.contiguous(), hi.contiguous()))
+    if len(_MASK_VERDICTS) >= 4:
+        _MASK_VERDICTS.pop(next(iter(_MASK_VERDICTS)))      # oldest first: a forward uses at most two masks (global / sliding)
+    _MASK_VERDICTS[key] = (plan, m)
+    return plan
 
 
 def _make_attention_forward(cp):
@@ -152,12 +170,12 @@ def _make_attention_forward(cp):
         window = int(kwargs.get("sliding_window") or 0)
         if window >= S:
             window = 0
-        kind = _mask_kind(attention_mask, S, module, window)
+        causal, window, row_iv = _mask_plan(attention_mask, S, module, window)
         if kwargs.get("softcap"):
             raise NotImplementedError("attention logit soft-capping is not supported")
         scale = float(scaling) if scaling is not None else d ** -0.5
         out = AttentionFn.apply(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2), scale,
-                                kind == "causal", window, cp)
+                                causal, window, cp, row_iv)
         return out, None
     return attention_forward
 

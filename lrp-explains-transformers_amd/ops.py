@@ -318,9 +318,20 @@ def transpose_heads(x, B, S, H, d, out=None):
     return out
 
 
-def attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0, q_begin=0):
+def _iv(row_iv, B, S):
+    """(row_lo, row_hi) int32 [B, S] device tensors -> two raw pointers (0, 0 when no intervals are given)"""
+    if row_iv is None:
+        return 0, 0
+    lo, hi = row_iv
+    for t in (lo, hi):
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.numel() != B * S or not t.is_cuda:
+            raise ValueError("row intervals must be contiguous int32 CUDA tensors of B*S elements")
+    return lo.data_ptr(), hi.data_ptr()
+
+
+def attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0, q_begin=0, row_iv=None):
     check(lib.lrp_attn_fwd(p(q), p(k), p(v_t), p(o), p(lse), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v_t.stride(2),
-                           o.stride(0), scale, int(causal), window, q_begin, dt(q), stream()), "lrp_attn_fwd")
+                           o.stride(0), scale, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_fwd")
     return o, lse
 
 
@@ -330,18 +341,19 @@ def attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, eps_pv, factor=0.5):
     return Gho, D
 
 
-def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True, window=0, q_begin=0):
+def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True, window=0, q_begin=0,
+                row_iv=None):
     check(lib.lrp_attn_bwd_dq(p(q), p(k), p(v), p(k_t), p(Gho), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0),
                               k.stride(0), v.stride(0), k_t.stride(2), Gho.stride(0), dq.stride(0), scale, eps_mask, eps_qk,
-                              int(causal), window, q_begin, dt(q), stream()), "lrp_attn_bwd_dq")
+                              int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_bwd_dq")
     return dq
 
 
 def attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True,
-                 window=0, q_begin=0):
+                 window=0, q_begin=0, row_iv=None):
     check(lib.lrp_attn_bwd_dkv(p(q), p(k), p(v), p(q_t), p(Gho), p(Gho_t), p(lse), p(D), p(dk_h), p(dv_h), B, S, Hq, Hkv, d,
                                q.stride(0), k.stride(0), v.stride(0), q_t.stride(2), Gho.stride(0), dk_h.stride(0),
-                               dv_h.stride(0), scale, eps_mask, eps_qk, int(causal), window, q_begin, dt(q), stream()),
+                               dv_h.stride(0), scale, eps_mask, eps_qk, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()),
           "lrp_attn_bwd_dkv")
     return dk_h, dv_h
 

@@ -154,21 +154,30 @@ def _cp_gated_mlp_forward(self, x):
     return self.down_proj(gate * self.up_proj(x))
 
 
-def patch_instance(model, variant="attnlrp"):
+def patch_instance(model, variant="attnlrp", skip=(), attn_configs=("text_config", "vision_config")):
     """Apply the efficient AttnLRP (variant="attnlrp") or CP-LRP (variant="cp") rule placement to ONE
-    model instance (instance-level forwards + a private attention interface).  Returns the model."""
+    model instance (instance-level forwards + a private attention interface).  Returns the model.
+    skip: module-name prefixes left untouched (except nn.Linear, pinned to the host everywhere) -- the reference's
+    gemma3 map patches nothing inside the SigLIP tower (ref: lxt/efficient/models/gemma3.py:14-19);
+    attn_configs: which sub-configs get the LRP attention (the reference reaches SigLIP's attention only through the
+    process-wide sdpa registry entry, not with eager: ref lxt/efficient/patches.py:171-190)."""
     from transformers import AttentionInterface, AttentionMaskInterface
     from transformers.masking_utils import eager_mask
     cp = variant == "cp"
     name_attn = "lrp_oracle_cp" if cp else "lrp_oracle"
     AttentionInterface.register(name_attn, cp_eager_attention if cp else lrp_eager_attention)
     AttentionMaskInterface.register(name_attn, eager_mask)      # HF builds the per-layer (causal / sliding) additive masks
-    for cfg in [model.config] + [getattr(model.config, k) for k in ("text_config", "vision_config") if hasattr(model.config, k)]:
-        cfg._attn_implementation = name_attn
-    for m in model.modules():
+    subs = {k: getattr(model.config, k) for k in ("text_config", "vision_config") if hasattr(model.config, k)}
+    keep = {k: c._attn_implementation for k, c in subs.items() if k not in attn_configs}
+    model.config._attn_implementation = name_attn            # (HF propagates the top-level setting to the sub-configs)
+    for k, c in subs.items():
+        c._attn_implementation = keep.get(k, name_attn)
+    for mname, m in model.named_modules():
         name = type(m).__name__
         if isinstance(m, nn.Linear):
             m.forward = types.MethodType(_linear_forward, m)
+        elif any(mname.startswith(pre) for pre in skip):
+            continue
         elif isinstance(m, nn.Dropout):
             m.forward = types.MethodType(_dropout_forward, m)
         elif isinstance(m, nn.LayerNorm):

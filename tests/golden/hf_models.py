@@ -24,6 +24,38 @@ def build_gemma3(seed=3, attn="eager"):
     return Gemma3ForCausalLM(cfg).eval()
 
 
+def build_gemma3_mm(seed=11, attn="eager"):
+    """tiny Gemma3ForConditionalGeneration: text tower (sliding + global layers) + SigLIP tower (head_dim 72 like the real
+    SigLIP-So400m: 1152 / 16) + multi-modal projector.  HF leaves the projector weight at zeros on random init -> seeded here."""
+    from transformers import Gemma3Config, Gemma3ForConditionalGeneration
+    torch.manual_seed(seed)
+    text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, head_dim=32,
+                vocab_size=300, sliding_window=24, layer_types=["sliding_attention", "sliding_attention", "full_attention"],
+                max_position_embeddings=512, query_pre_attn_scalar=32)
+    vision = dict(hidden_size=144, intermediate_size=192, num_hidden_layers=2, num_attention_heads=2, image_size=56, patch_size=14,
+                  num_channels=3)
+    cfg = Gemma3Config(text_config=text, vision_config=vision, mm_tokens_per_image=4, image_token_id=299, boi_token_id=297,
+                       eoi_token_id=298, attn_implementation=attn)
+    m = Gemma3ForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        w = m.model.multi_modal_projector.mm_input_projection_weight
+        w.copy_(torch.randn(w.shape, generator=g) * 0.05)
+    return m
+
+
+def gemma3_mm_inputs():
+    """ids with one image (boi, 4 image tokens, eoi) inside a 48-token prompt, token_type_ids, pixel values"""
+    S = 48
+    ids = torch.randint(0, 290, (1, S), generator=torch.Generator().manual_seed(3))
+    ids[0, 10] = 297
+    ids[0, 11:15] = 299
+    ids[0, 15] = 298
+    tt = (ids == 299).long()
+    pv = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(4))
+    return ids, tt, pv
+
+
 def build_llama(seed=5, attn="eager"):
     from transformers import LlamaConfig, LlamaForCausalLM
     torch.manual_seed(seed)

@@ -100,6 +100,48 @@ def gemma3():
                         R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build_gemma3(seed=3)), seed=3, S=96)
 
 
+def _explain_mm(model, ids, tt, pv, target=None):
+    e = model.get_input_embeddings()(ids).detach().requires_grad_()
+    p_ = pv.clone().to(e.dtype).requires_grad_()
+    last = model(inputs_embeds=e, pixel_values=p_, token_type_ids=tt, use_cache=False).logits[0, -1]
+    idx = int(last.argmax()) if target is None else target
+    last[idx].backward()
+    return idx, float(last[idx]), (e * e.grad)[0].sum(-1).detach(), (p_ * p_.grad)[0].detach()
+
+
+def gemma3_mm():
+    """Gemma-3 WITH the image branch.  The reference's gemma3 map patches nothing in modeling_siglip, so
+    its semantics for the image tower are: plain gradient x input through SigLIP's LayerNorm / GELU / Linear, and the
+    AttnLRP attention rule only where the process-wide attention registry is used (sdpa), not with eager.  Both variants
+    are captured: relevance of the text tokens AND of the pixels (patch relevance = sum over a 14x14x3 patch)."""
+    from lxt.efficient import monkey_patch
+    from transformers.models.gemma3 import modeling_gemma3
+    from tests.golden.hf_models import build_gemma3_mm, gemma3_mm_inputs
+    ids, tt, pv = gemma3_mm_inputs()
+    skip = ("model.vision_tower", "model.multi_modal_projector.avg_pool")
+    orc = {}
+    for impl, acfg in (("eager", ("text_config",)), ("sdpa", ("text_config", "vision_config"))):
+        m32 = oh.patch_instance(build_gemma3_mm(attn="eager"), skip=skip, attn_configs=acfg)
+        orc[impl, 32] = _explain_mm(m32, ids, tt, pv)
+        m64 = oh.patch_instance(build_gemma3_mm(attn="eager").double(), skip=skip, attn_configs=acfg)
+        orc[impl, 64] = _explain_mm(m64, ids, tt, pv.double(), target=orc[impl, 32][0])
+    monkey_patch(modeling_gemma3)
+    save = dict(ids=ids.numpy(), token_type_ids=tt.numpy(), pixel_values=pv.numpy(), wsum=wsum(build_gemma3_mm()))
+    for impl in ("eager", "sdpa"):
+        model = build_gemma3_mm(attn=impl)
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        idx, logit, Rt, Rp = _explain_mm(model, ids, tt, pv)
+        o32, o64 = orc[impl, 32], orc[impl, 64]
+        print(f"  [gemma3_mm/{impl}] idx={idx} logit={logit:.6f} sumR text={float(Rt.sum()):.6f} image={float(Rp.sum()):.6f}")
+        print(f"     oracle fp32 vs reference: text {nmax(o32[2], Rt):.2e} pixels {nmax(o32[3], Rp):.2e} ; "
+              f"oracle fp64 vs reference: text {nmax(o64[2], Rt):.2e} pixels {nmax(o64[3], Rp):.2e}")
+        assert o32[0] == idx and nmax(o32[2], Rt) < 2e-5 and nmax(o32[3], Rp) < 2e-5
+        save.update({f"{impl}_idx": idx, f"{impl}_logit": logit, f"{impl}_R_tok": Rt.numpy(), f"{impl}_R_pix": Rp.numpy(),
+                     f"{impl}_R_tok_fp64": o64[2].float().numpy(), f"{impl}_R_pix_fp64": o64[3].float().numpy()})
+    np.savez_compressed(os.path.join(HERE, "gemma3_mm.npz"), **save)
+
+
 def family(which):
     """tiny causal LMs through the reference's own default maps: qwen2, qwen3, gpt2 (attnLRP) and llama (cp_LRP)"""
     import importlib
@@ -132,17 +174,76 @@ def family(which):
                         R_tok_fp64=o64["R_tok"].float().numpy(), wsum=wsum(build()), S=80)
 
 
+def _explain_padded(model, ids, am, pos):
+    """batch of padded prompts: seed every row's arg-max logit at its last REAL position (rows are independent)"""
+    e = model.get_input_embeddings()(ids).detach().requires_grad_()
+    logits = model(inputs_embeds=e, attention_mask=am, use_cache=False).logits
+    rows = torch.arange(ids.shape[0])
+    last = logits[rows, pos]
+    idx = last.argmax(-1)
+    last[rows, idx].sum().backward()
+    return idx, last[rows, idx].detach(), (e * e.grad).sum(-1).detach()
+
+
+def padded(fam="qwen2"):
+    """left- and right-padded batches (attention_mask given) through the reference's default map: the masks HF builds
+    from a padding mask are per-row key intervals for the fused attention kernel"""
+    import importlib
+    from lxt.efficient import monkey_patch
+    from tests.golden.hf_models import BUILDERS
+    build = BUILDERS[fam]
+    S, lens = 80, [80, 57, 33]
+    g = torch.Generator().manual_seed(4242)
+    ids = torch.randint(1, 256, (len(lens), S), generator=g)
+    out = {}
+    cases = {}
+    for side in ("left", "right"):
+        am = torch.zeros(len(lens), S, dtype=torch.long)
+        for b, n in enumerate(lens):
+            if side == "left":
+                am[b, S - n:] = 1
+            else:
+                am[b, :n] = 1
+        pos = torch.full((len(lens),), S - 1) if side == "left" else torch.tensor(lens) - 1
+        cases[side] = (am, pos)
+        m_or = oh.patch_instance(build(attn="eager"))
+        out[side, "o32"] = _explain_padded(m_or, ids, am, pos)
+        m64 = oh.patch_instance(build(attn="eager").double())
+        out[side, "o64"] = _explain_padded(m64, ids, am, pos)
+    monkey_patch(importlib.import_module(f"transformers.models.{fam}.modeling_{fam}"))
+    save = dict(ids=ids.numpy(), lens=np.array(lens), wsum=wsum(build()), S=S)
+    for side, (am, pos) in cases.items():
+        model = build(attn="eager")
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        idx, logit, R = _explain_padded(model, ids, am, pos)
+        o32, o64 = out[side, "o32"], out[side, "o64"]
+        valid = am.bool()
+        e32 = max(nmax(o32[2][b][valid[b]], R[b][valid[b]]) for b in range(len(lens)))
+        e64 = max(nmax(o64[2][b][valid[b]], R[b][valid[b]]) for b in range(len(lens)))
+        print(f"  [{fam} {side}-padded] idx={idx.tolist()} sumR={[round(float(R[b][valid[b]].sum()), 5) for b in range(len(lens))]}")
+        print(f"     oracle fp32 vs reference {e32:.2e} ; oracle fp64 vs reference {e64:.2e}")
+        assert torch.equal(o32[0], idx) and e32 < 2e-5
+        save.update({f"{side}_mask": am.numpy(), f"{side}_pos": pos.numpy(), f"{side}_idx": idx.numpy(), f"{side}_logit": logit.numpy(),
+                     f"{side}_R_tok": R.numpy(), f"{side}_R_tok_fp64": o64[2].float().numpy()})
+    np.savez_compressed(os.path.join(HERE, f"hf_{fam}_padded.npz"), **save)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     # lxt's patches are process-global: one model family per process
     if which == "all":
         import subprocess
-        for w in ("bert", "gemma3", "llama_cp", "qwen2", "qwen3", "gpt2"):
+        for w in ("bert", "gemma3", "llama_cp", "qwen2", "qwen3", "gpt2", "qwen2_padded", "gemma3_mm"):
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
     elif which == "bert":
         bert()
     elif which == "gemma3":
         gemma3()
+    elif which == "gemma3_mm":
+        gemma3_mm()
+    elif which.endswith("_padded"):
+        padded(which[:-7])
     else:
         family(which)

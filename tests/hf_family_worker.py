@@ -15,7 +15,80 @@ from tests.golden.hf_models import BUILDERS, wsum  # noqa: E402
 from tests.util import load, t, nmax  # noqa: E402
 
 
+def padded(which):
+    """left / right padded batches: HF's padding masks reach the fused attention as per-row key intervals"""
+    fam = which[:-7]
+    fx = load(f"hf_{which}.npz")
+    mod = importlib.import_module(f"transformers.models.{fam}.modeling_{fam}")
+    from lxt_amd.efficient import monkey_patch
+    monkey_patch(mod)
+    ids = t(fx["ids"]).cuda()
+    rows = torch.arange(ids.shape[0], device="cuda")
+    worst = 0.0
+    for impl in ("eager", "sdpa"):
+        model = BUILDERS[fam](attn=impl)
+        assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"]), "weights did not reproduce"
+        for p in model.parameters():
+            p.requires_grad_(False)
+        model = model.cuda()
+        for side in ("left", "right"):
+            am, pos = t(fx[f"{side}_mask"]).cuda(), t(fx[f"{side}_pos"]).cuda()
+            e = model.get_input_embeddings()(ids).detach().requires_grad_()
+            logits = model(inputs_embeds=e, attention_mask=am, use_cache=False).logits
+            last = logits[rows, pos]
+            idx = last.argmax(-1)
+            assert idx.tolist() == t(fx[f"{side}_idx"]).tolist(), (idx.tolist(), fx[f"{side}_idx"])
+            last[rows, idx].sum().backward()
+            R = (e * e.grad).sum(-1)
+            assert torch.isfinite(R).all()
+            valid = am.bool()
+            for b in range(ids.shape[0]):
+                e32 = nmax(R[b][valid[b]], t(fx[f"{side}_R_tok"])[b][valid[b].cpu()])
+                e64 = nmax(R[b][valid[b]], t(fx[f"{side}_R_tok_fp64"])[b][valid[b].cpu()])
+                worst = max(worst, e32, e64)
+            print(f"[{which}/{impl}/{side}] worst so far {worst:.2e}")
+    print(f"WORST {worst:.3e}")
+    return 0 if worst < 1e-4 else 1
+
+
+def gemma3_mm():
+    """Gemma-3 with the image branch: relevance of the text tokens and of the pixels against the
+    reference's two semantics (eager: SigLIP attention un-patched; sdpa: AttnLRP attention rule inside SigLIP too)"""
+    from transformers.models.gemma3 import modeling_gemma3
+    from lxt_amd.efficient import monkey_patch
+    from tests.golden.hf_models import build_gemma3_mm
+    fx = load("gemma3_mm.npz")
+    monkey_patch(modeling_gemma3)
+    ids, tt, pv = t(fx["ids"]).cuda(), t(fx["token_type_ids"]).cuda(), t(fx["pixel_values"]).cuda()
+    worst = 0.0
+    for impl in ("eager", "sdpa"):
+        model = build_gemma3_mm(attn=impl)
+        assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * abs(float(fx["wsum"])), "weights did not reproduce"
+        for p in model.parameters():
+            p.requires_grad_(False)
+        model = model.cuda()
+        e = model.get_input_embeddings()(ids).detach().requires_grad_()
+        px = pv.clone().requires_grad_()
+        last = model(inputs_embeds=e, pixel_values=px, token_type_ids=tt, use_cache=False).logits[0, -1]
+        idx = int(last.argmax())
+        assert idx == int(fx[f"{impl}_idx"]), (idx, int(fx[f"{impl}_idx"]))
+        last[idx].backward()
+        Rt, Rp = (e * e.grad)[0].sum(-1), (px * px.grad)[0]
+        errs = [nmax(Rt, fx[f"{impl}_R_tok"]), nmax(Rt, fx[f"{impl}_R_tok_fp64"]), nmax(Rp, fx[f"{impl}_R_pix"]), nmax(Rp, fx[f"{impl}_R_pix_fp64"])]
+        patch = Rp.reshape(3, 4, 14, 4, 14).sum((0, 2, 4))                      # relevance per ViT patch
+        ref_patch = t(fx[f"{impl}_R_pix"]).reshape(3, 4, 14, 4, 14).sum((0, 2, 4))
+        errs.append(nmax(patch, ref_patch))
+        print(f"[gemma3_mm/{impl}] text vs ref {errs[0]:.2e} / fp64 {errs[1]:.2e} | pixels vs ref {errs[2]:.2e} / fp64 {errs[3]:.2e} | patches {errs[4]:.2e}")
+        worst = max(worst, *errs)
+    print(f"WORST {worst:.3e}")
+    return 0 if worst < 1e-4 else 1
+
+
 def main(which):
+    if which == "gemma3_mm":
+        return gemma3_mm()
+    if which.endswith("_padded"):
+        return padded(which)
     fx = load(f"hf_{which}.npz")
     fam = which.replace("_cp", "")
     mod = importlib.import_module(f"transformers.models.{fam}.modeling_{fam}")

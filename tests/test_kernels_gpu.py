@@ -331,6 +331,93 @@ def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     assert nmax(dk, _tm(dK)) < tol * 3 and nmax(dv, _tm(dV)) < tol * 3
 
 
+def _intervals(kind, B, S):
+    """(lo, hi, causal_flag) int32 [B, S] for the mask families HF produces"""
+    i = torch.arange(S)
+    lo, hi = torch.zeros(B, S, dtype=torch.int32), torch.zeros(B, S, dtype=torch.int32)
+    causal = True
+    for b in range(B):
+        if kind == "left_pad":           # causal + the first n_pad keys (and query rows) are padding
+            n_pad = (7 + 13 * b) % (S // 2)
+            lo[b], hi[b] = n_pad, i + 1
+            hi[b, :n_pad] = 0             # padded query rows: empty interval
+            lo[b, :n_pad] = 0
+        elif kind == "right_pad":
+            n = S - (5 + 11 * b) % (S // 2)
+            lo[b], hi[b] = 0, torch.minimum(i + 1, torch.tensor(n))
+        elif kind == "packed":           # block-diagonal causal (packed sequences)
+            cuts = [0, S // 3 + b, (2 * S) // 3, S]
+            for a, e in zip(cuts[:-1], cuts[1:]):
+                lo[b, a:e] = a
+            hi[b] = i + 1
+        elif kind == "image_block":      # Gemma-3: causal text, bidirectional inside an image block -> not causal-bounded
+            causal = False
+            a, e = S // 4, S // 4 + S // 3
+            lo[b], hi[b] = 0, i + 1
+            hi[b, a:e] = e
+    return lo, hi, causal
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["left_pad", "right_pad", "packed", "image_block"])
+@pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40)])
+def test_attention_row_intervals(ops, dtype, kind, B, S, Hq, Hkv, d, window):
+    """per-row key intervals (padding / packed sequences / bidirectional blocks) against an fp64 eager attention with
+    the same boolean mask; rows with an empty interval must come out as exact zeros and stay NaN-free"""
+    if kind == "image_block" and window:
+        pytest.skip("bidirectional blocks are used with global layers")
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    lo, hi, causal = _intervals(kind, B, S)
+    row_iv = (lo.cuda().contiguous(), hi.cuda().contiguous())
+    q, k, v = rnd(B, Hq, S, d, dtype=dtype, seed=1), rnd(B, Hkv, S, d, dtype=dtype, seed=2), rnd(B, Hkv, S, d, dtype=dtype, seed=3)
+    scale = d ** -0.5
+    qt, kt, vt = _tm(q), _tm(k), _tm(v)
+    v_t = ops.transpose_heads(vt, B, S, Hkv, d)
+    o = torch.empty(B * S, Hq * d, dtype=dtype, device="cuda")
+    lse = torch.empty(B, Hq, S, device="cuda")
+    ops.attn_fwd(qt, kt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
+    j = torch.arange(S, device="cuda")
+    vis = (j[None, None, :] >= row_iv[0][:, :, None]) & (j[None, None, :] < row_iv[1][:, :, None])      # [B,S,S]
+    if causal:
+        vis &= (j[None, :] <= j[:, None])[None]
+    if window:
+        vis &= (j[None, :] > j[:, None] - window)[None]
+    vis = vis[:, None]                                                                                      # [B,1,S,S]
+    rep = Hq // Hkv
+    qd, kx, vx = f64(q), f64(k).repeat_interleave(rep, 1), f64(v).repeat_interleave(rep, 1)
+    s = qd @ kx.transpose(-1, -2)
+    pr = torch.nan_to_num(torch.softmax((s * scale).masked_fill(~vis, float("-inf")), -1), nan=0.0)
+    o_ref = pr @ vx
+    assert torch.isfinite(o.float()).all()
+    assert nmax(o, _tm(o_ref)) < tol
+    empty = ~vis.any(-1).expand(B, Hq, S)
+    if empty.any():
+        assert (o.float().reshape(B, S, Hq, d).permute(0, 2, 1, 3)[empty] == 0).all()
+
+    Go = rnd(B * S, Hq * d, dtype=dtype, seed=4)
+    Gho, D = torch.empty_like(Go), torch.empty(B, Hq, S, device="cuda")
+    ops.attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, 0.0, 0.5)
+    Gh = f64(Gho).reshape(B, S, Hq, d).permute(0, 2, 1, 3)
+    dP = Gh @ vx.transpose(-1, -2)
+    dS3 = pr * (dP - (dP * pr).sum(-1, keepdim=True))
+    Ghs = torch.where(vis, dS3 * scale * 0.5, torch.zeros_like(s))
+    dQ = Ghs @ kx
+    dK = (Ghs.transpose(-1, -2) @ qd).reshape(B, Hkv, rep, S, d).sum(2)
+    dV = (pr.transpose(-1, -2) @ Gh).reshape(B, Hkv, rep, S, d).sum(2)
+    k_t, q_t, Gho_t = ops.transpose_heads(kt, B, S, Hkv, d), ops.transpose_heads(qt, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)
+    dq = torch.empty_like(qt)
+    ops.attn_bwd_dq(qt, kt, vt, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window, row_iv=row_iv)
+    dk_h, dv_h = torch.empty_like(qt), torch.empty_like(qt)
+    ops.attn_bwd_dkv(qt, kt, vt, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window, row_iv=row_iv)
+    dk, dv = torch.empty_like(kt), torch.empty_like(vt)
+    ops.gqa_reduce(dk_h, dk, B * S, Hkv, rep, d)
+    ops.gqa_reduce(dv_h, dv, B * S, Hkv, rep, d)
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    assert nmax(dq, _tm(dQ)) < tol * 3
+    assert nmax(dk, _tm(dK)) < tol * 3 and nmax(dv, _tm(dV)) < tol * 3
+
+
 def test_rule_goldens_attention_pieces(ops):
     """matmul rule (Prop 3.3) and uniform-eps P.V rule against the reference's outputs, composed
     from the C-ABI GEMM + eps-scale exactly as the explicit API layer does."""
