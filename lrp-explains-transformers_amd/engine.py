@@ -108,7 +108,7 @@ class LlamaLRP:
         self.eps_g = self.eps["lin"] if mode == "explicit" else self.eps["act"]
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, emb, B, S):
+    def forward(self, emb, B, S, row_iv=None):
         c, E = self.cfg, self.eps
         H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
         M = B * S
@@ -135,7 +135,7 @@ class LlamaLRP:
             o = new(M, nq * d)
             lse = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
             if top:
-                ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1)
+                ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1, row_iv=row_iv)
                 o_l, h_l = o.index_select(0, last), st["h"].index_select(0, last)
                 a_l = ops.gemm_nt_2d(o_l, Lw["wo"], new(B, H))
                 h1_l = new(B, H)
@@ -147,7 +147,7 @@ class LlamaLRP:
                 stash.append(st)
                 h_prev, branch = h1_l, dn_l
                 break
-            ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0)
+            ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
             a = ops.gemm_nt_2d(o, Lw["wo"], new(M, H))
             h1 = new(M, H)
             x2, st["rstd2"] = ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1)
@@ -165,7 +165,7 @@ class LlamaLRP:
         hL_last = new(B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h1_last, dn_last, self.norm, c["rms_eps"], hsum_out=hL_last)
         logits = ops.gemm_nt_2d(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
-        return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits)
+        return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
 
     # ---------------------------------------------------------------------------------------------
     def backward(self, fw, emb, idx, B, S, layer_relevance=False):
@@ -183,7 +183,7 @@ class LlamaLRP:
         rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
         ops.rmsnorm_bwd_add2(Gh_last, None, None, None, fw["hL_last"], fw["dn_last"], Gs_last, A_last, rel_last,
                              0.0, E["add"], E["lin"])
-        last = fw["last"]
+        last, row_iv = fw["last"], fw["row_iv"]
         top_sparse = bool(fw["stash"]) and fw["stash"][-1].get("top", False)
         if not top_sparse:
             Gs = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, Gs_last)
@@ -237,9 +237,9 @@ class LlamaLRP:
             self.side_stream.wait_stream(main)
             with torch.cuda.stream(self.side_stream):
                 ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                                q_begin=q_begin)
+                                q_begin=q_begin, row_iv=row_iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                             q_begin=q_begin)
+                             q_begin=q_begin, row_iv=row_iv)
             main.wait_stream(self.side_stream)
             for t_ in (q, k, v, k_t, Gho, D, dqk):
                 t_.record_stream(self.side_stream)
@@ -269,10 +269,14 @@ class LlamaLRP:
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False):
+    def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False, lengths=None):
         """input_ids [B,S] (or inputs_embeds [B,S,H]); target: None (arg-max of the last position) or
         int tensor [B].  Returns dict(idx [B], logit [B], R_tok [B,S] fp32, and optionally
-        layer_R [L+1, B] (sum_h h (*) G_h at every residual-stream boundary) and G_emb [B,S,H])."""
+        layer_R [L+1, B] (sum_h h (*) G_h at every residual-stream boundary) and G_emb [B,S,H]).
+        lengths [B] (optional): prompts of different lengths in ONE call, LEFT-padded to S (prompt b occupies columns
+        S-lengths[b] .. S-1, so every prompt's explained position is still the last column).  Pad keys are masked out
+        through the attention kernels' per-row key intervals; RoPE is relative, so the result equals the un-padded
+        single-prompt explanation up to rounding.  R_tok is exactly 0 at pad positions."""
         if inputs_embeds is None:
             input_ids = input_ids.to(self.device)
             B, S = input_ids.shape
@@ -282,7 +286,17 @@ class LlamaLRP:
             emb = inputs_embeds.to(device=self.device, dtype=self.dtype).reshape(B * S, -1).contiguous()
         if S > self.max_seq:
             raise ValueError(f"sequence length {S} exceeds max_seq={self.max_seq}")
-        fw = self.forward(emb, B, S)
+        row_iv = None
+        if lengths is not None:
+            lens = torch.as_tensor(lengths, device=self.device).to(torch.int32).reshape(B)
+            if int(lens.min()) < 1 or int(lens.max()) > S:
+                raise ValueError("lengths must lie in [1, S]")
+            i = torch.arange(S, device=self.device, dtype=torch.int32)
+            first = (S - lens)[:, None]
+            lo = first.expand(B, S).contiguous()
+            hi = torch.where(i[None] >= first, (i + 1)[None].expand(B, S), torch.zeros_like(lo)).contiguous()   # pad rows: empty
+            row_iv = (lo, hi)
+        fw = self.forward(emb, B, S, row_iv)
         if target is None:
             idx, _ = ops.argmax_rows(fw["logits"])
         else:

@@ -96,6 +96,33 @@ def test_llama_ragged_lengths(eng_mod, S, B, mode):
         assert err < max(1e-4, 20 * gap), (S, b, err, gap)
 
 
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_llama_left_padded_batch(eng_mod, mode):
+    """prompts of different lengths in ONE fused call (left-padded, pad keys masked by per-row key intervals): every
+    prompt equals its own un-padded oracle explanation; pad positions carry exactly zero relevance"""
+    cfg = dict(hidden=256, inter=512, n_layers=3, n_heads=8, n_kv=2, head_dim=32, vocab=512, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=303)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512)
+    S, lens = 150, [150, 97, 31, 1]
+    ids = torch.randint(0, 512, (len(lens), S), generator=torch.Generator().manual_seed(5))
+    out = eng.explain(ids, lengths=lens)
+    assert torch.isfinite(out["R_tok"]).all()
+    for b, n in enumerate(lens):
+        sub = ids[b, S - n:]
+        single = eng.explain(sub[None], target=out["idx"][b:b + 1])                 # the same prompt alone, un-padded
+        ref = ol.explain(cfg, W, ids=sub, target=int(out["idx"][b]), mode=mode, dtype=torch.float64)
+        e_pad, e_one = nmax(out["R_tok"][b, S - n:], ref["R_tok"]), nmax(single["R_tok"][0], ref["R_tok"])
+        e_ps = nmax(out["R_tok"][b, S - n:], single["R_tok"][0])
+        assert abs(float(out["logit"][b]) - float(ref["logit"])) < 1e-4 * max(1.0, abs(float(ref["logit"])))
+        assert (out["R_tok"][b, : S - n] == 0).all()
+        if n == S:
+            assert e_ps == 0.0                                                        # no padding: bit-identical to the plain path
+        # padding must not add error beyond the instance's own conditioning (explicit mode: eps poles, SURVEY finding 3)
+        assert e_ps < max(1e-5, 3 * e_one), (b, n, e_ps, e_one)
+        if mode == "efficient":
+            assert e_pad < 1e-4, (b, n, e_pad)
+
+
 def test_full_width_properties_bf16(eng_mod):
     """BASELINE-size layer width (H 4096, I 14336, 32/8 heads, d 128, S 2048, bf16), 2 layers: no oracle at this
     size, so size-independent properties: finite, batched == single (bit for bit), sum of token relevance ==
