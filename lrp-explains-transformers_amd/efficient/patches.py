@@ -83,6 +83,28 @@ def linear_forward(self, x):
     return LinearFn.apply(x, self.weight.detach(), self.bias.detach() if self.bias is not None else None, wt)
 
 
+def conv2d_patch_forward(self, x):
+    """nn.Conv2d whose stride equals its kernel (ViT / SigLIP patch embedding) as ONE GEMM over the unfolded patches:
+    same arithmetic, un-patched (plain gradient) semantics as in the reference, but forward AND input-gradient run on
+    liblrp_hip.so instead of MIOpen (whose backward-data solver search for the 896x896, 14x14/14 SigLIP stem takes
+    minutes on a fresh box).  Any other convolution falls through to the original forward."""
+    kh, kw = self.kernel_size
+    if (x.dim() != 4 or not x.is_cuda or tuple(self.stride) != (kh, kw) or self.groups != 1 or tuple(self.dilation) != (1, 1)
+            or self.padding not in ((0, 0), "valid", 0) or self.padding_mode != "zeros" or x.dtype not in (torch.float32, torch.bfloat16)):
+        return self._conv_forward(x, self.weight, self.bias)
+    B, C, Hh, Ww = x.shape
+    gh, gw = Hh // kh, Ww // kw
+    patches = x[:, :, : gh * kh, : gw * kw].reshape(B, C, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * kh * kw)
+    w2 = self.weight.detach().reshape(self.out_channels, C * kh * kw)
+    wt = getattr(self, "_lrp_weight_t", None)
+    if wt is None or wt.device != w2.device or wt.dtype != w2.dtype or getattr(self, "_lrp_weight_ver", None) != self.weight._version:
+        from .. import ops
+        wt = ops.transpose(w2.contiguous())
+        self._lrp_weight_t, self._lrp_weight_ver = wt, self.weight._version
+    y = LinearFn.apply(patches, w2, self.bias.detach() if self.bias is not None else None, wt)
+    return y.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
+
+
 def gated_mlp_forward(self, x):
     """identity rule on the activation, uniform rule on the product (ref: patches.py:145-157)"""
     act = _act_name(self.act_fn)
