@@ -55,6 +55,9 @@ int lrp_last_hip_error(void);          /* last HIP error code seen by this threa
  *   batch >= 1 with element strides sA/sB/sC (sB may be 0 to share B).
  *   out_dtype may differ from dtype only as LRP_F32 (fp32 output from bf16 operands).
  * --------------------------------------------------------------------------------------- */
+/* dev: buf != NULL -> the persistent GEMM variant (LRP_GEMM_TILE=25) writes shader-clock stamps (16 u64 per workgroup
+ * + one per K step of workgroup 0's first tile); NULL switches it off.  Not used by the product path. */
+int lrp_debug_gemm_prof(void* buf);
 int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int batch, int64_t sA, int64_t sB, int64_t sC,

@@ -378,7 +378,7 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
 template <typename T, typename TO>
 __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, unsigned long long* __restrict__ prof) {
     constexpr int TBM = 256, TBN = 256, WN = 4, NW = 16;
     constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
     constexpr int SM = 64, SN = 64, FM = 4, FN = 4;
@@ -429,10 +429,19 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
     };
 
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const bool remap_ok = ((ldc & 7) == 0) && ((N & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     int vb = blockIdx.x;
     int m0, n0;
+    // dev timeline (prof != nullptr): per workgroup 16 shader-clock stamps [start, {landed, K loop done, stored} per tile];
+    // workgroup 0 also stamps every K step of its first tile at prof[16 * gridDim.x + kt]
+    int pe = 0;
+    auto stamp = [&]() {
+        if (prof != nullptr && tid == 0 && pe < 16) prof[(size_t)blockIdx.x * 16 + pe++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
     set_tile(vb, m0, n0);
     stage(0, 0);
+    bool first_tile = true;
     while (true) {
         f32x4 acc[FM][FN];
 #pragma unroll
@@ -440,8 +449,11 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                       // K step 0 of this tile has landed (and the previous tile's stores retired)
+        stamp();
         int cur = 0;
         for (int kt = 0; kt < nkt; ++kt) {
+            if (prof != nullptr && first_tile && blockIdx.x == 0 && tid == 0 && kt < 512)
+                prof[(size_t)gridDim.x * 16 + kt] = __builtin_amdgcn_s_memtime();
             if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
             const char* pas = smem + cur * STAGE + (wm * SM) * KB;
             const char* pbs = smem + cur * STAGE + TBM * KB + (wn * SN) * KB;
@@ -461,6 +473,8 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
             __syncthreads();
             cur ^= 1;
         }
+        stamp();
+        first_tile = false;
         // both stages are free: start the next tile's first K step, then store this tile under its flight time
         const int em0 = m0, en0 = n0;
         vb += gridDim.x;
@@ -468,6 +482,44 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
         if (more) {
             set_tile(vb, m0, n0);
             stage(0, 0);
+        }
+        if constexpr (sizeof(TO) == 2) {
+            if (remap_ok) {
+                // STORE REMAP through the idle second LDS stage (wave-private 4 KiB, no barrier: a wave's LDS ops are in order):
+                // fragments (lane = 4 columns of one row, 32-byte row segments per store) are re-read as full 128-byte row
+                // segments, so every global store instruction writes 8 complete cache lines instead of 16 quarter lines
+                char* scratch = smem + STAGE + wave * 4096;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            f32x4 v = acc[hh * 2 + i2][j];
+                            if (bias) {
+                                const int gn = en0 + wn * SN + j * 16 + fq * 4;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+                            }
+                            bf16x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                            const int r_ = i2 * 16 + frow, chunk = (j * 2 + (fq >> 1)) ^ (r_ & 7);
+                            *reinterpret_cast<bf16x4*>(scratch + r_ * 128 + chunk * 16 + (fq & 1) * 8) = o;
+                        }
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int r_ = t4 * 8 + (lane >> 3), q = lane & 7;
+                        const f32x4 val = *reinterpret_cast<const f32x4*>(scratch + r_ * 128 + ((q ^ (r_ & 7)) << 4));
+                        const int gm = em0 + wm * SM + hh * 32 + r_, gn = en0 + wn * SN + q * 8;
+                        if (gm < M && gn < N) *reinterpret_cast<f32x4*>(C + (int64_t)gm * ldc + gn) = val;
+                    }
+                }
+                stamp();
+                if (!more) break;
+                continue;
+            }
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -500,9 +552,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_persist_kernel(
                 }
             }
         }
+        stamp();
         if (!more) break;
     }
 }
+
+static unsigned long long* g_gemm_prof = nullptr;
+extern "C" int lrp_debug_gemm_prof(void* buf) { g_gemm_prof = (unsigned long long*)buf; return LRP_OK; }
 
 template <typename T, typename TO>
 int launch_persist(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -527,7 +583,7 @@ int launch_persist(const void* A, const void* B, void* C, const void* bias, int 
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
-                       tiles_m, tiles_n);
+                       tiles_m, tiles_n, g_gemm_prof);
     return lrp_check_launch();
 }
 
