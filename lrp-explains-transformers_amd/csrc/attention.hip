@@ -311,6 +311,12 @@ LRP_DEVICE float lrp_ds2(float s_raw, float p, float dp, float Dq, float scale, 
     }
 }
 
+// softmax in the log2 domain: exp(x*scale - m) = exp2(fma(x, scale*log2e, -m*log2e)) -- one v_fma + one v_exp per element
+// instead of mul, sub, mul, exp (the score kernels are VALU-bound next to their MFMAs, so element ops are what counts)
+#define LRP_LOG2E 1.4426950408889634f
+#define LRP_LN2 0.6931471805599453f
+LRP_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // XCD-aware 1-D grid decode.  Workgroups that share column-side tiles (same kv head for forward /
 // dQ, same query head for dK/dV) must sit on ONE XCD so those tiles are served by its 4 MiB L2
 // instead of being pulled through the fabric by all eight: linear id L runs on XCD L % 8, so the
@@ -615,6 +621,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
 #pragma unroll
     for (int dt = 0; dt < ND16; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    const float c1 = scale * LRP_LOG2E;
+    const int kw_max = k0 + wave * 16 + 15;            // largest key of this wave (tile-level mask test)
     int qbeg = 0, qend = S;
     if (causal) qbeg = (k0 / CT) * CT;
     if (window > 0) qend = min(S, k0 + BK - 1 + window);
@@ -653,20 +661,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
                 dp[t] = Mma16<T>::mma(rm_frag<T, D>(sG, t, c, lane), vf[c], dp[t]);
             }
         f32x4 pp[NC16];
+        // interior tiles (every query of the tile sees every key of the wave) skip the per-element mask predicate
+        const bool tile_masked = (qt0 + CT > S) || (causal && qt0 < kw_max) || (window > 0) || (row_lo != nullptr);
 #pragma unroll
         for (int t = 0; t < NC16; ++t) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + t * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qi = qt0 + t * 16 + g * 4 + r;
-                int ivlo = 0, ivhi = S;
-                if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-                const bool ok = (qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi);
                 const float s_raw = st[t][r];
-                const float p = ok ? __expf(s_raw * scale - l4[r]) : 0.f;
+                float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(l4[r] * LRP_LOG2E)));
+                if (tile_masked) {
+                    const int qi = qt0 + t * 16 + g * 4 + r;
+                    int ivlo = 0, ivhi = S;
+                    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+                    if (!((qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi))) p = 0.f;
+                }
                 pp[t][r] = p;
-                st[t][r] = lrp_ds2<EXPL>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
+                if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
+                else st[t][r] = p * (dp[t][r] - d4[r]);      // * scale/2 folded into the dK store
             }
         }
         frag_t pf[2], df[2];
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
         __syncthreads();
         cur ^= 1;
     }
-    store_rows<T, D>(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, 1.f, lane);
+    store_rows<T, D>(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, lane);
     store_rows<T, D>(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, lane);
 }
 
@@ -731,6 +744,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
         ivlo[s] = 0; ivhi[s] = S;
         if (row_lo != nullptr && qi < S) { ivlo[s] = row_lo[(int64_t)b * S + qi]; ivhi[s] = row_hi[(int64_t)b * S + qi]; }
     }
+    const float c1 = scale * LRP_LOG2E;
     int kend = S;
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
@@ -762,30 +776,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
                 for (int s = 0; s < QSUB; ++s) st[s][t] = Mma16<T>::mma(kf, qf[s][c], st[s][t]);
             }
         const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
+        // running max m_run is kept in RAW score units (scale > 0, checked by the host); probabilities in the log2 domain:
+        // p = exp2(fma(s, c1, -m*c1)) -- per element: max, fma, exp2, add
 #pragma unroll
         for (int s = 0; s < QSUB; ++s) {
             const int qi = qw + s * 16 + (lane & 15);
             float mx = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int t = 0; t < NC16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (!visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) st[s][t][r] = -INFINITY;
+            }
 #pragma unroll
             for (int t = 0; t < NC16; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = st[s][t][r] * scale;
-                    if (need_mask && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) v = -INFINITY;
-                    st[s][t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[s][t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[s], mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __expf(m_run[s] - m_use);
+            const float alpha = fast_exp2((m_run[s] - m_use) * c1);
+            const float nm2 = -m_use * c1;
             float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < NC16; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(st[s][t][r] - m_use);
+                    const float p = fast_exp2(__builtin_fmaf(st[s][t][r], c1, nm2));
                     st[s][t][r] = p;
                     rs += p;
                 }
@@ -818,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
         const int qi = qw + s * 16 + (lane & 15);
         const float inv = (l_run[s] > 0.f) ? 1.f / l_run[s] : 0.f;
         store_rows<T, D>(ob, ldo, qi, S, oacc[s], inv, lane);
-        if (g == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run[s] + __logf(l_run[s]);
+        if (g == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run[s] * scale + __logf(l_run[s]);
     }
 }
 
@@ -857,6 +876,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const float D_q = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
     int ivlo = 0, ivhi = S;
     if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+    const float c1 = scale * LRP_LOG2E, lse2_q = lse_q * LRP_LOG2E;
+    const int qw_min = q0 + wave * 16;                 // smallest query row of this wave (tile-level mask test)
     f32x4 acc[ND16];
 #pragma unroll
     for (int dt = 0; dt < ND16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -889,14 +910,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
                 st[t] = Mma16<T>::mma(rm_frag<T, D>(sK, t, c, lane), qf[c], st[t]);
                 dp[t] = Mma16<T>::mma(rm_frag<T, D>(sV, t, c, lane), gf[c], dp[t]);
             }
+        // interior tiles (every key visible to every row of the wave) skip the per-element mask predicate altogether
+        const bool tile_masked = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw_min) || (window > 0) || (row_lo != nullptr);
 #pragma unroll
         for (int t = 0; t < NC16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt0 + t * 16 + g * 4 + r;
                 const float s_raw = st[t][r];
-                const float p = visible(qi, key, S, causal, window, ivlo, ivhi) ? __expf(s_raw * scale - lse_q) : 0.f;
-                st[t][r] = lrp_ds2<EXPL>(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
+                float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q));
+                if (tile_masked && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo, ivhi)) p = 0.f;
+                if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
+                else st[t][r] = p * (dp[t][r] - D_q);        // * scale/2 folded into the final store
             }
         frag_t df[2];
 #pragma unroll
@@ -908,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
         __syncthreads();
         cur ^= 1;
     }
-    store_rows<T, D>(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, 1.f, lane);
+    store_rows<T, D>(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, lane);
 }
 
 // ---- helpers: head transpose and GQA group reduction --------------------------------------------------
@@ -1018,7 +1042,8 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
     return lrp_check_launch();
 }
 
-static int attn_common_check(int B, int S, int Hq, int Hkv, int d, int dtype) {
+static int attn_common_check(int B, int S, int Hq, int Hkv, int d, int dtype, float scale = 1.f) {
+    if (!(scale > 0.f)) return LRP_EINVAL;          // the running max is tracked on raw scores
     if (B < 0 || S < 0 || Hq < 1 || Hkv < 1 || (Hq % Hkv) || d < 16) return LRP_EINVAL;
     if (dtype != LRP_F32 && dtype != LRP_BF16) return LRP_EINVAL;
     if (B > 65535 || Hq > 65535) return LRP_ESHAPE;
@@ -1030,7 +1055,7 @@ extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void*
                             int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v_t || !o || !lse) return LRP_EINVAL;
-    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
+    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
@@ -1086,7 +1111,7 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
                                float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v || !k_t || !Gho || !lse || !D || !dq) return LRP_EINVAL;
-    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
+    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
@@ -1145,7 +1170,7 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
                                 int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v || !q_t || !Gho || !Gho_t || !lse || !D || !dk_h || !dv_h) return LRP_EINVAL;
-    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype);
+    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
