@@ -601,7 +601,7 @@ template <typename T, typename TO, int TBM, int TBN, int WM, int WN, int SCHED =
 __global__ __launch_bounds__(64 * WM * WN, ((TBM / WM) * (TBN / WN) > 128 * 64 ? 1 : 2)) void gemm_nt_pipe_kernel(
     const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
-    int tiles_m, int tiles_n) {
+    int tiles_m, int tiles_n, unsigned long long* __restrict__ prof) {
     constexpr int NW = WM * WN;
     constexpr int RB = 64;                            // bytes of K per sub-step and per row
     constexpr int EPC = 16 / sizeof(T), KE = RB / sizeof(T);
@@ -733,22 +733,29 @@ __global__ __launch_bounds__(64 * WM * WN, ((TBM / WM) * (TBN / WN) > 128 * 64 ?
             mma_all(ca, cb);
             interleave();
         }
+        const bool stamp = (prof != nullptr) && blockIdx.x == 0 && tid == 0 && s < 256;    // dev timeline, workgroup 0 only
+        if (stamp) prof[64 + 3 * s] = __builtin_amdgcn_s_memtime();                      // MFMAs issued, fragments landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");      // slices <= s+2 landed
+        if (stamp) prof[64 + 3 * s + 1] = __builtin_amdgcn_s_memtime();                  // staging loads landed
         __builtin_amdgcn_s_barrier();
+        if (stamp) prof[64 + 3 * s + 2] = __builtin_amdgcn_s_memtime();                  // barrier passed
     };
 
     frag_t a0[FM], b0[FN], a1[FM], b1[FN];
+    if (prof != nullptr && blockIdx.x == 0 && tid == 0) prof[0] = __builtin_amdgcn_s_memtime();
     stage(0); stage(1); stage(2); stage(3);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(a0, b0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot 0 is refilled in sub-step 0: every wave must have read it
     __builtin_amdgcn_s_barrier();
+    if (prof != nullptr && blockIdx.x == 0 && tid == 0) prof[1] = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < nst; s += 2) {     // host guarantees nst even, >= 4
         substep(a0, b0, a1, b1, s);
         substep(a1, b1, a0, b0, s + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // + MFMA -> accvgpr_read wait states
+    if (prof != nullptr && blockIdx.x == 0 && tid == 0) prof[2] = __builtin_amdgcn_s_memtime();
 
     if constexpr (SCHED == 2) {
         // lean read-out (host guarantees N % 4 == 0, ldc % 4 == 0, C 16-byte aligned): one fragment at a time, fenced,
@@ -827,7 +834,7 @@ int launch_pipe(const void* A, const void* B, void* C, const void* bias, int M, 
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
-                       sA, sB, sC, tiles_m, tiles_n);
+                       sA, sB, sC, tiles_m, tiles_n, SCHED == 2 ? g_gemm_prof : nullptr);
     return lrp_check_launch();
 }
 
