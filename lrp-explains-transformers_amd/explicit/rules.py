@@ -125,7 +125,8 @@ class EpsilonRule(WrapModule):
 
     def forward(self, *inputs):
         m = self.module
-        if isinstance(m, nn.Linear) and len(inputs) == 1 and inputs[0].is_cuda:
+        linear_like = isinstance(m, nn.Linear) or type(m).__name__ in ("LinearInProjection", "LinearOutProjection")
+        if linear_like and len(inputs) == 1 and inputs[0].is_cuda:
             return lf.linear_epsilon(inputs[0], m.weight, m.bias, self.epsilon)     # fused MFMA path
         return epsilon_lrp_fn.apply(m, self.epsilon, *inputs)
 

@@ -169,6 +169,36 @@ def test_modules_and_composite(lf):
     assert type(model[0]) is nn.Linear
 
 
+def test_multihead_attention_cp_golden():
+    """lxt.explicit.modules.MultiheadAttention_CP (CP-LRP attention for ViTs) against outputs, attention
+    weights and input relevance captured from the real reference (tests/golden/make_golden_mha.py): additive float
+    attn_mask, boolean key_padding_mask, no mask; EpsilonRule on v_proj / out_proj as in the reference's own test"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.explicit.modules as lm
+    import lxt_amd.explicit.rules as rules
+    fx = load("mha_cp.npz")
+    kws = dict(mask=dict(attn_mask=t(fx["attn_mask"]).cuda()), kpm=dict(key_padding_mask=t(fx["key_padding_mask"]).cuda()), none={})
+    worst = 0.0
+    for name, kw in kws.items():
+        torch.manual_seed(21)
+        gt = nn.MultiheadAttention(256, 4, batch_first=True).eval()
+        assert abs(float(sum(p.double().abs().sum() for p in gt.parameters())) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+        gt = gt.cuda()
+        layer = lm.INIT_MODULE_MAPPING[lm.MultiheadAttention_CP](gt, lm.MultiheadAttention_CP)
+        layer.v_proj = rules.EpsilonRule(layer.v_proj)
+        layer.out_proj = rules.EpsilonRule(layer.out_proj)
+        x = t(fx[f"{name}_x"]).cuda().requires_grad_()
+        y, attn = layer(x, x, x, **kw)
+        assert nmax(y, fx[f"{name}_y"]) < 1e-5 and nmax(attn, fx[f"{name}_attn"]) < 1e-5
+        y.backward(y)
+        err = max(nmax(x.grad, fx[f"{name}_R"]), nmax(x.grad, fx[f"{name}_R_fp64"]))
+        print(f"[MultiheadAttention_CP/{name}] y {nmax(y, fx[f'{name}_y']):.2e} attn {nmax(attn, fx[f'{name}_attn']):.2e} R_in {err:.2e}")
+        worst = max(worst, err)
+        assert abs(float(x.grad.sum()) - float(t(fx[f"{name}_R"]).sum())) < 1e-3 * abs(float(t(fx[f"{name}_R"]).sum()))
+    assert worst < 1e-4
+
+
 # --------------------------------------------------------------------------- efficient drop-in path
 def _hf_llama(cfg, W, attn_impl):
     from transformers import LlamaConfig, LlamaForCausalLM
