@@ -5,11 +5,13 @@ import importlib
 import warnings
 
 DEFAULT_MAP = {}
-_FAMILIES = ("llama", "qwen2", "qwen3", "gemma3", "gpt2", "bert")
+_FAMILIES = ("llama", "qwen2", "qwen3", "gemma3", "gpt2", "bert", "vit_torch")
 
 for _name in _FAMILIES:
     try:
         _m = importlib.import_module(f"{__name__}.{_name}")
+        if _m.MODELING_MODULE is None:          # vit_torch without torchvision: usable with an explicit patch_map only
+            continue
         DEFAULT_MAP[_m.MODELING_MODULE] = _m.attnLRP
     except Exception as _e:  # noqa: BLE001
         warnings.warn(f"lxt_amd.efficient.models.{_name} disabled: {_e}")

@@ -239,9 +239,42 @@ def patch_cp_attention(module):
     return _patch_attention(module, cp=True)
 
 
-def cp_multi_head_attention_forward(self, query, key, value, *args, **kwargs):
-    """ref: patches.py:258-266"""
-    return self.original_forward(stop_gradient(query), stop_gradient(key), value, *args, **kwargs)
+def cp_multi_head_attention_forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None,
+                                    average_attn_weights=True, is_causal=False):
+    """CP-LRP for torch.nn.MultiheadAttention: query and key carry no relevance (ref: patches.py:258-266, which calls the
+    original forward on detached q/k).  The case vision transformers use -- self-attention without masks, weights not
+    requested -- runs entirely on liblrp_hip.so: three projection GEMMs, the fused attention kernel with its CP backward
+    (only dV), the output GEMM.  Everything else takes the reference's route through the original forward."""
+    fast = (query.is_cuda and not need_weights and key_padding_mask is None and attn_mask is None and not is_causal
+            and self._qkv_same_embed_dim and self.bias_k is None and self.bias_v is None and not self.add_zero_attn
+            and query.dim() == 3 and query.dtype in (torch.float32, torch.bfloat16))
+    if not fast:
+        return self.original_forward(stop_gradient(query), stop_gradient(key), value, key_padding_mask=key_padding_mask,
+                                     need_weights=need_weights, attn_mask=attn_mask, average_attn_weights=average_attn_weights,
+                                     is_causal=is_causal)
+    from .. import ops
+    if not self.batch_first:
+        query, key, value = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+    B, Sq, E = query.shape
+    H, d = self.num_heads, self.head_dim
+    w, b = self.in_proj_weight.detach(), (self.in_proj_bias.detach() if self.in_proj_bias is not None else None)
+    bq, bk, bv = (b[:E], b[E: 2 * E], b[2 * E:]) if b is not None else (None, None, None)
+    with torch.no_grad():
+        q = ops.gemm_nt(query.detach().reshape(B * Sq, E).contiguous(), w[:E], bq).view(B, Sq, H, d)
+        k = ops.gemm_nt(key.detach().reshape(-1, E).contiguous(), w[E: 2 * E], bk).view(B, -1, H, d)
+    wv = w[2 * E:]
+    wvt = getattr(self, "_lrp_wv_t", None)
+    if wvt is None or wvt.device != w.device or wvt.dtype != w.dtype or getattr(self, "_lrp_w_ver", None) != self.in_proj_weight._version:
+        wvt = ops.transpose(wv.contiguous())
+        self._lrp_wv_t, self._lrp_w_ver = wvt, self.in_proj_weight._version
+    v = LinearFn.apply(value, wv, bv, wvt).view(B, -1, H, d)
+    if k.shape[1] != Sq:
+        raise NotImplementedError("lxt_amd MultiheadAttention fast path: cross attention with a different key length")
+    o = AttentionFn.apply(q, k, v, d ** -0.5, False, 0, True, None)            # cp=True: dQ = dK = 0, all relevance on V
+    out = linear_forward(self.out_proj, o.reshape(B, Sq, E))
+    if not self.batch_first:
+        out = out.transpose(0, 1)
+    return out, None
 
 
 def cp_gated_mlp_forward(self, x):

@@ -19,6 +19,9 @@ def _act_name(fn):
     """map a callable onto one of the activations the fused kernels implement (or None)"""
     import torch.nn as nn
     import torch.nn.functional as F
+    owner = getattr(fn, "__self__", None)          # bound method of an activation module (non_linear_forward keeps
+    if isinstance(owner, (nn.SiLU, nn.GELU)) and getattr(fn, "__name__", "") in ("forward", "original_forward"):   # the original forward)
+        fn = owner
     if fn in (F.silu,) or isinstance(fn, nn.SiLU):
         return "silu"
     if isinstance(fn, nn.GELU):

@@ -56,6 +56,62 @@ def gemma3_mm_inputs():
     return ids, tt, pv
 
 
+class MiniViTBlock(torch.nn.Module):
+    """pre-LN encoder block with torch.nn.MultiheadAttention(batch_first) -- the structure of torchvision's EncoderBlock"""
+
+    def __init__(self, dim, heads, mlp_dim):
+        super().__init__()
+        nn = torch.nn
+        self.ln_1 = nn.LayerNorm(dim, eps=1e-6)
+        self.self_attention = nn.MultiheadAttention(dim, heads, dropout=0.0, batch_first=True)
+        self.dropout = nn.Dropout(0.0)
+        self.ln_2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Sequential(nn.Linear(dim, mlp_dim), nn.GELU(), nn.Dropout(0.0), nn.Linear(mlp_dim, dim), nn.Dropout(0.0))
+
+    def forward(self, x):
+        y = self.ln_1(x)
+        y, _ = self.self_attention(y, y, y, need_weights=False)
+        x = x + self.dropout(y)
+        return x + self.mlp(self.ln_2(x))
+
+
+class MiniViT(torch.nn.Module):
+    """patchify Conv2d (stride = kernel) + class token + learned positions + encoder blocks + LayerNorm + linear head"""
+
+    def __init__(self, image=32, patch=8, dim=96, heads=4, mlp_dim=192, layers=3, classes=10):
+        super().__init__()
+        nn = torch.nn
+        self.conv_proj = nn.Conv2d(3, dim, patch, patch)
+        n = (image // patch) ** 2
+        self.class_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embedding = nn.Parameter(torch.empty(1, n + 1, dim).normal_(std=0.02))
+        self.layers = nn.ModuleList([MiniViTBlock(dim, heads, mlp_dim) for _ in range(layers)])
+        self.ln = nn.LayerNorm(dim, eps=1e-6)
+        self.head = nn.Linear(dim, classes)
+
+    def forward(self, x):
+        x = self.conv_proj(x).flatten(2).transpose(1, 2)
+        x = torch.cat([self.class_token.expand(x.shape[0], -1, -1), x], 1) + self.pos_embedding
+        for blk in self.layers:
+            x = blk(x)
+        return self.head(self.ln(x)[:, 0])
+
+
+def build_mini_vit(seed=31):
+    torch.manual_seed(seed)
+    m = MiniViT().eval()
+    with torch.no_grad():
+        for p in m.parameters():          # random biases / class token too: nothing in the explanation is trivially zero
+            if p.dim() == 1 or p is m.class_token:
+                p.normal_(0, 0.05)
+        for blk in m.layers:
+            blk.ln_1.weight.add_(1.0); blk.ln_2.weight.add_(1.0)
+        m.ln.weight.add_(1.0)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
+
+
 def build_llama(seed=5, attn="eager"):
     from transformers import LlamaConfig, LlamaForCausalLM
     torch.manual_seed(seed)

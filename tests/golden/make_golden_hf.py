@@ -142,6 +142,38 @@ def gemma3_mm():
     np.savez_compressed(os.path.join(HERE, "gemma3_mm.npz"), **save)
 
 
+def mini_vit():
+    """SURVEY 8f rank 3 without torchvision: a ViT built from the torch.nn classes the reference's vit_torch map patches
+    (nn.GELU identity rule, nn.LayerNorm, nn.MultiheadAttention CP-LRP: lxt/efficient/models/vit_torch.py:7-11), explained
+    with the quickstart protocol (heatmap = (x * x.grad).sum(1)).  zennit's Gamma rule is NOT part of this fixture."""
+    from functools import partial
+    from torch import nn
+    from lxt.efficient import monkey_patch
+    from lxt.efficient.patches import patch_method, non_linear_forward, layer_norm_forward, cp_multi_head_attention_forward
+    from tests.golden.hf_models import build_mini_vit
+    import types
+    cp_map = {nn.GELU: partial(patch_method, non_linear_forward, keep_original=True),
+              nn.LayerNorm: partial(patch_method, layer_norm_forward),
+              nn.MultiheadAttention: partial(patch_method, cp_multi_head_attention_forward, keep_original=True)}
+    monkey_patch(types.ModuleType("mini_vit"), cp_map)
+    x0 = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(32))
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        model = build_mini_vit().to(dt)
+        x = x0.clone().to(dt).requires_grad_()
+        y = model(x)
+        idx = y.argmax(-1)
+        y[torch.arange(2), idx].sum().backward()
+        res[dt] = (idx, y.detach(), (x * x.grad).detach())
+    gap = nmax(res[torch.float32][2], res[torch.float64][2])
+    idx, y, R = res[torch.float32]
+    print(f"  [mini_vit] idx={idx.tolist()} logits={[round(float(v), 5) for v in y[torch.arange(2), idx]]} sumR={[round(float(R[b].sum()), 5) for b in range(2)]} "
+          f"reference fp32-vs-fp64 {gap:.1e}")
+    assert gap < 5e-5
+    np.savez_compressed(os.path.join(HERE, "mini_vit.npz"), x=x0.numpy(), idx=idx.numpy(), logits=y.numpy(), R_pix=R.numpy(),
+                        R_pix_fp64=res[torch.float64][2].float().numpy(), wsum=wsum(build_mini_vit()), cond_gap=gap)
+
+
 def family(which):
     """tiny causal LMs through the reference's own default maps: qwen2, qwen3, gpt2 (attnLRP) and llama (cp_LRP)"""
     import importlib
@@ -235,7 +267,7 @@ if __name__ == "__main__":
     # lxt's patches are process-global: one model family per process
     if which == "all":
         import subprocess
-        for w in ("bert", "gemma3", "llama_cp", "qwen2", "qwen3", "gpt2", "qwen2_padded", "gemma3_mm"):
+        for w in ("bert", "gemma3", "llama_cp", "qwen2", "qwen3", "gpt2", "qwen2_padded", "gemma3_mm", "mini_vit"):
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
     elif which == "bert":
         bert()
@@ -243,6 +275,8 @@ if __name__ == "__main__":
         gemma3()
     elif which == "gemma3_mm":
         gemma3_mm()
+    elif which == "mini_vit":
+        mini_vit()
     elif which.endswith("_padded"):
         padded(which[:-7])
     else:

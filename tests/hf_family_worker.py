@@ -84,7 +84,34 @@ def gemma3_mm():
     return 0 if worst < 1e-4 else 1
 
 
+def mini_vit():
+    """ViT from torch.nn classes under lxt_amd's vit_torch cp_LRP map (explicit patch_map: torchvision is absent) against
+    the pixel relevance captured from the reference's patches; the attention runs on the HIP CP path (only dV)"""
+    import types
+    from lxt_amd.efficient import monkey_patch
+    from lxt_amd.efficient.models.vit_torch import cp_LRP
+    from tests.golden.hf_models import build_mini_vit
+    fx = load("mini_vit.npz")
+    monkey_patch(types.ModuleType("mini_vit"), cp_LRP)
+    model = build_mini_vit()
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * abs(float(fx["wsum"])), "weights did not reproduce"
+    model = model.cuda()
+    x = t(fx["x"]).cuda().requires_grad_()
+    y = model(x)
+    idx = y.argmax(-1)
+    assert idx.tolist() == t(fx["idx"]).tolist()
+    y[torch.arange(2, device="cuda"), idx].sum().backward()
+    R = x * x.grad
+    errs = [nmax(y, fx["logits"]), nmax(R, fx["R_pix"]), nmax(R, fx["R_pix_fp64"]), nmax(R.sum(1), t(fx["R_pix"]).sum(1))]
+    print(f"[mini_vit] logits {errs[0]:.2e} | pixel relevance vs ref {errs[1]:.2e} / fp64 {errs[2]:.2e} | heat-map (sum over channels) {errs[3]:.2e}")
+    worst = max(errs)
+    print(f"WORST {worst:.3e}")
+    return 0 if worst < 1e-4 else 1
+
+
 def main(which):
+    if which == "mini_vit":
+        return mini_vit()
     if which == "gemma3_mm":
         return gemma3_mm()
     if which.endswith("_padded"):
