@@ -129,3 +129,41 @@ def identity_rule_implicit(fn, x, G_out, eps=1e-10):
 def divide_gradient(x, G_out, factor=2):
     """lxt/efficient/rules.py:119-127: identity forward, G/factor backward."""
     return x, G_out / factor
+
+
+# ----------------------------------------------------------------------------- Gamma rule (zennit) -- PARITY UNPINNED
+def zennit_stabilize(x, eps):
+    """zennit.core.stabilize: x + eps * sign(x), with sign(0) := +1 (signed stabiliser, unlike lxt's own)"""
+    return x + ((x == 0.).to(x) + x.sign()) * eps
+
+
+def gamma_linear_gxi(x, weight, bias, G_out, gamma, eps=1e-6):
+    """Generalised Gamma rule for a Linear layer in lxt's gradient x input framework.
+
+    PARITY UNPINNED: the arithmetic lives in the third-party package zennit (setup.py:18 of the reference, un-pinned,
+    not vendored, NOT installed here), so this is a restatement of zennit's published rule (zennit/rules.py `Gamma`,
+    release 0.5.x: four modified passes + the plain one) composed with the reference's own hook changes
+    (lxt/efficient/zennit_patches.py:32-62: relevance = grad_output * output on entry, / stabilize(input, 1e-10) on exit).
+    No reference test or fixture touches it.
+
+      pass  input        weight              bias
+      0     x+ = max(x,0)  W + g*max(W,0)      b + g*max(b,0)
+      1     x- = min(x,0)  W + g*min(W,0)      --
+      2     x+             W + g*min(W,0)      b + g*min(b,0)
+      3     x-             W + g*max(W,0)      --
+      z = x W^T + b ; R = G*z ; s+ = [z>0] R / stab(o0+o1) ; s- = [z<0] R / stab(o2+o3)
+      R_in = x+*(s+ Wp) + x-*(s+ Wm) + x+*(s- Wm) + x-*(s- Wp) ;  G_in = R_in / stab(x, 1e-10)
+    Returns (z, G_in)."""
+    xp, xm = x.clamp(min=0), x.clamp(max=0)
+    Wp, Wm = weight + gamma * weight.clamp(min=0), weight + gamma * weight.clamp(max=0)
+    bp = bm = None
+    if bias is not None:
+        bp, bm = bias + gamma * bias.clamp(min=0), bias + gamma * bias.clamp(max=0)
+    z = F.linear(x, weight, bias)
+    zpos = F.linear(xp, Wp, bp) + F.linear(xm, Wm)
+    zneg = F.linear(xp, Wm, bm) + F.linear(xm, Wp)
+    R = G_out * z
+    sp = (z > 0).to(z) * R / zennit_stabilize(zpos, eps)
+    sn = (z < 0).to(z) * R / zennit_stabilize(zneg, eps)
+    R_in = xp * (sp @ Wp) + xm * (sp @ Wm) + xp * (sn @ Wm) + xm * (sn @ Wp)
+    return z, R_in / zennit_stabilize(x, 1e-10)
