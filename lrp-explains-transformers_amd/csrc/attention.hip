@@ -955,6 +955,38 @@ __global__ void transpose_heads_kernel(const T* x, T* xt, int S, int H, int d, i
     }
 }
 
+// 16-byte form (bf16, d % 8 == 0, S % 8 == 0, aligned): 64 x 64 tile, 16-byte loads along d, 16-byte stores along S
+__global__ __launch_bounds__(256) void transpose_heads_vec_kernel(const bf16_t* x, bf16_t* xt, int S, int H, int d, int64_t ldx, int64_t ldt) {
+    __shared__ bf16_t tile[64][66];
+    const int bh = blockIdx.z, b = bh / H, h = bh % H;
+    const bf16_t* in = x + (int64_t)b * S * ldx + (int64_t)h * d;
+    bf16_t* out = xt + (int64_t)bh * d * ldt;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256, rr = idx >> 3, ch = idx & 7;          // row of the tile, 8-element chunk along d
+        const int r = r0 + rr, c = c0 + ch * 8;
+        if (r < S && c < d) {
+            const Vec16<bf16_t> v = ld16(in + (int64_t)r * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[rr][ch * 8 + e] = v.v[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256, cc = idx >> 3, s8 = idx & 7;          // output row (d index), 8-element chunk along S
+        const int c = c0 + cc, r = r0 + s8 * 8;
+        if (c < d && r < S) {
+            Vec16<bf16_t> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = tile[s8 * 8 + e][cc];
+            st16(out + (int64_t)c * ldt + r, o);
+        }
+    }
+}
+
 template <typename T>
 __global__ void gqa_reduce_kernel(const T* in, T* out, int64_t rows, int Hkv, int rep, int d, int64_t ld_in, int64_t ld_out) {
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -1189,7 +1221,9 @@ extern "C" int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H,
     if ((int64_t)B * H > 65535 || (S + 63) / 64 > 65535) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((d + 63) / 64, (S + 63) / 64, B * H), block(256);
-    if (dtype == LRP_F32) hipLaunchKernelGGL((transpose_heads_kernel<float>), grid, block, 0, st, (const float*)x, (float*)xt, S, H, d, ldx, ldt);
+    const bool vec = dtype == LRP_BF16 && (d % 8) == 0 && (S % 8) == 0 && (ldx % 8) == 0 && (ldt % 8) == 0 && al16(x) && al16(xt);
+    if (vec) hipLaunchKernelGGL(transpose_heads_vec_kernel, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)xt, S, H, d, ldx, ldt);
+    else if (dtype == LRP_F32) hipLaunchKernelGGL((transpose_heads_kernel<float>), grid, block, 0, st, (const float*)x, (float*)xt, S, H, d, ldx, ldt);
     else if (dtype == LRP_BF16) hipLaunchKernelGGL((transpose_heads_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)xt, S, H, d, ldx, ldt);
     else return LRP_EINVAL;
     return lrp_check_launch();
