@@ -165,8 +165,22 @@ def main():
     ops.GEMM_TIMER = timer
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_step = []
+    done = []                                               # one marker event per step
     for i in range(args.steps):
         R = step(args.warmup + i)
+        ev = torch.cuda.Event()
+        ev.record()
+        done.append(ev)
+        # bounded run-ahead: the host may be at most ONE step ahead of the device.  Unbounded, it queues K steps x ~1500
+        # launches (+ two timing events per GEMM) and the HIP runtime's signal pool / queue back-pressure turns into
+        # a slow path in some processes (measured: 250 -> 400-650 ms per step, erratic); with the bound the device
+        # never idles (the next step is already queued) and the step time is reproducible.
+        if i >= 1:
+            done[i - 1].synchronize()
+        if os.environ.get("LRP_BENCH_PER_STEP"):            # dev: per-step wall times (adds a full sync per step)
+            torch.cuda.synchronize()
+            per_step.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,6 +192,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
 
+    if rank == 0 and per_step:
+        print("per-step ms:", [round((b - a) * 1e3, 1) for a, b in zip([0.0] + per_step[:-1], per_step)], file=sys.stderr)
     if rank == 0:
         n_launch, flops, secs = timer.summary()
         achieved = flops / secs / 1e12
