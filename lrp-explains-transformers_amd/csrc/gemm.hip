@@ -554,6 +554,200 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_swp_kernel(
     }
 }
 
+// ---- persistent form of the software-pipelined kernel + LDS store remap ------------------------------------------------------
+// One workgroup per CU walks tiles vb = blockIdx.x, += gridDim.x.  At the end of a tile's K loop both LDS stages are dead, so the
+// first TWO K steps of the next tile are issued at once; the accumulators are then written out through a 32 KiB scratch region above
+// the stages (wave-private 2 KiB, four passes of 16 rows, no barrier): full 128-byte row segments per store instruction instead of
+// 32-byte ones.  The store burst of a tile and the cold start of the next overlap (tools/gemm_timeline.py: 20 k -> 9 k cycles of
+// per-tile overhead on the plain persistent form).  Needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned C (host-checked).
+template <typename T, typename TO>
+__global__ __launch_bounds__(1024, 4) void gemm_nt_swpp_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n) {
+    constexpr int TBM = 256, TBN = 256, WN = 4, NW = 16;
+    constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
+    constexpr int SM = 64, SN = 64, FM = 4, FN = 4;
+    constexpr int GA = TBM / 8 / NW, GB = TBN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (TBM + TBN) * KB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntile = tiles_m * tiles_n;
+    const int nkt = K / KE;                            // host guarantees nkt >= 2
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    const int frow = lane & 15, fq = lane >> 4;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    typedef typename Mma16<T>::frag frag_t;
+
+    int m0 = 0, n0 = 0;
+    const T* pa[GA];
+    const T* pb[GB];
+    auto set_tile = [&](int vb) {
+        int tm, tn;
+        grouped_tile(xcd_remap(vb, ntile), tiles_m, tiles_n, tm, tn);
+        m0 = tm * TBM;
+        n0 = tn * TBN;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            int r = m0 + (wave * GA + i) * 8 + lrow;
+            r = r < M ? r : M - 1;
+            pa[i] = A + (int64_t)r * lda + lchunk * EPC;
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            int r = n0 + (wave * GB + i) * 8 + lrow;
+            r = r < N ? r : N - 1;
+            pb[i] = B + (int64_t)r * ldb + lchunk * EPC;
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE + (wave * GA) * 1024;
+        char* sb = smem + buf * STAGE + TBM * KB + (wave * GB) * 1024;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)kt * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)kt * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
+    };
+    const int offA = (wm * SM + frow) * KB, offB = TBM * KB + (wn * SN + frow) * KB;
+    const int sw0 = ((0 * 4 + fq) ^ (frow & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (frow & 7)) << 4;
+#define LRP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define LRP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
+#define LRP_WAIT(n, ...) asm volatile("s_waitcnt lgkmcnt(" #n ")" : __VA_ARGS__)
+    constexpr int RS = 16 * KB;
+    const unsigned cA0 = offA + sw0, cA1 = offA + sw1, cB0 = offB + sw0, cB1 = offB + sw1;
+
+    int vb = blockIdx.x;
+    set_tile(vb);
+    stage(0, 0);
+    stage(1, 1);
+    while (true) {
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma_row = [&](int i, const frag_t& a, const frag_t (&b)[FN]) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(b[j], a, acc[i][j]);
+        };
+        // both first K steps were issued before the previous tile's stores: everything this wave has in flight must land
+        // (loads and stores share vmcnt and may retire out of order with respect to each other)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        frag_t bP[FN], bQ[FN], a0, a1;
+        unsigned A0c = cA0, A1c = cA1, B0n, B1c = cB1, A0n;
+        LRP_DSRD(bP[0], cB0, 0); LRP_DSRD(bP[1], cB0, RS); LRP_DSRD(bP[2], cB0, 2 * RS); LRP_DSRD(bP[3], cB0, 3 * RS);
+        LRP_DSRD(a0, cA0, 0);
+        int cur = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            LRP_DSRD(bQ[0], B1c, 0);      LRP_DSRD(a1, A0c, RS);     LRP_WAIT(2, "+v"(a0), "+v"(bP[0]), "+v"(bP[1]), "+v"(bP[2]), "+v"(bP[3])); mma_row(0, a0, bP); LRP_FENCE();
+            LRP_DSRD(bQ[1], B1c, RS);     LRP_DSRD(a0, A0c, 2 * RS); LRP_WAIT(2, "+v"(a1)); mma_row(1, a1, bP); LRP_FENCE();
+            LRP_DSRD(bQ[2], B1c, 2 * RS); LRP_DSRD(a1, A0c, 3 * RS); LRP_WAIT(2, "+v"(a0)); mma_row(2, a0, bP); LRP_FENCE();
+            LRP_DSRD(bQ[3], B1c, 3 * RS); LRP_DSRD(a0, A1c, 0);      LRP_WAIT(2, "+v"(a1)); mma_row(3, a1, bP); LRP_FENCE();
+            LRP_DSRD(a1, A1c, RS);     LRP_WAIT(1, "+v"(a0), "+v"(bQ[0]), "+v"(bQ[1]), "+v"(bQ[2]), "+v"(bQ[3])); mma_row(0, a0, bQ); LRP_FENCE();
+            LRP_DSRD(a0, A1c, 2 * RS); LRP_WAIT(1, "+v"(a1)); mma_row(1, a1, bQ); LRP_FENCE();
+            LRP_DSRD(a1, A1c, 3 * RS); LRP_WAIT(1, "+v"(a0)); mma_row(2, a0, bQ); LRP_FENCE();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a1) : : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nkt) stage(kt + 2, cur);
+            cur ^= 1;
+            const unsigned base = (unsigned)cur * STAGE;
+            B0n = cB0 + base; A0n = cA0 + base;
+            LRP_DSRD(bP[0], B0n, 0); LRP_DSRD(bP[1], B0n, RS); LRP_DSRD(bP[2], B0n, 2 * RS); LRP_DSRD(bP[3], B0n, 3 * RS);
+            LRP_DSRD(a0, A0n, 0);
+            mma_row(3, a1, bQ); LRP_FENCE();
+            A0c = A0n; A1c = cA1 + base; B1c = cB1 + base;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave is past its (dummy) reads of the stages: they may be refilled
+        const int em0 = m0, en0 = n0;
+        vb += gridDim.x;
+        const bool more = vb < ntile;
+        if (more) {
+            set_tile(vb);
+            stage(0, 0);
+            stage(1, 1);
+        }
+        // ---- store remap: 4 passes of 16 rows x 64 columns through the wave's 2 KiB of scratch
+        char* scratch = smem + 2 * STAGE + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 v = acc[i][j];
+                if (bias) {
+                    const int gn = en0 + wn * SN + j * 16 + fq * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gn + r < N) v[r] += to_f32(bias[gn + r]);
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    const int chunk = (j * 2 + (fq >> 1)) ^ (frow & 7);
+                    *reinterpret_cast<bf16x4*>(scratch + frow * 128 + chunk * 16 + (fq & 1) * 8) = o;
+                } else {                               // fp32 output: 256-byte rows, 16 chunks, swizzle on the low 3 chunk bits
+                    const int chunk = (j * 4 + fq) ^ (frow & 7);
+                    *reinterpret_cast<f32x4*>(scratch + frow * 256 + chunk * 16) = v;
+                }
+            }
+            if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int r_ = t2 * 8 + (lane >> 3), q = lane & 7;
+                    const f32x4 val = *reinterpret_cast<const f32x4*>(scratch + r_ * 128 + ((q ^ (r_ & 7)) << 4));
+                    const int gm = em0 + wm * SM + i * 16 + r_, gn = en0 + wn * SN + q * 8;
+                    if (gm < M && gn < N) *reinterpret_cast<f32x4*>(C + (int64_t)gm * ldc + gn) = val;
+                }
+            } else {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int r_ = t4 * 4 + (lane >> 4), q = lane & 15;
+                    const f32x4 val = *reinterpret_cast<const f32x4*>(scratch + r_ * 256 + ((q ^ (r_ & 7)) << 4));
+                    const int gm = em0 + wm * SM + i * 16 + r_, gn = en0 + wn * SN + q * 4;
+                    if (gm < M && gn < N) *reinterpret_cast<f32x4*>(C + (int64_t)gm * ldc + gn) = val;
+                }
+            }
+        }
+        if (!more) break;
+    }
+#undef LRP_DSRD
+#undef LRP_WAIT
+#undef LRP_FENCE
+}
+
+template <typename T, typename TO>
+int launch_swpp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, hipStream_t st) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LRP_ELAUNCH;
+        ncu = prop.multiProcessorCount & ~7;
+        if (ncu < 8) ncu = 8;
+    }
+    const int ntile = tiles_m * tiles_n;
+    dim3 grid(ntile < ncu ? ntile : ncu), block(1024);
+    const size_t lds = 2 * (size_t)512 * KB + 16 * (sizeof(TO) == 2 ? 2048 : 4096);
+    auto kern = gemm_nt_swpp_kernel<T, TO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
+                       tiles_m, tiles_n);
+    return lrp_check_launch();
+}
+
 template <typename T, typename TO, bool ASMRD>
 int launch_swp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                int64_t ldc, hipStream_t st) {
@@ -1239,6 +1433,12 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     if (cfg == 13) return launch_glds<T, TO, 128, 128, 2, 2, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 14) return launch_glds<T, TO, 128, 256, 2, 4, false, false, 3>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     if (cfg == 15) return launch_glds<T, TO, 128, 256, 2, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    if (cfg == 29) {       // persistent + store remap: needs full-width vector stores; fp32 C would need 64 KiB of scratch (> 160 KiB LDS)
+        const bool ok = batch == 1 && K / (dtype_is_f32<T>() ? 32 : 64) >= 2 && sizeof(TO) == 2 && (N & 7) == 0 && (ldc & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+        if (ok) return launch_swpp<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
+        cfg = 28;
+    }
     if ((cfg == 27 || cfg == 28) && batch == 1 && K / (dtype_is_f32<T>() ? 32 : 64) >= 2)
         return cfg == 27 ? launch_swp<T, TO, false>(A, B, C, bias, M, N, K, lda, ldb, ldc, st)
                          : launch_swp<T, TO, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
