@@ -73,6 +73,7 @@ class LlamaLRP:
             return t.to(device=dev, dtype=dtype).contiguous()
 
         self.embed, self.norm, self.lm_head = put(W["embed"]), put(W["norm"]), put(W["lm_head"])
+        self.lm_head_t = None                        # [H, V] copy, made on the first dense-seed explanation
         self.layers = []
         for L in W["layers"]:
             wqkv = torch.cat([put(L["wq"]), put(L["wk"]), put(L["wv"])], dim=0)
@@ -168,7 +169,7 @@ class LlamaLRP:
         return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
 
     # ---------------------------------------------------------------------------------------------
-    def backward(self, fw, emb, idx, B, S, layer_relevance=False):
+    def backward(self, fw, emb, idx, B, S, layer_relevance=False, seed=None):
         c, E = self.cfg, self.eps
         H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
         M, rep = B * S, nq // nk
@@ -177,7 +178,19 @@ class LlamaLRP:
         scale = d ** -0.5
         new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
         # LM head eps rule + final-norm identity rule on the single explained row of each prompt
-        Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
+        if seed is None:
+            Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
+        else:
+            # dense seed over the last-position logits (contrastive explanations): gradient in efficient mode, relevance
+            # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm on the GEMM (W_lm^T copy made on first use: 1 GB
+            # at V = 128k, HBM is not the constraint), then the final norm's identity rule as a row scale
+            if self.lm_head_t is None:
+                self.lm_head_t = ops.transpose(self.lm_head)
+            coef = seed.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()
+            if E["lin"] != 0.0:
+                coef = ops.eps_scale(coef, fw["logits"], 1.0, E["lin"], relevance=True)
+            g_xn = ops.gemm_nt_2d(coef.to(dt), self.lm_head_t, torch.empty(B, H, device=dev, dtype=torch.float32))
+            Gh_last = (g_xn * self.norm.float()[None] * fw["rstd_f"].reshape(B, 1)).to(dt)
         # add2 at h_L = h1 + dn and the eps scale of the last down_proj, still one row per prompt
         Gs_last, A_last = new(B, H), new(B, H)
         rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
@@ -269,14 +282,18 @@ class LlamaLRP:
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False, lengths=None):
+    def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False, lengths=None,
+                seed=None):
         """input_ids [B,S] (or inputs_embeds [B,S,H]); target: None (arg-max of the last position) or
         int tensor [B].  Returns dict(idx [B], logit [B], R_tok [B,S] fp32, and optionally
         layer_R [L+1, B] (sum_h h (*) G_h at every residual-stream boundary) and G_emb [B,S,H]).
         lengths [B] (optional): prompts of different lengths in ONE call, LEFT-padded to S (prompt b occupies columns
         S-lengths[b] .. S-1, so every prompt's explained position is still the last column).  Pad keys are masked out
         through the attention kernels' per-row key intervals; RoPE is relative, so the result equals the un-padded
-        single-prompt explanation up to rounding.  R_tok is exactly 0 at pad positions."""
+        single-prompt explanation up to rounding.  R_tok is exactly 0 at pad positions.
+        seed [B,V] (optional, instead of target): what the reference's protocol passes to `logits[:, -1].backward(seed)` --
+        a gradient over the last-position logits in efficient mode (contrastive explanations), a relevance over them
+        in explicit mode."""
         if inputs_embeds is None:
             input_ids = input_ids.to(self.device)
             B, S = input_ids.shape
@@ -301,7 +318,7 @@ class LlamaLRP:
             idx, _ = ops.argmax_rows(fw["logits"])
         else:
             idx = torch.as_tensor(target, device=self.device).to(torch.int32).reshape(B).contiguous()
-        G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance)
+        G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance, seed=seed)
         R_tok = ops.readout(emb, G).view(B, S)
         out = dict(idx=idx, logit=fw["logits"].gather(1, idx.long()[:, None])[:, 0], R_tok=R_tok, logits=fw["logits"])
         if layer_relevance:

@@ -169,8 +169,11 @@ def forward(cfg, W, emb):
 
 
 # ----------------------------------------------------------------------------- backward
-def backward(cfg, W, cache, target, mode="explicit"):
-    """Gradient-form LRP backward.  Returns G at the embedding [S,H] and per-layer sum(h*G_h)."""
+def backward(cfg, W, cache, target, mode="explicit", seed=None):
+    """Gradient-form LRP backward.  Returns G at the embedding [S,H] and per-layer sum(h*G_h).
+    seed [V] (optional, instead of target): what the user hands to `logits[0,-1].backward(seed)` -- a GRADIENT over the
+    last-position logits in efficient mode (contrastive explanations, ref docs/source/quickstart.rst:267-270), a
+    RELEVANCE over them in explicit mode (ref examples/paper/llama.py:45: `.backward(logit)` is the one-hot case)."""
     E = eps_table(mode)
     S = cache["hf"].shape[0]
     d, nq, nk = cfg["head_dim"], cfg["n_heads"], cfg["n_kv"]
@@ -179,8 +182,13 @@ def backward(cfg, W, cache, target, mode="explicit"):
     dt = cache["hf"].dtype
 
     # seed: explicit .backward(logit) <=> G = 1 at the explained logit
-    z = cache["logits_last"][target]
-    g_xn_last = ratio(z, 1, E["lin"]) * W["lm_head"][target]       # Linear eps rule, single row/col
+    if seed is None:
+        z = cache["logits_last"][target]
+        g_xn_last = ratio(z, 1, E["lin"]) * W["lm_head"][target]   # Linear eps rule, single row/col
+    else:
+        zl = cache["logits_last"]
+        coef = seed.to(zl.dtype) / (zl + E["lin"]) if mode == "explicit" else seed.to(zl.dtype)
+        g_xn_last = coef @ W["lm_head"]                            # Linear eps rule over every seeded logit
     Gh = torch.zeros(S, cfg["hidden"], dtype=dt)
     Gh[-1] = g_xn_last * W["norm"] * cache["rstdf"][-1]            # RMSNorm identity rule
     layer_R = [float((cache["hf"] * Gh).sum())]
@@ -237,7 +245,7 @@ def backward(cfg, W, cache, target, mode="explicit"):
     return Gh, layer_R[::-1]
 
 
-def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32):
+def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32, seed=None):
     """One explanation: returns dict(idx, logit, R_tok [S], R_emb [S,H], layer_R [L+1])."""
     Wd = cast_weights(W, dtype)
     if emb is None:
@@ -246,7 +254,7 @@ def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torc
     cache = forward(cfg, Wd, emb)
     if target is None:
         target = int(cache["logits_last"].argmax())
-    G, layer_R = backward(cfg, Wd, cache, target, mode)
+    G, layer_R = backward(cfg, Wd, cache, target, mode, seed=seed)
     R_emb = emb * G
     return dict(idx=target, logit=float(cache["logits_last"][target]), R_tok=R_emb.sum(-1),
                 R_emb=R_emb, layer_R=layer_R, logits_last=cache["logits_last"])

@@ -123,6 +123,33 @@ def test_llama_left_padded_batch(eng_mod, mode):
             assert e_pad < 1e-4, (b, n, e_pad)
 
 
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_llama_dense_seed_contrastive(eng_mod, mode):
+    """`logits[0,-1].backward(mask)` with a dense mask (contrastive explanation, ref docs/source/quickstart.rst:267-270):
+    +1 on the arg-max logit, -1/V elsewhere; explicit mode seeds that pattern as relevance (mask * logits)"""
+    cfg = dict(hidden=256, inter=512, n_layers=3, n_heads=8, n_kv=2, head_dim=32, vocab=512, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=311)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=256)
+    ids = torch.randint(0, 512, (2, 96), generator=torch.Generator().manual_seed(9))
+    base = eng.explain(ids)
+    V = cfg["vocab"]
+    mask = torch.full((2, V), -1.0 / V)
+    mask[torch.arange(2), base["idx"].long().cpu()] = 1.0
+    seed = mask * base["logits"].cpu() if mode == "explicit" else mask
+    out = eng.explain(ids, seed=seed)
+    one_hot = torch.zeros(2, V)
+    one_hot[torch.arange(2), base["idx"].long().cpu()] = 1.0
+    out1 = eng.explain(ids, seed=(one_hot * base["logits"].cpu() if mode == "explicit" else one_hot))
+    for b in range(2):
+        assert nmax(out1["R_tok"][b], base["R_tok"][b]) < 1e-5               # a one-hot seed is the target path
+        ref = ol.explain(cfg, W, ids=ids[b], mode=mode, dtype=torch.float64, seed=seed[b].double())
+        ref32 = ol.explain(cfg, W, ids=ids[b], mode=mode, dtype=torch.float32, seed=seed[b])
+        gap = nmax(ref32["R_tok"], ref["R_tok"])
+        err = nmax(out["R_tok"][b], ref["R_tok"])
+        print(f"[dense seed {mode} prompt {b}] engine vs oracle fp64 {err:.2e} (oracle fp32-vs-fp64 {gap:.1e})")
+        assert err < max(1e-4, 20 * gap)
+
+
 def test_full_width_properties_bf16(eng_mod):
     """BASELINE-size layer width (H 4096, I 14336, 32/8 heads, d 128, S 2048, bf16), 2 layers: no oracle at this
     size, so size-independent properties: finite, batched == single (bit for bit), sum of token relevance ==
