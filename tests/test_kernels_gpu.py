@@ -50,6 +50,24 @@ def test_gemm_nt(ops, dtype, M, N, K):
         assert nmax(out[:K], f64(b).T[:K]) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(3301, 3700, 192), (4096, 3100, 128), (3600, 3584, 64), (3333, 3841, 320)])
+def test_gemm_nt_big_tile_path(ops, dtype, M, N, K):
+    """>= 190 tiles of 256x256: the software-pipelined 16-wave kernel (ragged M / N: clamped rows, odd and minimal numbers
+    of K steps; one K step falls back to the plain form), bias, row strides larger than K"""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K + 64, generator=g).to(dtype).cuda()[:, :K]
+    b = (torch.randn(N, K + 64, generator=g) * K ** -0.5).to(dtype).cuda()[:, :K]
+    bias = torch.randn(N, generator=g).to(dtype).cuda()
+    out = torch.empty(M, N + 8, dtype=dtype, device="cuda")[:, :N]
+    ops.gemm_nt_2d(a, b, out, bias)
+    ref = f64(a) @ f64(b).T + f64(bias)
+    assert nmax(out, ref) < TOL[dtype]
+    # every tile, not only the largest entries: block-wise normalised error
+    blk = (out.double() - ref).abs().reshape(-1)[: (M * N // 4096) * 4096].reshape(-1, 4096).max(1).values
+    assert float(blk.max()) < 4 * TOL[dtype] * float(ref.abs().max())
+
+
 def test_gemm_batched_and_f32_out(ops):
     a, b = rnd(3, 70, 96, seed=4), rnd(3, 50, 96, seed=5)
     assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).transpose(1, 2)) < 2e-5
