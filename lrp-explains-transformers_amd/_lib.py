@@ -23,7 +23,8 @@ _CTYPE = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_floa
 
 def parse_header(path=HEADER_PATH):
     """-> {name: (restype_str, [argtype_str...])} for every function the header declares."""
-    src = open(path).read()
+    with open(path) as f:
+        src = f.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(lrp_\w+)\s*\(([^)]*)\)\s*;", src):
