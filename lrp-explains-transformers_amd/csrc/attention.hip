@@ -841,8 +841,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
     }
 }
 
-// ---- v2 dQ: 8 waves x 16 queries, K + V + K^T tiles, two LDS stages --------------------------------
-template <typename T, int D, bool EXPL>
+// ---- v2 dQ: 8 waves x (16*QS) queries, K + V + K^T tiles, two LDS stages ---------------------------------
+// QS = 2 (dev knob LRP_ATTN_DQ_QS=2): two 16-row sub-tiles per wave.  With 16 rows per wave every column-side fragment read
+// feeds ONE MFMA (48 ds_read_b128 : 48 MFMA per tile step and wave) and the kernel is LDS-bandwidth-bound (8 waves x 48 x 8
+// clk = 3072 clk of LDS per workgroup step vs 1536 clk of MFMA per SIMD); with two sub-tiles each fragment feeds two MFMAs
+// at the same occupancy (96 KiB of LDS allow one workgroup per CU either way; 2 waves per SIMD = 256 VGPRs).
+template <typename T, int D, bool EXPL, int QS>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
-    constexpr int NW = 8, BQ = NW * 16;
+    constexpr int NW = 8, BQ = NW * 16 * QS;
     constexpr int TILE = 128 * D, STAGE = 3 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -863,24 +867,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
     const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
     const int qblk = nqb - 1 - item / rep;
-    const int q0 = qblk * BQ, qi = q0 + wave * 16 + (lane & 15);
+    const int q0 = qblk * BQ, qw = q0 + wave * 16 * QS;
     if (q0 + BQ <= q_begin) return;
     const T* kb = k + (int64_t)b * S * ldk + (int64_t)hk * D;
     const T* vb = v + (int64_t)b * S * ldv + (int64_t)hk * D;
     const T* ktb = kt + ((int64_t)b * Hkv + hk) * D * ldt;
 
-    frag_t qf[NDC], gf[NDC];
-    load_row_frags<T, D>(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, lane);
-    load_row_frags<T, D>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, lane);
-    const float lse_q = (qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f;
-    const float D_q = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
-    int ivlo = 0, ivhi = S;
-    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-    const float c1 = scale * LRP_LOG2E, lse2_q = lse_q * LRP_LOG2E;
-    const int qw_min = q0 + wave * 16;                 // smallest query row of this wave (tile-level mask test)
-    f32x4 acc[ND16];
+    frag_t qf[QS][NDC], gf[QS][NDC];
+    float lse2_q[QS], D_q[QS];
+    int ivlo[QS], ivhi[QS], qi[QS];
+    f32x4 acc[QS][ND16];
 #pragma unroll
-    for (int dt = 0; dt < ND16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < QS; ++s) {
+        qi[s] = qw + s * 16 + (lane & 15);
+        load_row_frags<T, D>(qf[s], q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi[s], S, lane);
+        load_row_frags<T, D>(gf[s], gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi[s], S, lane);
+        lse2_q[s] = ((qi[s] < S) ? lse[((int64_t)b * Hq + h) * S + qi[s]] : 0.f) * LRP_LOG2E;
+        D_q[s] = (qi[s] < S) ? Dd[((int64_t)b * Hq + h) * S + qi[s]] : 0.f;
+        ivlo[s] = 0; ivhi[s] = S;
+        if (row_lo != nullptr && qi[s] < S) { ivlo[s] = row_lo[(int64_t)b * S + qi[s]]; ivhi[s] = row_hi[(int64_t)b * S + qi[s]]; }
+#pragma unroll
+        for (int dt = 0; dt < ND16; ++dt) acc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c1 = scale * LRP_LOG2E;
     int kend = S;
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
@@ -900,39 +909,54 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
         const char* sK = smem + cur * STAGE;
         const char* sV = sK + TILE;
         const char* sKt = sK + 2 * TILE;
-        f32x4 st[NC16], dp[NC16];
+        f32x4 st[QS][NC16], dp[QS][NC16];
 #pragma unroll
-        for (int t = 0; t < NC16; ++t) { st[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int s = 0; s < QS; ++s)
+#pragma unroll
+            for (int t = 0; t < NC16; ++t) { st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[s][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int t = 0; t < NC16; ++t)
 #pragma unroll
             for (int c = 0; c < NDC; ++c) {
-                st[t] = Mma16<T>::mma(rm_frag<T, D>(sK, t, c, lane), qf[c], st[t]);
-                dp[t] = Mma16<T>::mma(rm_frag<T, D>(sV, t, c, lane), gf[c], dp[t]);
+                const frag_t kf = rm_frag<T, D>(sK, t, c, lane), vf = rm_frag<T, D>(sV, t, c, lane);
+#pragma unroll
+                for (int s = 0; s < QS; ++s) {
+                    st[s][t] = Mma16<T>::mma(kf, qf[s][c], st[s][t]);
+                    dp[s][t] = Mma16<T>::mma(vf, gf[s][c], dp[s][t]);
+                }
             }
-        // interior tiles (every key visible to every row of the wave) skip the per-element mask predicate altogether
-        const bool tile_masked = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw_min) || (window > 0) || (row_lo != nullptr);
+        frag_t df[QS][2];
 #pragma unroll
-        for (int t = 0; t < NC16; ++t)
+        for (int s = 0; s < QS; ++s) {
+            // interior tiles (every key visible to every row of the sub-tile) skip the per-element mask predicate altogether
+            const bool tile_masked = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw + s * 16) || (window > 0) || (row_lo != nullptr);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s_raw = st[t][r];
-                float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q));
-                if (tile_masked && !visible(qi, kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo, ivhi)) p = 0.f;
-                if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], D_q, scale, eps_mask, eps_qk);
-                else st[t][r] = p * (dp[t][r] - D_q);        // * scale/2 folded into the final store
-            }
-        frag_t df[2];
+            for (int t = 0; t < NC16; ++t)
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) df[kc] = PackCols<T>::pack(st, kc);
+                for (int r = 0; r < 4; ++r) {
+                    const float s_raw = st[s][t][r];
+                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q[s]));
+                    if (tile_masked && !visible(qi[s], kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) p = 0.f;
+                    if constexpr (EXPL) st[s][t][r] = lrp_ds2<true>(s_raw, p, dp[s][t][r], D_q[s], scale, eps_mask, eps_qk);
+                    else st[s][t][r] = p * (dp[s][t][r] - D_q[s]);        // * scale/2 folded into the final store
+                }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) df[s][kc] = PackCols<T>::pack(st[s], kc);
+        }
 #pragma unroll
         for (int dt = 0; dt < ND16; ++dt)
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) acc[dt] = Mma16<T>::mma(tr_frag<T>(sKt, dt, kc, lane), df[kc], acc[dt]);
+            for (int kc = 0; kc < 2; ++kc) {
+                const frag_t ktf = tr_frag<T>(sKt, dt, kc, lane);
+#pragma unroll
+                for (int s = 0; s < QS; ++s) acc[s][dt] = Mma16<T>::mma(ktf, df[s][kc], acc[s][dt]);
+            }
         __syncthreads();
         cur ^= 1;
     }
-    store_rows<T, D>(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, lane);
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+        store_rows<T, D>(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi[s], S, acc[s], EXPL ? 1.f : 0.5f * scale, lane);
 }
 
 // ---- helpers: head transpose and GQA group reduction --------------------------------------------------
@@ -1108,15 +1132,25 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
         ATT_DISPATCH_D(T, d, {
             if constexpr (DD <= 128) {
                 const size_t lds = 2 * (3 * (size_t)128 * DD);
-                dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
+                // LRP_ATTN_DQ_QS=2: two 16-row sub-tiles per wave (dev knob, efficient mode only)
+                static const int qs2 = [] { const char* e = getenv("LRP_ATTN_DQ_QS"); return e ? atoi(e) : 1; }();
                 if (eps_mask != 0.f || eps_qk != 0.f) {
-                    auto kern = attn_bwd_dq_v2_kernel<T, DD, true>;
+                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, true, 1>;
+                    set_lds(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
+                                       (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
+                                       eps_qk, causal, window, B, q_begin, row_lo, row_hi);
+                } else if (qs2 == 2) {
+                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false, 2>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
                                        eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
-                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false>;
+                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false, 1>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
