@@ -9,6 +9,30 @@ from torch.autograd import Function
 from .. import ops
 
 
+CONSERVATION_CHECK_FLAG = [False]
+
+
+def conservation_check_wrap(func):
+    """sanity mode of the reference (ref: functional.py:10-37, toggled by lxt.explicit.check.conservation_check): with the flag
+    set, a rule's backward hands sum(R_out) spread UNIFORMLY over its inputs instead of the rule's own result, so that
+    sum(relevance) at the model input equals the seeded relevance iff every op on the path is LRP-wrapped (bias terms aside)"""
+    def wrapped(ctx, *out_relevance):
+        inp_relevance = func(ctx, *out_relevance)
+        if CONSERVATION_CHECK_FLAG[0]:
+            single = not isinstance(inp_relevance, tuple)
+            rel = (inp_relevance,) if single else inp_relevance
+            total = sum(r.float().sum() for r in out_relevance if r is not None)
+            n = sum(r.numel() for r in rel if torch.is_tensor(r))
+            mean = total / n
+            if torch.isnan(mean).any():
+                raise ValueError(f"NaN at {func}")
+            rel = tuple(torch.full(r.shape, float(mean), device=r.device, dtype=r.dtype) if torch.is_tensor(r) else None for r in rel)
+            inp_relevance = rel[0] if single else rel
+        return inp_relevance
+    wrapped.__name__ = getattr(func, "__name__", "backward")
+    return wrapped
+
+
 def _stabilize(input, epsilon=1e-6, inplace=False):
     """ref: functional.py:266-273 -- unsigned stabiliser x + eps"""
     return input.add_(epsilon) if inplace else input + epsilon
@@ -27,6 +51,7 @@ class linear_epsilon_fn(Function):
         return z.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         x2, weight, z = ctx.saved_tensors
         s = ops.eps_scale(R_out.reshape(z.shape), z, 1.0, ctx.epsilon, relevance=True)
@@ -47,6 +72,7 @@ class matmul_fn(Function):
         return o
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         a, b, bt, o = ctx.saved_tensors
         s = ops.eps_scale(R_out, o, 2.0, ctx.epsilon, relevance=True)
@@ -71,6 +97,7 @@ class softmax_fn(Function):
         return p.transpose(dim, nd - 1) if dim != nd - 1 else p
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         xt, p = ctx.saved_tensors
         dim, nd = ctx.dim, ctx.nd
@@ -93,6 +120,7 @@ class add2_tensors_fn(Function):
         return a + b
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         a, b = ctx.saved_tensors
         Ra, Rb = ops.add2_rule_bwd(a, b, R_out, ctx.epsilon, need_b=True)
@@ -113,6 +141,7 @@ class mul2_fn(Function):
         return input_a * input_b
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         n = len(ctx.requires_grads)
         g = R_out.contiguous()
@@ -130,6 +159,7 @@ class rms_norm_identity_fn(Function):
         return y.view(shp)
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         return R_out, None, None
 
@@ -146,6 +176,7 @@ class layer_norm_grad_fn(Function):
         return y
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         x, y, weight, rstd = ctx.saved_tensors
         s = ops.eps_scale(R_out, y, 1.0, ctx.epsilon, relevance=True)      # R/(y+eps)
@@ -163,6 +194,7 @@ class mean_fn(Function):
         return x.mean(dim, keepdim)
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         (x,) = ctx.saved_tensors
         xs = x.sum(ctx.dim, keepdim=True)
@@ -179,6 +211,7 @@ class normalize_identity_fn(Function):
         return torch.nn.functional.normalize(input, p=p, dim=dim, eps=eps)
 
     @staticmethod
+    @conservation_check_wrap
     def backward(ctx, R_out):
         return R_out, None, None, None
 

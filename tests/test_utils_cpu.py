@@ -25,3 +25,37 @@ def test_heatmaps(tmp_path):
         utils.pdf_heatmap(words, [2.0, 0.0, 0.0], path=str(tmp_path / "bad.pdf"))
     with pytest.raises(AssertionError, match="same"):
         utils.html_heatmap(words, [0.0])
+
+
+def test_conservation_check_mode():
+    """lxt.explicit.check.conservation_check: the decorator every rule backward carries (host logic; a toy Function stands in
+    for the HIP-backed rules, which need a device)"""
+    import torch
+    from torch.autograd import Function
+    from lxt_amd.explicit.functional import conservation_check_wrap, CONSERVATION_CHECK_FLAG
+    from lxt_amd.explicit.check import conservation_check
+    import lxt_amd.explicit.functional as lf
+
+    class toy(Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            return a + b
+
+        @staticmethod
+        @conservation_check_wrap
+        def backward(ctx, R):
+            return 0.25 * R, 0.75 * R
+
+    a, b = torch.ones(3, requires_grad=True), torch.ones(3, requires_grad=True)
+    toy.apply(a, b).backward(torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.allclose(a.grad, torch.tensor([0.25, 0.5, 0.75])) and torch.allclose(b.grad, torch.tensor([0.75, 1.5, 2.25]))
+    a.grad = b.grad = None
+    with conservation_check():
+        assert CONSERVATION_CHECK_FLAG[0]
+        toy.apply(a, b).backward(torch.tensor([1.0, 2.0, 3.0]))
+    assert not CONSERVATION_CHECK_FLAG[0]
+    assert torch.allclose(a.grad, torch.full((3,), 1.0)) and torch.allclose(b.grad, torch.full((3,), 1.0))     # 6 / 6 elements
+    # every rule Function of the package carries the decorator
+    for name in ("linear_epsilon_fn", "matmul_fn", "softmax_fn", "add2_tensors_fn", "mul2_fn", "rms_norm_identity_fn",
+                 "layer_norm_grad_fn", "mean_fn", "normalize_identity_fn"):
+        assert getattr(lf, name).backward.__name__ == "backward"
