@@ -59,3 +59,9 @@ def test_conservation_check_mode():
     for name in ("linear_epsilon_fn", "matmul_fn", "softmax_fn", "add2_tensors_fn", "mul2_fn", "rms_norm_identity_fn",
                  "layer_norm_grad_fn", "mean_fn", "normalize_identity_fn"):
         assert getattr(lf, name).backward.__name__ == "backward"
+
+
+def test_monkey_patch_zennit_fails_loudly():
+    from lxt_amd.efficient import monkey_patch_zennit
+    with pytest.raises(NotImplementedError, match="GammaComposite"):
+        monkey_patch_zennit()
