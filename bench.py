@@ -110,6 +110,48 @@ def smallm_roofline(ops, dtype, device):
             "peak": 8000.0, "unit": "GB/s", "frac": nbytes / sec / 1e9 / 8000.0, "avg_launch_us": sec * 1e6, "traffic": None}
 
 
+def dry_run(args):
+    """the N-rank control flow of main() with the explanation replaced by a pure function of the ids (no engine, no device):
+    what torch.distributed.run + this script must get right before any kernel matters"""
+    import lxt_amd.dist as D
+    import torch.distributed as dist
+    rank, world, _ = D.init(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    B, S = args.batch, min(args.seq, 64)
+    n_total = world * B
+    ids_all = torch.randint(0, 1000, (n_total * (args.steps + args.warmup), S), generator=torch.Generator().manual_seed(1234))
+    fake = lambda x: x.float().cumsum(1)                                    # noqa: E731
+
+    def step(i):
+        chunk = ids_all[i * n_total: (i + 1) * n_total]
+        lo, hi = D.shard_range(n_total, rank, world)
+        return D.gather_relevance(fake(chunk[lo:hi]), n_total)
+    for i in range(args.warmup):
+        R = step(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        R = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    last = ids_all[(args.warmup + args.steps - 1) * n_total: (args.warmup + args.steps) * n_total]
+    assert R.shape == (n_total, S) and torch.equal(R, fake(last)), "gathered relevance is not in global prompt order"
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    if rank == 0:
+        print(json.dumps({"metric": "explanations/sec (full AttnLRP backward) Llama-3-8B seq=2048", "value": None, "unit": "explanations/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "dry_run": True, "config": {"workload": "dry run: control flow only, no kernels", "global_batch": n_total,
+                                                      "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +164,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing self-test WITHOUT kernels or a GPU (gloo): rank env, sharding, barrier, max-over-ranks, gather, "
+                         "one JSON line from rank 0 -- value is null; used by tests/test_dist_cpu.py for the N>1 launch contract")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     import lxt_amd.dist as D
     import lxt_amd.engine as E

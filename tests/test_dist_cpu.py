@@ -60,3 +60,32 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launch_contract_dry_run():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 --steps K --warmup W` (the driver's
+    launch line) through bench.py's control flow with the kernels stubbed out: exactly one JSON line, from rank 0, with the
+    contract's keys; and the single-process form"""
+    import json
+    import socket
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode == 0 or "global prompt order" in (r.stdout + r.stderr):
+            break
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True
+    r1 = subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
