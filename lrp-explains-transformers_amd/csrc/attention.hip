@@ -17,6 +17,7 @@
 // ds_read_b128 / ds_read_b64 for every pitch used here.  One LDS buffer + register prefetch of the
 // next tile (global loads are issued before the MFMAs of the current tile).
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -584,7 +585,7 @@ LRP_DEVICE void glds_stats(const float* base, int r0, int S, char* lds, int lane
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + r), (lds_ptr_t)lds, 4, 0, 0);
 }
 
-template <typename T, int D, bool EXPL>
+template <typename T, int D, bool EXPL, bool HOIST = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
@@ -663,6 +664,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
         f32x4 pp[NC16];
         // interior tiles (every query of the tile sees every key of the wave) skip the per-element mask predicate
         const bool tile_masked = (qt0 + CT > S) || (causal && qt0 < kw_max) || (window > 0) || (row_lo != nullptr);
+        auto elems = [&](auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+            for (int t = 0; t < NC16; ++t) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + t * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s_raw = st[t][r];
+                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(l4[r] * LRP_LOG2E)));
+                    if constexpr (MASKED) {
+                        const int qi = qt0 + t * 16 + g * 4 + r;
+                        int ivlo = 0, ivhi = S;
+                        if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+                        if (!((qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi))) p = 0.f;
+                    }
+                    pp[t][r] = p;
+                    if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
+                    else st[t][r] = p * (dp[t][r] - d4[r]);      // * scale/2 folded into the dK store
+                }
+            }
+        };
+        if constexpr (HOIST) {         // ONE wave-uniform branch per tile step (dev knob LRP_ATTN_HOIST=1)
+            if (tile_masked) elems(std::true_type{}); else elems(std::false_type{});
+        } else {
 #pragma unroll
         for (int t = 0; t < NC16; ++t) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
@@ -681,6 +707,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
                 if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
                 else st[t][r] = p * (dp[t][r] - d4[r]);      // * scale/2 folded into the dK store
             }
+        }
         }
         frag_t pf[2], df[2];
 #pragma unroll
@@ -846,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
 // feeds ONE MFMA (48 ds_read_b128 : 48 MFMA per tile step and wave) and the kernel is LDS-bandwidth-bound (8 waves x 48 x 8
 // clk = 3072 clk of LDS per workgroup step vs 1536 clk of MFMA per SIMD); with two sub-tiles each fragment feeds two MFMAs
 // at the same occupancy (96 KiB of LDS allow one workgroup per CU either way; 2 waves per SIMD = 256 VGPRs).
-template <typename T, int D, bool EXPL, int QS>
+template <typename T, int D, bool EXPL, int QS, bool HOIST = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
@@ -930,16 +957,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
         for (int s = 0; s < QS; ++s) {
             // interior tiles (every key visible to every row of the sub-tile) skip the per-element mask predicate altogether
             const bool tile_masked = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw + s * 16) || (window > 0) || (row_lo != nullptr);
+            auto elems = [&](auto masked_c) {
+                constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-            for (int t = 0; t < NC16; ++t)
+                for (int t = 0; t < NC16; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s_raw = st[s][t][r];
-                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q[s]));
-                    if (tile_masked && !visible(qi[s], kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) p = 0.f;
-                    if constexpr (EXPL) st[s][t][r] = lrp_ds2<true>(s_raw, p, dp[s][t][r], D_q[s], scale, eps_mask, eps_qk);
-                    else st[s][t][r] = p * (dp[s][t][r] - D_q[s]);        // * scale/2 folded into the final store
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float s_raw = st[s][t][r];
+                        float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q[s]));
+                        if constexpr (MASKED) {
+                            if (!visible(qi[s], kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) p = 0.f;
+                        }
+                        if constexpr (EXPL) st[s][t][r] = lrp_ds2<true>(s_raw, p, dp[s][t][r], D_q[s], scale, eps_mask, eps_qk);
+                        else st[s][t][r] = p * (dp[s][t][r] - D_q[s]);        // * scale/2 folded into the final store
+                    }
+            };
+            if constexpr (HOIST) {     // ONE wave-uniform branch per tile step instead of one per element (dev knob LRP_ATTN_HOIST=1)
+                if (tile_masked) elems(std::true_type{}); else elems(std::false_type{});
+            } else {
+#pragma unroll
+                for (int t = 0; t < NC16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float s_raw = st[s][t][r];
+                        float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q[s]));
+                        if (tile_masked && !visible(qi[s], kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) p = 0.f;
+                        if constexpr (EXPL) st[s][t][r] = lrp_ds2<true>(s_raw, p, dp[s][t][r], D_q[s], scale, eps_mask, eps_qk);
+                        else st[s][t][r] = p * (dp[s][t][r] - D_q[s]);        // * scale/2 folded into the final store
+                    }
+            }
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) df[s][kc] = PackCols<T>::pack(st[s], kc);
         }
@@ -1134,6 +1180,7 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                 const size_t lds = 2 * (3 * (size_t)128 * DD);
                 // LRP_ATTN_DQ_QS=2: two 16-row sub-tiles per wave (dev knob, efficient mode only)
                 static const int qs2 = [] { const char* e = getenv("LRP_ATTN_DQ_QS"); return e ? atoi(e) : 1; }();
+                static const int hoist = [] { const char* e = getenv("LRP_ATTN_HOIST"); return e ? atoi(e) : 0; }();
                 if (eps_mask != 0.f || eps_qk != 0.f) {
                     dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
                     auto kern = attn_bwd_dq_v2_kernel<T, DD, true, 1>;
@@ -1141,9 +1188,11 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
                                        eps_qk, causal, window, B, q_begin, row_lo, row_hi);
-                } else if (qs2 == 2) {
-                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
-                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false, 2>;
+                } else if (qs2 == 2 || hoist) {
+                    const int bq = qs2 == 2 ? 256 : 128;
+                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + bq - 1) / bq)));
+                    auto kern = qs2 == 2 ? (hoist ? attn_bwd_dq_v2_kernel<T, DD, false, 2, true> : attn_bwd_dq_v2_kernel<T, DD, false, 2, false>)
+                                         : attn_bwd_dq_v2_kernel<T, DD, false, 1, true>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
@@ -1207,7 +1256,8 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
                                        ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
-                    auto kern = attn_bwd_dkv_v2_kernel<T, DD, false>;
+                    static const int hoist = [] { const char* e = getenv("LRP_ATTN_HOIST"); return e ? atoi(e) : 0; }();
+                    auto kern = hoist ? attn_bwd_dkv_v2_kernel<T, DD, false, true> : attn_bwd_dkv_v2_kernel<T, DD, false, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
