@@ -21,11 +21,14 @@ def _table(first, shared, module, attention_patch):
 def decoder_maps(module, mlp_cls, norm_cls, norm_forward=P.rms_norm_forward, mlp_forward=P.gated_mlp_forward,
                  cp_mlp_forward=P.cp_gated_mlp_forward, linear=True, conv_patch_embedding=False):
     """-> (attnLRP, cp_LRP) for one HuggingFace modeling module"""
-    shared = [(norm_cls, partial(P.patch_method, norm_forward)), (nn.Dropout, partial(P.patch_method, P.dropout_forward))]
+    # torch.nn classes keep their original forward (keep_original): the patched forwards hand every instance that is not
+    # part of an explained model back to it (patches.adopt / patches.linear_forward)
+    shared = [(norm_cls, partial(P.patch_method, norm_forward, keep_original=norm_cls is nn.LayerNorm)),
+              (nn.Dropout, partial(P.patch_method, P.dropout_forward))]
     if linear:
-        shared.append((nn.Linear, partial(P.patch_method, P.linear_forward)))
+        shared.append((nn.Linear, partial(P.patch_method, P.linear_forward, keep_original=True)))
     if conv_patch_embedding:
-        shared.append((nn.Conv2d, partial(P.patch_method, P.conv2d_patch_forward)))
+        shared.append((nn.Conv2d, partial(P.patch_method, P.conv2d_patch_forward, keep_original=True)))
     attn = _table((mlp_cls, partial(P.patch_method, mlp_forward)), shared, module, P.patch_attention)
     cp = _table((mlp_cls, partial(P.patch_method, cp_mlp_forward)), shared, module, P.patch_cp_attention)
     return attn, cp

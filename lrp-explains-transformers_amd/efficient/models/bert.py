@@ -26,9 +26,9 @@ def pooler_forward(self, hidden_states):
 attnLRP = {
     BertIntermediate: partial(patch_method, intermediate_forward),
     BertPooler: partial(patch_method, pooler_forward),
-    LayerNorm: partial(patch_method, layer_norm_forward),
+    LayerNorm: partial(patch_method, layer_norm_forward, keep_original=True),
     Dropout: partial(patch_method, dropout_forward),
-    Linear: partial(patch_method, linear_forward),
+    Linear: partial(patch_method, linear_forward, keep_original=True),
     modeling_bert: patch_attention,
 }
 

@@ -46,6 +46,60 @@ def _need_cuda(t, what):
         raise RuntimeError(f"{what}: lxt_amd runs on the HIP device only (no CPU fallback); got a CPU tensor")
 
 
+# ------------------------------------------------------------------------------------------- ownership
+# The reference never touches nn.Linear / nn.LayerNorm / nn.Conv2d semantics for OTHER models in the process (its Linear
+# stays ATen, lxt/efficient/models/llama.py:9-14).  The default maps here do patch those torch.nn classes -- so that every
+# contraction of the explained model runs on liblrp_hip.so -- but the patched forwards only take the HIP path for module
+# INSTANCES that belong to an explained model ("owned"); every other instance (a CPU probe, a second un-explained model,
+# a module whose weights still require grad) runs its original forward, bit-identical to un-patched PyTorch.
+# Ownership is given by adopt(model): called automatically the first time a model class of a patched modeling module is
+# invoked (monkey_patch may run before or after the model is built), or by the user for models built from plain torch.nn.
+_OWNABLE = (torch.nn.Linear, torch.nn.LayerNorm, torch.nn.Conv2d)
+
+
+def adopt(model):
+    """mark the nn.Linear / nn.LayerNorm / nn.Conv2d instances under `model` as part of an explained model"""
+    for m in model.modules():
+        if isinstance(m, _OWNABLE) or type(m).__name__ == "Conv1D":
+            m.__dict__["_lrp_owned"] = True
+        m.__dict__["_lrp_adopted"] = True
+    return model
+
+
+def _owned(m):
+    return m.__dict__.get("_lrp_owned", False)
+
+
+def _adopting_call(self, *args, **kwargs):
+    if not self.__dict__.get("_lrp_adopted", False):
+        adopt(self)
+    return torch.nn.Module.__call__(self, *args, **kwargs)
+
+
+def patch_ownership(module):
+    """give every PreTrainedModel class DEFINED in `module` an entry hook that adopts the instance on its first call"""
+    try:
+        from transformers import PreTrainedModel
+    except Exception:  # noqa: BLE001
+        return False
+    for cls in list(vars(module).values()):
+        if isinstance(cls, type) and issubclass(cls, PreTrainedModel) and cls.__module__ == module.__name__:
+            if cls.__dict__.get("__call__") is not _adopting_call:
+                cls.__call__ = _adopting_call
+    return True
+
+
+def _weight_t(mod, w2):
+    """cached W^T copy for the dgrad GEMM (frozen weights); the key covers re-assignment of the Parameter
+    (resize_token_embeddings / tie_weights / adapter loading keep _version 0 but change storage or shape)"""
+    key = (w2.data_ptr(), tuple(w2.shape), w2.device, w2.dtype, mod.weight._version)
+    if mod.__dict__.get("_lrp_weight_key") != key:
+        from .. import ops
+        mod.__dict__["_lrp_weight_t"] = ops.transpose(w2.contiguous())
+        mod.__dict__["_lrp_weight_key"] = key
+    return mod.__dict__["_lrp_weight_t"]
+
+
 # ----------------------------------------------------------------------------------- AttnLRP patches
 def rms_norm_forward(self, hidden_states):
     """identity rule on RMSNorm (ref: lxt/efficient/patches.py:111-123) -- fused HIP row kernel"""
@@ -64,23 +118,39 @@ def gemma3_rms_norm_forward(self, x):
 
 
 def layer_norm_forward(self, x):
-    """identity rule on LayerNorm's 1/std (ref: lxt/efficient/patches.py:126-142)"""
+    """identity rule on LayerNorm's 1/std (ref: lxt/efficient/patches.py:126-142); instances outside an explained model
+    keep torch's own forward"""
+    if not _owned(self) and hasattr(self, "original_forward"):
+        return self.original_forward(x)
     _need_cuda(x, "layer_norm_forward")
     return LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))
 
 
 def linear_forward(self, x):
-    """nn.Linear on the MFMA GEMM; the W^T copy for the dgrad is cached on the module (frozen
-    weights).  Not patched by the reference (ATen mm there); part of the default maps here so the
-    whole backward runs on liblrp_hip.so."""
+    """nn.Linear on the MFMA GEMM; the W^T copy for the dgrad is cached on the module (frozen weights).  Not patched by
+    the reference (ATen mm there); part of the default maps here so the whole backward runs on liblrp_hip.so.  Only
+    instances of an explained model with frozen weights take this path (see `adopt`); everything else -- foreign
+    modules, CPU probes, trainable weights, dtypes the kernels do not serve -- runs torch's own forward unchanged."""
+    w = self.weight
+    if hasattr(self, "original_forward") and (not _owned(self) or w.requires_grad or x.dtype != w.dtype
+                                              or x.dtype not in (torch.float32, torch.bfloat16)):
+        return self.original_forward(x)
     _need_cuda(x, "linear_forward")
-    wt = getattr(self, "_lrp_weight_t", None)
-    if wt is None or wt.device != self.weight.device or wt.dtype != self.weight.dtype or \
-            getattr(self, "_lrp_weight_ver", None) != self.weight._version:
-        from .. import ops
-        wt = ops.transpose(self.weight.detach())
-        self._lrp_weight_t, self._lrp_weight_ver = wt, self.weight._version
-    return LinearFn.apply(x, self.weight.detach(), self.bias.detach() if self.bias is not None else None, wt)
+    wd = w.detach()
+    return LinearFn.apply(x, wd, self.bias.detach() if self.bias is not None else None, _weight_t(self, wd))
+
+
+def conv1d_forward(self, x):
+    """HF's Conv1D (GPT-2's c_attn / c_fc / c_proj: y = x W + b with W stored [in, out]) on the MFMA GEMM: the forward
+    uses a cached [out, in] copy, the dgrad the stored weight itself -- both NT contractions.  The reference leaves these
+    on ATen (lxt/efficient/models/gpt2.py:11-32 patches only the MLP forward around them)."""
+    w = self.weight
+    if hasattr(self, "original_forward") and (not _owned(self) or w.requires_grad or x.dtype != w.dtype
+                                              or x.dtype not in (torch.float32, torch.bfloat16)):
+        return self.original_forward(x)
+    _need_cuda(x, "conv1d_forward")
+    wd = w.detach()
+    return LinearFn.apply(x, _weight_t(self, wd), self.bias.detach() if self.bias is not None else None, wd.contiguous())
 
 
 def conv2d_patch_forward(self, x):
@@ -89,19 +159,14 @@ def conv2d_patch_forward(self, x):
     liblrp_hip.so instead of MIOpen (whose backward-data solver search for the 896x896, 14x14/14 SigLIP stem takes
     minutes on a fresh box).  Any other convolution falls through to the original forward."""
     kh, kw = self.kernel_size
-    if (x.dim() != 4 or not x.is_cuda or tuple(self.stride) != (kh, kw) or self.groups != 1 or tuple(self.dilation) != (1, 1)
+    if (not _owned(self) or self.weight.requires_grad or x.dim() != 4 or not x.is_cuda or tuple(self.stride) != (kh, kw) or self.groups != 1 or tuple(self.dilation) != (1, 1)
             or self.padding not in ((0, 0), "valid", 0) or self.padding_mode != "zeros" or x.dtype not in (torch.float32, torch.bfloat16)):
         return self._conv_forward(x, self.weight, self.bias)
     B, C, Hh, Ww = x.shape
     gh, gw = Hh // kh, Ww // kw
     patches = x[:, :, : gh * kh, : gw * kw].reshape(B, C, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * kh * kw)
     w2 = self.weight.detach().reshape(self.out_channels, C * kh * kw)
-    wt = getattr(self, "_lrp_weight_t", None)
-    if wt is None or wt.device != w2.device or wt.dtype != w2.dtype or getattr(self, "_lrp_weight_ver", None) != self.weight._version:
-        from .. import ops
-        wt = ops.transpose(w2.contiguous())
-        self._lrp_weight_t, self._lrp_weight_ver = wt, self.weight._version
-    y = LinearFn.apply(patches, w2, self.bias.detach() if self.bias is not None else None, wt)
+    y = LinearFn.apply(patches, w2, self.bias.detach() if self.bias is not None else None, _weight_t(self, w2))
     return y.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -213,6 +278,7 @@ def cp_wrap_attention_forward(forward_fn):
 
 
 def _patch_attention(module, cp):
+    patch_ownership(module)
     new_forward = _make_attention_forward(cp)
     if hasattr(module, "eager_attention_forward"):
         if check_already_patched(module.eager_attention_forward, new_forward):
@@ -263,15 +329,15 @@ def cp_multi_head_attention_forward(self, query, key, value, key_padding_mask=No
         q = ops.gemm_nt(query.detach().reshape(B * Sq, E).contiguous(), w[:E], bq).view(B, Sq, H, d)
         k = ops.gemm_nt(key.detach().reshape(-1, E).contiguous(), w[E: 2 * E], bk).view(B, -1, H, d)
     wv = w[2 * E:]
-    wvt = getattr(self, "_lrp_wv_t", None)
-    if wvt is None or wvt.device != w.device or wvt.dtype != w.dtype or getattr(self, "_lrp_w_ver", None) != self.in_proj_weight._version:
-        wvt = ops.transpose(wv.contiguous())
-        self._lrp_wv_t, self._lrp_w_ver = wvt, self.in_proj_weight._version
-    v = LinearFn.apply(value, wv, bv, wvt).view(B, -1, H, d)
+    key = (w.data_ptr(), tuple(w.shape), w.device, w.dtype, self.in_proj_weight._version)
+    if self.__dict__.get("_lrp_wv_key") != key:
+        self.__dict__["_lrp_wv_t"], self.__dict__["_lrp_wv_key"] = ops.transpose(wv.contiguous()), key
+    v = LinearFn.apply(value, wv, bv, self.__dict__["_lrp_wv_t"]).view(B, -1, H, d)
     if k.shape[1] != Sq:
         raise NotImplementedError("lxt_amd MultiheadAttention fast path: cross attention with a different key length")
     o = AttentionFn.apply(q, k, v, d ** -0.5, False, 0, True, None)            # cp=True: dQ = dK = 0, all relevance on V
-    out = linear_forward(self.out_proj, o.reshape(B, Sq, E))
+    op_, ow = self.out_proj, self.out_proj.weight.detach()
+    out = LinearFn.apply(o.reshape(B, Sq, E), ow, op_.bias.detach() if op_.bias is not None else None, _weight_t(op_, ow))
     if not self.batch_first:
         out = out.transpose(0, 1)
     return out, None

@@ -26,7 +26,22 @@ EXPLICIT = dict(lin=1e-8, add=1e-8, qk=1e-8, mask=1e-8, pv=1e-6, rope=1e-8, act=
 EFFICIENT = dict(lin=0.0, add=0.0, qk=0.0, mask=0.0, pv=0.0, rope=0.0, act=1e-10)
 
 
+_STATIC_ROPE = ("default", "linear", "llama3", "yarn")
+
+
 def config_from_hf(hf_cfg):
+    """HF LlamaConfig -> engine cfg.  Everything the fused driver does not implement is refused LOUDLY here instead of
+    being ignored: other model types (use lxt_amd.efficient.monkey_patch for those), attention / MLP biases, and rope
+    types whose frequencies depend on the running sequence length ("dynamic", "longrope").  The rotary frequencies and
+    the cos/sin post-scale are taken from HF's own initialiser for the config's rope_type (Llama-3.1/3.2: "llama3"),
+    exactly what LlamaRotaryEmbedding.__init__ does -- the reference inherits them from HF unchanged."""
+    mt = getattr(hf_cfg, "model_type", "llama")
+    if mt != "llama":
+        raise NotImplementedError(f"LlamaLRP drives Llama-architecture decoders only (model_type={mt!r}); "
+                                  "other families run through lxt_amd.efficient.monkey_patch")
+    if getattr(hf_cfg, "attention_bias", False) or getattr(hf_cfg, "mlp_bias", False):
+        raise NotImplementedError("LlamaLRP: attention_bias / mlp_bias = True are not supported by the fused driver "
+                                  "(use the monkey_patch drop-in path)")
     hd = getattr(hf_cfg, "head_dim", None) or hf_cfg.hidden_size // hf_cfg.num_attention_heads
     theta = None
     rp = getattr(hf_cfg, "rope_parameters", None)
@@ -34,10 +49,18 @@ def config_from_hf(hf_cfg):
         theta = rp.get("rope_theta")
     if theta is None:
         theta = getattr(hf_cfg, "rope_theta", 10000.0)
-    return dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size, n_layers=hf_cfg.num_hidden_layers,
-                n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hd,
-                vocab=hf_cfg.vocab_size, rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps),
-                act=getattr(hf_cfg, "hidden_act", "silu"))
+    cfg = dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size, n_layers=hf_cfg.num_hidden_layers,
+               n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hd,
+               vocab=hf_cfg.vocab_size, rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps),
+               act=getattr(hf_cfg, "hidden_act", "silu"))
+    kind = rp.get("rope_type", "default") if isinstance(rp, dict) else "default"
+    if kind not in _STATIC_ROPE:
+        raise NotImplementedError(f"LlamaLRP: rope_type {kind!r} (sequence-length dependent frequencies) is not supported")
+    if kind != "default":
+        from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+        inv_freq, att = ROPE_INIT_FUNCTIONS[kind](hf_cfg, "cpu")
+        cfg["inv_freq"], cfg["attention_scaling"] = inv_freq.float().cpu(), float(att)
+    return cfg
 
 
 def weights_from_hf(model):
@@ -82,12 +105,15 @@ class LlamaLRP:
             self.layers.append(dict(ln1=put(L["ln1"]), ln2=put(L["ln2"]), wqkv=wqkv, wqkv_t=ops.transpose(wqkv), wo=wo,
                                     wo_t=ops.transpose(wo), wgu=wgu, wgu_t=ops.transpose(wgu), wd=wd, wd_t=ops.transpose(wd)))
         d = cfg["head_dim"]
-        inv = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
-        fr = torch.arange(max_seq, dtype=torch.float32)[:, None] * inv[None, :]
+        inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
+        if inv is None:
+            inv = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        att = float(cfg.get("attention_scaling", 1.0))
+        fr = torch.arange(max_seq, dtype=torch.float32)[:, None] * inv.float().cpu()[None, :]
         emb = torch.cat((fr, fr), dim=-1)
         # HF hands cos/sin to the layers in the model dtype; keep that rounding, store as fp32 tables
-        self.cos = emb.cos().to(dtype).to(torch.float32).to(dev).contiguous()
-        self.sin = emb.sin().to(dtype).to(torch.float32).to(dev).contiguous()
+        self.cos = (emb.cos() * att).to(dtype).to(torch.float32).to(dev).contiguous()
+        self.sin = (emb.sin() * att).to(dtype).to(torch.float32).to(dev).contiguous()
         self.max_seq = max_seq
         # second HIP stream: the dQ kernel runs beside the dK/dV kernel (both only read the forward stash;
         # their causal tails interleave instead of leaving CUs idle)
@@ -313,11 +339,22 @@ class LlamaLRP:
             lo = first.expand(B, S).contiguous()
             hi = torch.where(i[None] >= first, (i + 1)[None].expand(B, S), torch.zeros_like(lo)).contiguous()   # pad rows: empty
             row_iv = (lo, hi)
+        V = self.cfg["vocab"]
+        if target is not None:
+            tgt = torch.as_tensor(target).reshape(-1).cpu().long()
+            if tgt.numel() != B or int(tgt.min()) < 0 or int(tgt.max()) >= V:
+                raise ValueError(f"target must hold {B} vocabulary indices in [0, {V})")
+        if seed is not None:
+            if target is not None:
+                raise ValueError("pass either target or seed, not both")
+            if tuple(seed.shape) != (B, V):
+                raise ValueError(f"seed must have shape ({B}, {V}), got {tuple(seed.shape)}")
         fw = self.forward(emb, B, S, row_iv)
         if target is None:
+            # (a dense seed explains no single logit; idx / logit then report the arg-max for convenience)
             idx, _ = ops.argmax_rows(fw["logits"])
         else:
-            idx = torch.as_tensor(target, device=self.device).to(torch.int32).reshape(B).contiguous()
+            idx = tgt.to(device=self.device, dtype=torch.int32).contiguous()
         G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance, seed=seed)
         R_tok = ops.readout(emb, G).view(B, S)
         out = dict(idx=idx, logit=fw["logits"].gather(1, idx.long()[:, None])[:, 0], R_tok=R_tok, logits=fw["logits"])

@@ -46,16 +46,18 @@ class linear_epsilon_fn(Function):
         shp = inputs.shape
         x2 = inputs.reshape(-1, shp[-1]).contiguous()
         z = ops.gemm_nt(x2, weight, bias)
-        ctx.save_for_backward(x2, weight, z)
+        # the W^T copy of the dgrad GEMM is cached on the weight object (frozen weights): one transpose per weight,
+        # not one per call
+        ctx.save_for_backward(x2, ops.weight_t(weight), z)
         ctx.epsilon, ctx.shp = epsilon, shp
         return z.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
     @conservation_check_wrap
     def backward(ctx, R_out):
-        x2, weight, z = ctx.saved_tensors
+        x2, weight_t, z = ctx.saved_tensors
         s = ops.eps_scale(R_out.reshape(z.shape), z, 1.0, ctx.epsilon, relevance=True)
-        R_in = ops.mul(ops.gemm_nt(s, ops.transpose(weight)), x2)
+        R_in = ops.mul(ops.gemm_nt(s, weight_t), x2)
         return R_in.view(ctx.shp), None, None, None
 
 

@@ -52,8 +52,8 @@ class _LinearProjection(nn.Module):
     def forward(self, x):
         from ..efficient.functions import LinearFn
         from .. import ops
-        w = self.weight.detach().contiguous()
-        return LinearFn.apply(x, w, self.bias.detach() if self.bias is not None else None, ops.transpose(w))
+        w = self.weight if self.weight.is_contiguous() else self.weight.contiguous()
+        return LinearFn.apply(x, w.detach(), self.bias.detach() if self.bias is not None else None, ops.weight_t(w))
 
 
 class LinearInProjection(_LinearProjection):

@@ -26,6 +26,7 @@ class identity_fn(Function):
         return fn(input)
 
     @staticmethod
+    @lf.conservation_check_wrap
     def backward(ctx, R_out):
         return None, R_out
 
@@ -52,6 +53,7 @@ class epsilon_lrp_fn(Function):
         return _eps_forward(ctx, fn, epsilon, inputs)
 
     @staticmethod
+    @lf.conservation_check_wrap
     def backward(ctx, R_out):
         return _eps_backward(ctx, R_out, uniform=False)
 
@@ -64,6 +66,7 @@ class uniform_epsilon_lrp_fn(Function):
         return _eps_forward(ctx, fn, epsilon, inputs)
 
     @staticmethod
+    @lf.conservation_check_wrap
     def backward(ctx, R_out):
         return _eps_backward(ctx, R_out, uniform=True)
 
@@ -100,6 +103,7 @@ class uniform_rule_fn(Function):
         return fn(*inputs)
 
     @staticmethod
+    @lf.conservation_check_wrap
     def backward(ctx, R_out):
         g = R_out.contiguous()
         r = ops.eps_scale(g, g, float(ctx.n), 0.0)

@@ -30,6 +30,33 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def same(ref, *ts):
+    """every tensor handed to a kernel next to `ref` must share its dtype and device: the C ABI takes ONE dtype code
+    per call and raw pointers, so a mismatch would be reinterpreted bytes (or an out-of-bounds read), not an error"""
+    for t in ts:
+        if t is not None and (t.dtype != ref.dtype or t.device != ref.device):
+            raise TypeError(f"lrp_hip: operand of dtype {t.dtype} on {t.device} next to {ref.dtype} on {ref.device}; "
+                            "all activation operands of one call must share dtype and device")
+
+
+def aux(t, ref, n=None):
+    """small parameter vector (norm weight, bias) for a kernel whose activations are `ref`: brought to ref's dtype /
+    device / contiguity if it differs (mixed-precision modules keep fp32 norm weights next to bf16 activations)"""
+    if t is None:
+        return None
+    if n is not None and t.numel() != n:
+        raise ValueError(f"lrp_hip: parameter vector of {t.numel()} elements where {n} are expected")
+    if t.dtype != ref.dtype or t.device != ref.device or not t.is_contiguous():
+        t = t.to(device=ref.device, dtype=ref.dtype).contiguous()
+    return t
+
+
+def f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"lrp_hip: row statistics / tables must be float32, got {t.dtype}")
+
+
 def epc(t):
     return 16 // t.element_size()
 
@@ -70,6 +97,7 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=None):
             b3 = b3.contiguous()
         sB, ldb = (b3.stride(0) if batch > 1 else 0), b3.stride(1)
     odt = out_dtype or a.dtype
+    bias = aux(bias, a, N)
     if out is None:
         out = torch.empty(*lead, M, N, device=a.device, dtype=odt)
     o3 = out.view(-1, M, N)
@@ -107,6 +135,8 @@ def gemm_nt_2d(a, b, out, bias=None):
     """strict 2-D fast path used by the engine: no reshapes, no copies; row strides may exceed K."""
     M, K = a.shape
     N = b.shape[0]
+    same(a, b)
+    bias = aux(bias, a, N)
     ev = GEMM_TIMER.span(2.0 * M * N * K) if GEMM_TIMER is not None else None
     if ev:
         ev[0].record()
@@ -131,6 +161,21 @@ def transpose(x, out=None):
     return out
 
 
+def weight_t(w):
+    """W^T copy ([in, out]) of a frozen weight for the dgrad GEMM, cached ON the weight tensor object: valid while that
+    object keeps its storage, shape and in-place version (a replaced Parameter is a new object without the cache)."""
+    key = (w.data_ptr(), tuple(w.shape), w.dtype, w.device, w._version)
+    hit = w.__dict__.get("_lrp_wt") if hasattr(w, "__dict__") else None
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wt = transpose(w.detach())
+    try:
+        w._lrp_wt = (key, wt)
+    except Exception:  # noqa: BLE001  (tensor subclasses without attribute storage: just do not cache)
+        pass
+    return wt
+
+
 def cast(x, dtype):
     x = _c(x)
     out = torch.empty_like(x, dtype=dtype)
@@ -142,12 +187,14 @@ def cast(x, dtype):
 def eps_scale(g, z, c=1.0, eps=1e-8, relevance=False, out=None):
     g, z = _c(g), _c(z)
     out = torch.empty_like(g) if out is None else out
+    same(g, z, out)
     check(lib.lrp_eps_scale(p(g), p(z), p(out), g.numel(), c, eps, 1 if relevance else 0, dt(g), stream()), "lrp_eps_scale")
     return out
 
 
 def eps_scale2d(g, z, out, c=1.0, eps=1e-8, relevance=False):
     rows, cols = g.shape
+    same(g, z, out)
     check(lib.lrp_eps_scale2d(p(g), p(z), p(out), rows, cols, g.stride(0), z.stride(0), out.stride(0), c, eps,
                               1 if relevance else 0, dt(g), stream()), "lrp_eps_scale2d")
     return out
@@ -156,6 +203,7 @@ def eps_scale2d(g, z, out, c=1.0, eps=1e-8, relevance=False):
 def mul(a, b, out=None):
     a, b = _c(a), _c(b)
     out = torch.empty_like(a) if out is None else out
+    same(a, b, out)
     check(lib.lrp_mul(p(a), p(b), p(out), a.numel(), dt(a), stream()), "lrp_mul")
     return out
 
@@ -164,6 +212,7 @@ def add2_rule_bwd(a, b, R, eps=1e-8, need_b=True):
     a, b, R = _c(a), _c(b), _c(R)
     Ra = torch.empty_like(a)
     Rb = torch.empty_like(b) if need_b else None
+    same(a, b, R)
     check(lib.lrp_add2_rule_bwd(p(a), p(b), p(R), p(Ra), p(Rb), a.numel(), eps, dt(a), stream()), "lrp_add2_rule_bwd")
     return Ra, Rb
 
@@ -178,6 +227,7 @@ def act_fwd(x, act="silu"):
 def act_bwd(Gy, x, act="silu", eps_g=1e-10):
     Gy, x = _c(Gy), _c(x)
     Gx = torch.empty_like(x)
+    same(x, Gy)
     check(lib.lrp_act_bwd(p(Gy), p(x), p(Gx), x.numel(), eps_g, ACT[act], dt(x), stream()), "lrp_act_bwd")
     return Gx
 
@@ -185,6 +235,7 @@ def act_bwd(Gy, x, act="silu", eps_g=1e-10):
 def gated_act_fwd(g, u, out=None, act="silu"):
     M, I = g.shape
     out = torch.empty(M, I, device=g.device, dtype=g.dtype) if out is None else out
+    same(g, u, out)
     check(lib.lrp_gated_act_fwd(p(g), p(u), p(out), M, I, g.stride(0), u.stride(0), out.stride(0), ACT[act], dt(g), stream()),
           "lrp_gated_act_fwd")
     return out
@@ -192,6 +243,7 @@ def gated_act_fwd(g, u, out=None, act="silu"):
 
 def gated_act_bwd(Gm, g, u, Ag, Au, eps_g, eps_lin, act="silu"):
     M, I = g.shape
+    same(g, Gm, u, Ag, Au)
     check(lib.lrp_gated_act_bwd(p(Gm), p(g), p(u), p(Ag), p(Au), M, I, Gm.stride(0), g.stride(0), u.stride(0), Ag.stride(0),
                                 Au.stride(0), eps_g, eps_lin, ACT[act], dt(g), stream()), "lrp_gated_act_bwd")
     return Ag, Au
@@ -200,6 +252,8 @@ def gated_act_bwd(Gm, g, u, Ag, Au, eps_g, eps_lin, act="silu"):
 def rope_fwd(x, out, cos, sin, seq, n_heads, d):
     """x/out: [rows, >= n_heads*d] 2-D views (row stride = stride(0)); cos/sin fp32 [seq, d]"""
     rows = x.shape[0]
+    same(x, out)
+    f32(cos, sin)
     check(lib.lrp_rope_fwd(p(x), p(out), p(cos), p(sin), rows, seq, n_heads, d, x.stride(0), out.stride(0), dt(x), stream()),
           "lrp_rope_fwd")
     return out
@@ -207,6 +261,8 @@ def rope_fwd(x, out, cos, sin, seq, n_heads, d):
 
 def rope_bwd(Gr, xr, x, A, cos, sin, seq, n_heads, d, eps_rope, eps_lin):
     rows = Gr.shape[0]
+    same(Gr, xr, x, A)
+    f32(cos, sin)
     check(lib.lrp_rope_bwd(p(Gr), p(xr), p(x), p(A), p(cos), p(sin), rows, seq, n_heads, d, Gr.stride(0),
                            xr.stride(0) if xr is not None else 0, x.stride(0) if x is not None else 0, A.stride(0),
                            eps_rope, eps_lin, dt(Gr), stream()), "lrp_rope_bwd")
@@ -218,6 +274,9 @@ def add_rmsnorm_fwd(h, branch, w, eps, w_offset=0.0, hsum_out=None, y=None, rstd
     M, H = h.shape
     y = torch.empty_like(h) if y is None else y
     rstd = torch.empty(M, device=h.device, dtype=torch.float32) if rstd is None else rstd
+    same(h, branch, hsum_out, y)
+    f32(rstd)
+    w = aux(w, h, H)
     check(lib.lrp_add_rmsnorm_fwd(p(h), p(branch), p(w), p(hsum_out), p(y), p(rstd), M, H, eps, w_offset, dt(h), stream()),
           "lrp_add_rmsnorm_fwd")
     return y, rstd
@@ -225,6 +284,9 @@ def add_rmsnorm_fwd(h, branch, w, eps, w_offset=0.0, hsum_out=None, y=None, rstd
 
 def rmsnorm_bwd_add2(Gres, Gx, w, rstd, hsum, branch, Gs_out, A_out, rel_out=None, w_offset=0.0, eps_add=0.0, eps_lin=0.0):
     M, H = (Gx if Gx is not None else Gres).shape
+    same(Gs_out, Gres, Gx, hsum, branch, A_out)
+    f32(rstd, rel_out)
+    w = aux(w, Gs_out, H)
     check(lib.lrp_rmsnorm_bwd_add2(p(Gres), p(Gx), p(w), p(rstd), p(hsum), p(branch), p(Gs_out), p(A_out), p(rel_out), M, H,
                                    w_offset, eps_add, eps_lin, dt(Gs_out), stream()), "lrp_rmsnorm_bwd_add2")
     return Gs_out, A_out
@@ -237,6 +299,7 @@ def layernorm_fwd(x, w, b, eps):
     y = torch.empty_like(x)
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    w, b = aux(w, x, H), aux(b, x, H)
     check(lib.lrp_layernorm_fwd(p(x), p(w), p(b), p(y), p(mean), p(rstd), M, H, eps, dt(x), stream()), "lrp_layernorm_fwd")
     return y, mean, rstd
 
@@ -246,6 +309,9 @@ def layernorm_bwd(Gy, y, w, rstd, eps_y=0.0):
     H = Gy.shape[-1]
     M = Gy.numel() // H
     Gx = torch.empty_like(Gy)
+    same(Gy, y)
+    f32(rstd)
+    w = aux(w, Gy, H)
     check(lib.lrp_layernorm_bwd(p(Gy), p(y), p(w), p(rstd), p(Gx), M, H, eps_y, dt(Gy), stream()), "lrp_layernorm_bwd")
     return Gx
 
@@ -262,6 +328,7 @@ def softmax_rule_bwd(x, pr, Rp, inv_temp=1.0):
     x, pr, Rp = _c(x), _c(pr), _c(Rp)
     n = x.shape[-1]
     Rx = torch.empty_like(x)
+    same(x, pr, Rp)
     check(lib.lrp_softmax_rule_bwd(p(x), p(pr), p(Rp), p(Rx), x.numel() // n, n, inv_temp, dt(x), stream()),
           "lrp_softmax_rule_bwd")
     return Rx
@@ -270,6 +337,7 @@ def softmax_rule_bwd(x, pr, Rp, inv_temp=1.0):
 def readout(emb, G):
     M, H = emb.shape
     out = torch.empty(M, device=emb.device, dtype=torch.float32)
+    same(emb, G)
     check(lib.lrp_readout(p(emb), p(G), p(out), M, H, dt(emb), stream()), "lrp_readout")
     return out
 
@@ -285,6 +353,11 @@ def argmax_rows(logits):
 def head_seed(W_lm, logits, idx, w_norm, rstd_last, out, w_offset=0.0, eps_lin=0.0):
     B, V = logits.shape
     H = W_lm.shape[1]
+    same(W_lm, out)
+    f32(logits, rstd_last)
+    w_norm = aux(w_norm, W_lm, H)
+    if idx.dtype != torch.int32:
+        raise TypeError("head_seed: idx must be int32")
     check(lib.lrp_head_seed(p(W_lm), p(logits), p(idx), p(w_norm), p(rstd_last), p(out), B, V, H, logits.stride(0), w_offset,
                             eps_lin, dt(W_lm), stream()), "lrp_head_seed")
     return out
@@ -330,12 +403,16 @@ def _iv(row_iv, B, S):
 
 
 def attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0, q_begin=0, row_iv=None):
+    same(q, k, v_t, o)
+    f32(lse)
     check(lib.lrp_attn_fwd(p(q), p(k), p(v_t), p(o), p(lse), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v_t.stride(2),
                            o.stride(0), scale, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_fwd")
     return o, lse
 
 
 def attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, eps_pv, factor=0.5):
+    same(Go, o, Gho)
+    f32(D)
     check(lib.lrp_attn_bwd_prep(p(Go), p(o), p(Gho), p(D), B, S, Hq, d, Go.stride(0), o.stride(0), Gho.stride(0), eps_pv,
                                 factor, dt(Go), stream()), "lrp_attn_bwd_prep")
     return Gho, D
@@ -343,6 +420,8 @@ def attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, eps_pv, factor=0.5):
 
 def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True, window=0, q_begin=0,
                 row_iv=None):
+    same(q, k, v, k_t, Gho, dq)
+    f32(lse, D)
     check(lib.lrp_attn_bwd_dq(p(q), p(k), p(v), p(k_t), p(Gho), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0),
                               k.stride(0), v.stride(0), k_t.stride(2), Gho.stride(0), dq.stride(0), scale, eps_mask, eps_qk,
                               int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_bwd_dq")
@@ -351,6 +430,8 @@ def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask
 
 def attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True,
                  window=0, q_begin=0, row_iv=None):
+    same(q, k, v, q_t, Gho, Gho_t, dk_h, dv_h)
+    f32(lse, D)
     check(lib.lrp_attn_bwd_dkv(p(q), p(k), p(v), p(q_t), p(Gho), p(Gho_t), p(lse), p(D), p(dk_h), p(dv_h), B, S, Hq, Hkv, d,
                                q.stride(0), k.stride(0), v.stride(0), q_t.stride(2), Gho.stride(0), dk_h.stride(0),
                                dv_h.stride(0), scale, eps_mask, eps_qk, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()),

@@ -53,10 +53,13 @@ def config_from_hf(hf_cfg):
         theta = rp.get("rope_theta")
     if theta is None:
         theta = getattr(hf_cfg, "rope_theta", 10000.0)
-    return dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size,
-                n_layers=hf_cfg.num_hidden_layers, n_heads=hf_cfg.num_attention_heads,
-                n_kv=hf_cfg.num_key_value_heads, head_dim=hd, vocab=hf_cfg.vocab_size,
-                rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps))
+    cfg = dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size,
+               n_layers=hf_cfg.num_hidden_layers, n_heads=hf_cfg.num_attention_heads,
+               n_kv=hf_cfg.num_key_value_heads, head_dim=hd, vocab=hf_cfg.vocab_size,
+               rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps))
+    if isinstance(rp, dict) and rp.get("rope_type", "default") != "default":
+        cfg["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
+    return cfg
 
 
 def weights_from_hf(model, dtype=torch.float32):
@@ -94,14 +97,39 @@ def random_weights(cfg, seed=0, dtype=torch.float32, std=0.02):
     return W
 
 
-def rope_tables(cfg, S, dtype):
-    """HF LlamaRotaryEmbedding.forward (default rope): cos/sin [S, head_dim], fp32 math."""
+def rope_inv_freq(cfg):
+    """-> (inv_freq [d/2] fp32, attention_scaling).  Restates HF's rope initialisers for the static rope types
+    (HF:modeling_rope_utils.py `_compute_default/linear_scaling/llama3_parameters`): "default", "linear" (inv_freq / factor),
+    "llama3" (Llama-3.1/3.2: low frequencies divided by `factor`, a smooth blend in the medium band).  The reference inherits
+    whatever HF computes (lxt patches nothing in the rotary embedding)."""
     d = cfg["head_dim"]
-    inv = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    inv = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, d, 2, dtype=torch.int64).to(torch.float32) / d))
+    rs = cfg.get("rope_scaling") or {}
+    kind = rs.get("rope_type", "default")
+    if kind == "default":
+        return inv, 1.0
+    if kind == "linear":
+        return inv / rs["factor"], 1.0
+    if kind == "llama3":
+        factor, lo_f, hi_f = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+        old_len = rs["original_max_position_embeddings"]
+        lo_wl, hi_wl = old_len / lo_f, old_len / hi_f
+        wl = 2 * math.pi / inv
+        out = torch.where(wl > lo_wl, inv / factor, inv)
+        smooth = (old_len / wl - lo_f) / (hi_f - lo_f)
+        blended = (1 - smooth) * out / factor + smooth * out
+        medium = ~(wl < hi_wl) & ~(wl > lo_wl)
+        return torch.where(medium, blended, out), 1.0
+    raise NotImplementedError(f"oracle: rope_type {kind!r}")
+
+
+def rope_tables(cfg, S, dtype):
+    """HF LlamaRotaryEmbedding.forward: cos/sin [S, head_dim], fp32 math, then the model dtype."""
+    inv, att = rope_inv_freq(cfg)
     pos = torch.arange(S, dtype=torch.float32)
     fr = pos[:, None] * inv[None, :]
     emb = torch.cat((fr, fr), dim=-1)
-    return emb.cos().to(dtype), emb.sin().to(dtype)
+    return (emb.cos() * att).to(dtype), (emb.sin() * att).to(dtype)
 
 
 def rotate_half(x):
@@ -122,8 +150,21 @@ def rms(x, w, eps):
 
 
 # ----------------------------------------------------------------------------- forward
-def forward(cfg, W, emb):
-    """emb [S,H] -> cache of every activation the backward needs (one prompt)."""
+def _ident(x):
+    return x
+
+
+def round_through(dtype):
+    """activation-storage model: every materialised activation is rounded through `dtype` (bf16: what a bf16 run of the
+    reference -- or of the HIP engine -- keeps in memory between ops) while the arithmetic stays in the oracle's dtype.
+    Used by the BASELINE-size bf16 test to quote the oracle's OWN sensitivity to bf16 storage next to the engine's error."""
+    return lambda x: x.to(dtype).to(x.dtype)
+
+
+def forward(cfg, W, emb, rnd=None):
+    """emb [S,H] -> cache of every activation the backward needs (one prompt).  rnd: optional storage-rounding model
+    (round_through); attention scores / probabilities stay un-rounded (fused attention keeps them on chip)."""
+    R = rnd or _ident
     S, H = emb.shape
     d, nq, nk = cfg["head_dim"], cfg["n_heads"], cfg["n_kv"]
     rep = nq // nk
@@ -135,46 +176,50 @@ def forward(cfg, W, emb):
     for Lw in W["layers"]:
         c = dict(h=h)
         x, c["rstd1"] = rms(h, Lw["ln1"], cfg["rms_eps"])
+        x = R(x)
         c["x"] = x
-        q = (x @ Lw["wq"].T).view(S, nq, d).transpose(0, 1)      # [nq,S,d]
-        k = (x @ Lw["wk"].T).view(S, nk, d).transpose(0, 1)
-        v = (x @ Lw["wv"].T).view(S, nk, d).transpose(0, 1)
-        qr = q * cos + rotate_half(q) * sin
-        kr = k * cos + rotate_half(k) * sin
+        q = R(x @ Lw["wq"].T).view(S, nq, d).transpose(0, 1)      # [nq,S,d]
+        k = R(x @ Lw["wk"].T).view(S, nk, d).transpose(0, 1)
+        v = R(x @ Lw["wv"].T).view(S, nk, d).transpose(0, 1)
+        qr = R(q * cos + rotate_half(q) * sin)
+        kr = R(k * cos + rotate_half(k) * sin)
         kx = kr.repeat_interleave(rep, dim=0)
         vx = v.repeat_interleave(rep, dim=0)
         s = qr @ kx.transpose(-1, -2)                              # raw scores (lf.matmul output)
         s2 = s * scale
         s3 = s2.masked_fill(~causal, float("-inf"))
         p = F.softmax(s3, dim=-1)
-        o = p @ vx                                                 # [nq,S,d]
+        o = R(p @ vx)                                              # [nq,S,d]
         of = o.transpose(0, 1).reshape(S, nq * d)
-        a = of @ Lw["wo"].T
-        h1 = h + a
+        a = R(of @ Lw["wo"].T)
+        h1 = R(h + a)
         x2, c["rstd2"] = rms(h1, Lw["ln2"], cfg["rms_eps"])
-        g = x2 @ Lw["wg"].T
-        u = x2 @ Lw["wu"].T
+        x2 = R(x2)
+        g = R(x2 @ Lw["wg"].T)
+        u = R(x2 @ Lw["wu"].T)
         act = F.silu(g)
-        m = act * u
-        dn = m @ Lw["wd"].T
-        h2 = h1 + dn
+        m = R(act * u)
+        dn = R(m @ Lw["wd"].T)
+        h2 = R(h1 + dn)
         c.update(q=q, k=k, v=v, qr=qr, kr=kr, s=s, p=p, o=o, of=of, a=a, h1=h1, x2=x2, g=g, u=u,
                  act=act, m=m, dn=dn, h2=h2)
         layers.append(c)
         h = h2
     xn, rstdf = rms(h, W["norm"], cfg["rms_eps"])
+    xn = R(xn)
     logits_last = xn[-1] @ W["lm_head"].T
     return dict(layers=layers, hf=h, xn=xn, rstdf=rstdf, logits_last=logits_last, cos=cos, sin=sin,
                 scale=scale, causal=causal)
 
 
 # ----------------------------------------------------------------------------- backward
-def backward(cfg, W, cache, target, mode="explicit", seed=None):
+def backward(cfg, W, cache, target, mode="explicit", seed=None, rnd=None):
     """Gradient-form LRP backward.  Returns G at the embedding [S,H] and per-layer sum(h*G_h).
     seed [V] (optional, instead of target): what the user hands to `logits[0,-1].backward(seed)` -- a GRADIENT over the
     last-position logits in efficient mode (contrastive explanations, ref docs/source/quickstart.rst:267-270), a
     RELEVANCE over them in explicit mode (ref examples/paper/llama.py:45: `.backward(logit)` is the one-hot case)."""
     E = eps_table(mode)
+    R = rnd or _ident
     S = cache["hf"].shape[0]
     d, nq, nk = cfg["head_dim"], cfg["n_heads"], cfg["n_kv"]
     rep = nq // nk
@@ -190,14 +235,14 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None):
         coef = seed.to(zl.dtype) / (zl + E["lin"]) if mode == "explicit" else seed.to(zl.dtype)
         g_xn_last = coef @ W["lm_head"]                            # Linear eps rule over every seeded logit
     Gh = torch.zeros(S, cfg["hidden"], dtype=dt)
-    Gh[-1] = g_xn_last * W["norm"] * cache["rstdf"][-1]            # RMSNorm identity rule
+    Gh[-1] = R(g_xn_last * W["norm"] * cache["rstdf"][-1])         # RMSNorm identity rule
     layer_R = [float((cache["hf"] * Gh).sum())]
 
     for Lw, c in zip(reversed(W["layers"]), reversed(cache["layers"])):
         # h2 = add2(h1, dn)
-        Gs = Gh * ratio(c["h2"], 1, E["add"])
+        Gs = R(Gh * ratio(c["h2"], 1, E["add"]))
         # down_proj eps rule
-        Gm = (Gs * ratio(c["dn"], 1, E["lin"])) @ Lw["wd"]
+        Gm = R(R(Gs * ratio(c["dn"], 1, E["lin"])) @ Lw["wd"])
         # uniform rule on act*u, identity rule on silu
         Gu = 0.5 * Gm * c["act"]
         Gact = 0.5 * Gm * c["u"]
@@ -207,14 +252,14 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None):
         else:
             Ag = Gact * (c["act"] / (c["g"] + E["act"]))           # efficient: act/(g+1e-10), plain Linear
         Au = Gu * ratio(c["u"], 1, E["lin"])
-        Gx2 = Ag @ Lw["wg"] + Au @ Lw["wu"]
+        Gx2 = R(R(Ag) @ Lw["wg"] + R(Au) @ Lw["wu"])
         Gh1 = Gs + Gx2 * Lw["ln2"] * c["rstd2"]
         # h1 = add2(h, a)
-        Gs1 = Gh1 * ratio(c["h1"], 1, E["add"])
-        Gof = (Gs1 * ratio(c["a"], 1, E["lin"])) @ Lw["wo"]
+        Gs1 = R(Gh1 * ratio(c["h1"], 1, E["add"]))
+        Gof = R(R(Gs1 * ratio(c["a"], 1, E["lin"])) @ Lw["wo"])
         Go = Gof.view(S, nq, d).transpose(0, 1)                    # [nq,S,d]
         # P.V : UniformEpsilon rule (c=1, then /2)
-        Ghat_o = 0.5 * Go * ratio(c["o"], 1, E["pv"])
+        Ghat_o = R(0.5 * Go * ratio(c["o"], 1, E["pv"]))
         vx = c["v"].repeat_interleave(rep, dim=0)
         kx = c["kr"].repeat_interleave(rep, dim=0)
         dP = Ghat_o @ vx.transpose(-1, -2)
@@ -226,10 +271,10 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None):
         dS2 = torch.where(causal, dS3 * ratio(s2, 1, E["mask"]), torch.zeros_like(dS3))
         dS = dS2 * scale                                            # mul2 by the constant 1/sqrt(d)
         Ghat_s = dS * ratio(c["s"], 2, E["qk"])                     # lf.matmul: R/(2 s + eps)
-        dQr = Ghat_s @ kx
-        dKx = Ghat_s.transpose(-1, -2) @ c["qr"]
-        dKr = dKx.view(nk, rep, S, d).sum(1)
-        dV = dVx.view(nk, rep, S, d).sum(1)
+        dQr = R(Ghat_s @ kx)
+        dKx = R(Ghat_s.transpose(-1, -2) @ c["qr"])
+        dKr = R(dKx.view(nk, rep, S, d).sum(1))
+        dV = R(R(dVx).view(nk, rep, S, d).sum(1))
         # RoPE: add2 eps on the rotated tensor, then ordinary transpose of the rotation
         def rope_bwd(Gr, r):
             Gp = Gr * ratio(r, 1, E["rope"])
@@ -239,22 +284,22 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None):
         Aq = (Gq * ratio(c["q"], 1, E["lin"])).transpose(0, 1).reshape(S, nq * d)
         Ak = (Gk * ratio(c["k"], 1, E["lin"])).transpose(0, 1).reshape(S, nk * d)
         Av = (dV * ratio(c["v"], 1, E["lin"])).transpose(0, 1).reshape(S, nk * d)
-        Gx = Aq @ Lw["wq"] + Ak @ Lw["wk"] + Av @ Lw["wv"]
-        Gh = Gs1 + Gx * Lw["ln1"] * c["rstd1"]
+        Gx = R(R(Aq) @ Lw["wq"] + R(Ak) @ Lw["wk"] + R(Av) @ Lw["wv"])
+        Gh = R(Gs1 + Gx * Lw["ln1"] * c["rstd1"])
         layer_R.append(float((c["h"] * Gh).sum()))
     return Gh, layer_R[::-1]
 
 
-def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32, seed=None):
+def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32, seed=None, rnd=None):
     """One explanation: returns dict(idx, logit, R_tok [S], R_emb [S,H], layer_R [L+1])."""
     Wd = cast_weights(W, dtype)
     if emb is None:
         emb = Wd["embed"][ids]
     emb = emb.to(dtype)
-    cache = forward(cfg, Wd, emb)
+    cache = forward(cfg, Wd, emb, rnd=rnd)
     if target is None:
         target = int(cache["logits_last"].argmax())
-    G, layer_R = backward(cfg, Wd, cache, target, mode, seed=seed)
+    G, layer_R = backward(cfg, Wd, cache, target, mode, seed=seed, rnd=rnd)
     R_emb = emb * G
     return dict(idx=target, logit=float(cache["logits_last"][target]), R_tok=R_emb.sum(-1),
                 R_emb=R_emb, layer_R=layer_R, logits_last=cache["logits_last"])

@@ -95,7 +95,8 @@ def mini_vit():
     monkey_patch(types.ModuleType("mini_vit"), cp_LRP)
     model = build_mini_vit()
     assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * abs(float(fx["wsum"])), "weights did not reproduce"
-    model = model.cuda()
+    from lxt_amd.efficient import adopt
+    model = adopt(model.cuda())          # a plain torch.nn model: its Linear / LayerNorm / Conv2d instances join the HIP path
     x = t(fx["x"]).cuda().requires_grad_()
     y = model(x)
     idx = y.argmax(-1)

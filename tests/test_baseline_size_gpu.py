@@ -1,0 +1,189 @@
+"""GPU parity AT THE BASELINE WIDTH AND SEQUENCE LENGTH (BASELINE.json configs 3 and 5): Llama-3-8B layer shape
+H 4096 / I 14336 / 32 query + 8 kv heads / d 128 at S = 2048, two decoder layers, small vocabulary -- the shapes that put
+the 256x256 software-pipelined GEMM, the 8-wave attention kernels and the one-pass small-M Linear kernel on the path.
+
+  (a) fused engine, fp32, mode explicit AND efficient, against oracle/llama.py in fp64 on the host   -- bar 1e-4
+      (what the reference defines at this size: lxt/explicit/models/llama.py:83-93,379-391,481-488);
+  (b) fused engine, bf16, against the fp64 oracle on the bf16-rounded weights; the bar is tied to the oracle's OWN
+      sensitivity to bf16 activation storage (oracle.llama.round_through), printed next to the engine's error;
+  (c) the drop-in path (HF LlamaForCausalLM + lxt_amd.efficient.monkey_patch, one fresh process) on the same weights
+      against the same oracle                                                                          -- bar 1e-4;
+  (d) the attention kernels alone at S = 2048 and S = 4096 (config 5's sequence length), d 128, GQA 4:1, causal,
+      against an fp64 eager attention.
+Metric: normalised max error max|dR| / max|R|."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama as ol
+from tests.util import nmax
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+CFG = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=2048, rope_theta=500000.0, rms_eps=1e-5)
+S = 2048
+WSEED, IDSEED = 20, 21
+
+
+def _oracle_both_modes(W, ids, dtype, target=None, rnd=None, modes=("explicit", "efficient")):
+    """one oracle forward, one backward per mode -> {mode: dict(R_tok, R_emb, layer_R)}, idx, logit"""
+    Wd = ol.cast_weights(W, dtype)
+    emb = Wd["embed"][ids]
+    cache = ol.forward(CFG, Wd, emb, rnd=rnd)
+    idx = int(cache["logits_last"].argmax()) if target is None else target
+    out = {}
+    for mode in modes:
+        G, layer_R = ol.backward(CFG, Wd, cache, idx, mode, rnd=rnd)
+        R_emb = emb * G
+        out[mode] = dict(R_tok=R_emb.sum(-1), R_emb=R_emb, layer_R=torch.tensor(layer_R, dtype=torch.float64))
+    return out, idx, float(cache["logits_last"][idx])
+
+
+@pytest.fixture(scope="module")
+def case():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    t0 = time.time()
+    W = ol.random_weights(CFG, seed=WSEED)
+    ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(IDSEED))
+    ref64, idx, logit = _oracle_both_modes(W, ids, torch.float64)
+    ref32, _, _ = _oracle_both_modes(W, ids, torch.float32, target=idx)
+    gap = {m: {k: nmax(ref32[m][k], ref64[m][k]) for k in ("R_tok", "R_emb", "layer_R")} for m in ref64}
+    print(f"[baseline-size oracle] fp64 + fp32 runs in {time.time() - t0:.1f} s on {torch.get_num_threads()} host threads; "
+          f"oracle's own fp32-vs-fp64 gap (token / neuron / layer): explicit {gap['explicit']['R_tok']:.1e} / "
+          f"{gap['explicit']['R_emb']:.1e} / {gap['explicit']['layer_R']:.1e}, efficient {gap['efficient']['R_tok']:.1e} / "
+          f"{gap['efficient']['R_emb']:.1e} / {gap['efficient']['layer_R']:.1e}")
+    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap)
+
+
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_engine_fp32_full_width_vs_oracle(case, mode):
+    import lxt_amd.engine as E
+    eng = E.LlamaLRP(CFG, case["W"], dtype=torch.float32, mode=mode, max_seq=S)
+    out = eng.explain(case["ids"][None], layer_relevance=True, return_G=True)
+    ref = case["ref64"][mode]
+    assert int(out["idx"][0]) == case["idx"]
+    assert abs(float(out["logit"][0]) - case["logit"]) < 1e-4 * max(1.0, abs(case["logit"]))
+    e_tok = nmax(out["R_tok"][0], ref["R_tok"])
+    e_neu = nmax(out["emb"][0].double() * out["G_emb"][0].double(), ref["R_emb"])
+    e_lay = nmax(out["layer_R"][:, 0], ref["layer_R"])
+    gap = case["gap"][mode]
+    print(f"[H4096/S2048 fp32 {mode}] token {e_tok:.2e} | neuron {e_neu:.2e} | layer {e_lay:.2e} "
+          f"(oracle's own fp32-vs-fp64 gap on this instance: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
+    # explicit mode: z/(z+eps) has a pole at z = -eps and at this size some of the 2 x 8.4 M P.V outputs
+    # land within a few percent of it; where the reference's OWN fp32 run does not resolve the instance to 1e-4 the bar
+    # follows the reference's fp32-vs-fp64 disagreement for that quantity, otherwise it is the north star's 1e-4
+    assert e_tok < max(1e-4, 3 * gap["R_tok"]) and e_neu < max(1e-4, 3 * gap["R_emb"]) and e_lay < max(1e-4, 3 * gap["layer_R"])
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_engine_bf16_full_width_vs_oracle(case):
+    """bf16 engine (the headline dtype) against the fp64 oracle on the SAME bf16-rounded weights and explained token.
+    Bar: 5x the oracle's own error when its activations are stored in bf16 (fp32 arithmetic between the stores) -- the
+    floor any bf16 evaluation of this instance has, including the reference's own bf16 run -- and never above 5e-2."""
+    import lxt_amd.engine as E
+    Wb = ol.cast_weights(ol.cast_weights(case["W"], torch.bfloat16), torch.float32)
+    ref, idx, _ = _oracle_both_modes(Wb, case["ids"], torch.float64, modes=("efficient",))
+    stor, _, _ = _oracle_both_modes(Wb, case["ids"], torch.float32, target=idx, rnd=ol.round_through(torch.bfloat16), modes=("efficient",))
+    floor = nmax(stor["efficient"]["R_tok"], ref["efficient"]["R_tok"])
+    eng = E.LlamaLRP(CFG, case["W"], dtype=torch.bfloat16, mode="efficient", max_seq=S)
+    out = eng.explain(case["ids"][None], target=torch.tensor([idx]))
+    e_tok = nmax(out["R_tok"][0], ref["efficient"]["R_tok"])
+    a, b = out["R_tok"][0].double().cpu(), ref["efficient"]["R_tok"]
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    print(f"[H4096/S2048 bf16 efficient] engine vs fp64 oracle on bf16 weights {e_tok:.2e} (cosine {cos:.6f}); "
+          f"oracle with bf16 activation storage vs itself in fp64: {floor:.2e}")
+    assert torch.isfinite(out["R_tok"]).all()
+    assert e_tok < min(5e-2, max(5 * floor, 1e-2)) and cos > 0.999
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
+    """HF LlamaForCausalLM (fp32, eager and sdpa) under lxt_amd.efficient.monkey_patch on the same weights, in a fresh
+    process (the patches are class-level), against the same fp64 oracle: the user protocol of
+    docs/source/quickstart.rst:120-141 at the BASELINE width."""
+    ref = case["ref64"]["efficient"]
+    path = str(tmp_path / "ref.npz")
+    np.savez(path, ids=case["ids"].numpy(), idx=case["idx"], logit=case["logit"], R_tok=ref["R_tok"].numpy(),
+             cfg_keys=np.array(list(CFG.keys())), cfg_vals=np.array([float(v) for v in CFG.values()]), wseed=WSEED)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "baseline_dropin_worker.py"), path], capture_output=True,
+                       text=True, timeout=1500, cwd=ROOT)
+    print(r.stdout[-1200:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------------------ (d) attention kernels at S = 2048 / 4096
+def _tm(x):      # [B,H,S,d] -> token-major [B*S, H*d]
+    B, H, S_, d = x.shape
+    return x.permute(0, 2, 1, 3).reshape(B * S_, H * d).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S_", [2048, 4096])
+@pytest.mark.parametrize("mode", ["efficient", "explicit"])
+def test_attention_long_sequences(dtype, S_, mode):
+    """forward, dQ, dK/dV at config 3's / config 5's sequence length (d 128, GQA 4:1, causal) against fp64 eager attention
+    with the LRP modifiers (ref: lxt/explicit/functional.py:293-322,385-408, rules.py:267-282); 8 query heads keep the fp64
+    score tensors at 1 GB"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.ops as ops
+    B, Hq, Hkv, d = 1, 8, 2, 128
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    g = torch.Generator(device="cuda").manual_seed(S_)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda").to(dtype)       # noqa: E731
+    f64 = lambda x: x.double()                                                    # noqa: E731
+    q, k, v = rnd(B, Hq, S_, d), rnd(B, Hkv, S_, d), rnd(B, Hkv, S_, d)
+    scale, rep = d ** -0.5, Hq // Hkv
+    qt, kt, vt = _tm(q), _tm(k), _tm(v)
+    v_t = ops.transpose_heads(vt, B, S_, Hkv, d)
+    o = torch.empty(B * S_, Hq * d, dtype=dtype, device="cuda")
+    lse = torch.empty(B, Hq, S_, device="cuda")
+    ops.attn_fwd(qt, kt, v_t, o, lse, B, S_, Hq, Hkv, d, scale, True, 0)
+    kx, vx = f64(k).repeat_interleave(rep, 1), f64(v).repeat_interleave(rep, 1)
+    s = f64(q) @ kx.transpose(-1, -2)
+    i = torch.arange(S_, device="cuda")
+    vis = i[None, :] <= i[:, None]
+    s3 = (s * scale).masked_fill(~vis, float("-inf"))
+    p = torch.softmax(s3, -1)
+    e_o, e_lse = nmax(o, _tm(p @ vx)), nmax(lse, torch.logsumexp(s3, -1))
+    del s3
+    E = dict(pv=1e-6, mask=1e-8, qk=1e-8) if mode == "explicit" else dict(pv=0.0, mask=0.0, qk=0.0)
+    Go = rnd(B * S_, Hq * d)
+    Gho, D = torch.empty_like(Go), torch.empty(B, Hq, S_, device="cuda")
+    ops.attn_bwd_prep(Go, o, Gho, D, B, S_, Hq, d, E["pv"], 0.5)
+    Gh = f64(Gho).reshape(B, S_, Hq, d).permute(0, 2, 1, 3)
+    dP = Gh @ vx.transpose(-1, -2)
+    dS3 = p * (dP - (dP * p).sum(-1, keepdim=True))
+    del dP
+    f = torch.ones_like(s)
+    if E["mask"]:
+        f = f * (s * scale) / (s * scale + E["mask"])
+    f = f * (s / (2 * s + E["qk"]) if E["qk"] else 0.5)
+    Ghs = torch.where(vis, dS3 * scale * f, torch.zeros_like(s))
+    del dS3, f, s
+    dQ = Ghs @ kx
+    dK = (Ghs.transpose(-1, -2) @ f64(q)).reshape(B, Hkv, rep, S_, d).sum(2)
+    dV = (p.transpose(-1, -2) @ Gh).reshape(B, Hkv, rep, S_, d).sum(2)
+    del Ghs, p
+    k_t, q_t, Gho_t = ops.transpose_heads(kt, B, S_, Hkv, d), ops.transpose_heads(qt, B, S_, Hq, d), ops.transpose_heads(Gho, B, S_, Hq, d)
+    dq = torch.empty_like(qt)
+    ops.attn_bwd_dq(qt, kt, vt, k_t, Gho, lse, D, dq, B, S_, Hq, Hkv, d, scale, E["mask"], E["qk"], True, 0)
+    dk_h, dv_h = torch.empty_like(qt), torch.empty_like(qt)
+    ops.attn_bwd_dkv(qt, kt, vt, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S_, Hq, Hkv, d, scale, E["mask"], E["qk"], True, 0)
+    dk, dv = torch.empty_like(kt), torch.empty_like(vt)
+    ops.gqa_reduce(dk_h, dk, B * S_, Hkv, rep, d)
+    ops.gqa_reduce(dv_h, dv, B * S_, Hkv, rep, d)
+    e_dq, e_dk, e_dv = nmax(dq, _tm(dQ)), nmax(dk, _tm(dK)), nmax(dv, _tm(dV))
+    print(f"[attention S={S_} {str(dtype)[6:]} {mode}] o {e_o:.2e} lse {e_lse:.2e} dQ {e_dq:.2e} dK {e_dk:.2e} dV {e_dv:.2e}")
+    assert e_o < tol and e_lse < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert e_dq < 3 * tol and e_dk < 3 * tol and e_dv < 3 * tol
+    torch.cuda.empty_cache()

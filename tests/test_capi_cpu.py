@@ -81,3 +81,82 @@ def test_mask_plan_reduces_hf_masks_to_row_intervals():
     hole[6, 2] = False
     with pytest.raises(NotImplementedError, match="non-contiguous"):
         _mask_plan(hole[None, None].clone(), S, mod)
+
+
+def test_patched_torch_nn_classes_leave_foreign_modules_alone():
+    """after monkey_patch(modeling_llama) / (modeling_bert) the class-level nn.Linear / nn.LayerNorm patches must only act on
+    instances of an explained model: a CPU nn.Linear or nn.LayerNorm elsewhere in the process still runs torch's own forward
+    (bit-identical), keeps its parameter gradients, and a model class of the patched module adopts its instances on the
+    first call.  The reference never patches nn.Linear at all (lxt/efficient/models/llama.py:9-14).  One fresh process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, warnings, torch
+sys.path.insert(0, %r)
+warnings.simplefilter("ignore")
+from torch import nn
+import torch.nn.functional as F
+from transformers.models.llama import modeling_llama
+from transformers.models.bert import modeling_bert
+from lxt_amd.efficient import monkey_patch, adopt
+lin, ln = nn.Linear(8, 6), nn.LayerNorm(8)
+x = torch.randn(3, 8)
+y0, n0 = lin(x).detach().clone(), ln(x).detach().clone()
+monkey_patch(modeling_llama)
+monkey_patch(modeling_bert)
+assert nn.Linear.forward.__module__ == "lxt_amd.efficient.patches"
+y1 = lin(x)
+assert torch.equal(y1, y0) and torch.equal(ln(x), n0)
+y1.sum().backward()
+assert lin.weight.grad is not None and torch.equal(lin.weight.grad, x.sum(0)[None].expand(6, 8))
+# a model class defined in the patched module adopts its nn.Linear instances on the first call
+cfg = modeling_llama.LlamaConfig(hidden_size=16, intermediate_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                 num_key_value_heads=1, vocab_size=32)
+m = modeling_llama.LlamaForCausalLM(cfg)
+for p_ in m.parameters():
+    p_.requires_grad_(False)
+assert not m.lm_head.__dict__.get("_lrp_owned", False)
+try:
+    m(input_ids=torch.zeros(1, 4, dtype=torch.long))
+    raise SystemExit("an adopted model on the CPU must fail loudly (no CPU fallback)")
+except RuntimeError as e:
+    assert "no CPU fallback" in str(e), e
+assert m.lm_head.__dict__["_lrp_owned"] and m.model.layers[0].mlp.down_proj.__dict__["_lrp_owned"]
+assert not lin.__dict__.get("_lrp_owned", False)
+print("SCOPED-OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SCOPED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rope_scaling_tables_match_hf():
+    """oracle.llama.rope_inv_freq restates HF's static rope initialisers (Llama-3.1/3.2 use rope_type='llama3'); the engine
+    takes HF's own frequencies through config_from_hf.  Both against transformers' ROPE_INIT_FUNCTIONS on the CPU."""
+    from transformers import LlamaConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    from oracle import llama as ol
+    import lxt_amd.engine as E
+    rp = dict(rope_type="llama3", rope_theta=500000.0, factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+              original_max_position_embeddings=8192)
+    hc = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                     head_dim=128, vocab_size=64, rope_parameters=rp)
+    ref, att = ROPE_INIT_FUNCTIONS["llama3"](hc, "cpu")
+    ocfg = ol.config_from_hf(hc)
+    inv, oatt = ol.rope_inv_freq(ocfg)
+    assert oatt == att == 1.0 and torch.equal(inv, ref)
+    assert not torch.equal(inv, ol.rope_inv_freq(dict(ocfg, rope_scaling=None))[0])          # the scaling really changes the table
+    ecfg = E.config_from_hf(hc)
+    assert torch.equal(ecfg["inv_freq"], ref) and ecfg["attention_scaling"] == 1.0
+    lin = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                      head_dim=128, vocab_size=64, rope_parameters=dict(rope_type="linear", rope_theta=10000.0, factor=4.0))
+    assert torch.equal(ol.rope_inv_freq(ol.config_from_hf(lin))[0], ROPE_INIT_FUNCTIONS["linear"](lin, "cpu")[0])
+    # unsupported configurations are refused loudly instead of being silently ignored
+    for bad in (dict(attention_bias=True), dict(mlp_bias=True),
+                dict(rope_parameters=dict(rope_type="dynamic", rope_theta=10000.0, factor=2.0))):
+        kw = dict(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=8)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            E.config_from_hf(LlamaConfig(**kw))
+    from transformers import Qwen2Config
+    with pytest.raises(NotImplementedError, match="model_type"):
+        E.config_from_hf(Qwen2Config(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=8))

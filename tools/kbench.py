@@ -78,11 +78,12 @@ def bench_attn(dtype, B, S, Hq, Hkv, d):
     t = timeit(lambda: ops.transpose_heads(q, B, S, Hq, d, out=q_t))
     print(f"transpose_heads q: {t*1e6:9.1f} us  {2*q.numel()*q.element_size()/t/1e9:7.1f} GB/s")
     dq = torch.empty_like(q)
-    t = timeit(lambda: ops.attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, sc, 1e-8, 1e-8))
-    print(f"attn dq   : {t*1e6:9.1f} us  {1.5*fl/t/1e12:7.1f} TF/s", flush=True)
     dk, dv = torch.empty_like(q), torch.empty_like(q)
-    t = timeit(lambda: ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk, dv, B, S, Hq, Hkv, d, sc, 1e-8, 1e-8))
-    print(f"attn dkv  : {t*1e6:9.1f} us  {2*fl/t/1e12:7.1f} TF/s", flush=True)
+    for name, e in (("efficient", 0.0), ("explicit", 1e-8)):
+        t = timeit(lambda: ops.attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, sc, e, e))
+        print(f"attn dq   {name}: {t*1e6:9.1f} us  {1.5*fl/t/1e12:7.1f} TF/s", flush=True)
+        t = timeit(lambda: ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk, dv, B, S, Hq, Hkv, d, sc, e, e))
+        print(f"attn dkv  {name}: {t*1e6:9.1f} us  {2*fl/t/1e12:7.1f} TF/s", flush=True)
 
 
 def bench_row(dtype, M, H, I):
@@ -133,7 +134,9 @@ if __name__ == "__main__":
     elif "gemm" in a.what:
         bench_gemm(torch.bfloat16, L)
         bench_gemm(torch.float32, [(2048, 4096, 4096), (2048, 14336, 4096)])
-    if "attn" in a.what:
+    if "attnb" in a.what:
+        bench_attn(torch.bfloat16, 4, 2048, 32, 8, 128)
+    elif "attn" in a.what:
         bench_attn(torch.bfloat16, 1, 2048, 32, 8, 128)
         bench_attn(torch.bfloat16, 4, 2048, 32, 8, 128)
         bench_attn(torch.float32, 1, 2048, 32, 8, 128)
