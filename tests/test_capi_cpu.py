@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     raw = ctypes.CDLL(L.LIB_PATH)
     for name in decls:
         assert hasattr(raw, name), f"{name} declared in lrp_hip.h but not exported"
-    assert L.lib.lrp_version() == 1 and L.lib.lrp_build_arch() == b"gfx950"
+    assert L.lib.lrp_version() == 2 and L.lib.lrp_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu():
@@ -25,7 +25,7 @@ def test_argument_validation_without_gpu():
     assert L.lib.lrp_gemm_nt(None, None, None, None, 4, 4, 8, 8, 8, 4, 1, 0, 0, 0, 0, 0, None) == -1
     assert L.lib.lrp_gemm_nt(16, 16, 16, None, 4, 4, 6, 8, 8, 4, 1, 0, 0, 0, 0, 0, None) == -2
     assert L.lib.lrp_eps_scale(None, None, None, 10, 1.0, 1e-6, 0, 0, None) == -1
-    assert L.lib.lrp_attn_fwd(16, 16, 16, 16, 16, 1, 8, 3, 2, 64, 64, 64, 8, 64, 1.0, 1, 0, 0, None, None, 1, None) == -1  # Hq % Hkv
+    assert L.lib.lrp_attn_fwd(16, 16, 16, 16, 16, 16, 1, 8, 3, 2, 64, 64, 64, 64, 8, 64, 1.0, 1, 0, 0, None, None, 1, None) == -1  # Hq % Hkv
 
 
 def test_no_cpu_fallback():

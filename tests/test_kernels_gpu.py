@@ -295,7 +295,8 @@ def _tm(x):      # [B,H,S,d] -> token-major [B*S, H*d]
 @pytest.mark.parametrize("B,S,Hq,Hkv,d,causal,window", [
     (1, 16, 4, 2, 16, True, 0), (2, 100, 4, 2, 32, True, 0), (1, 192, 4, 1, 128, True, 0),
     (1, 130, 2, 2, 64, False, 0), (1, 200, 2, 1, 64, True, 48), (1, 300, 8, 2, 128, True, 0),
-    (1, 150, 2, 1, 256, True, 0), (1, 150, 2, 1, 256, True, 64)])
+    (1, 150, 2, 1, 256, True, 0), (1, 150, 2, 1, 256, True, 64),
+    (1, 500, 4, 2, 128, True, 100), (1, 260, 4, 2, 128, False, 0), (2, 700, 8, 2, 128, True, 0), (1, 257, 4, 4, 128, True, 0)])
 @pytest.mark.parametrize("mode", ["efficient", "explicit"])
 def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     if dtype == torch.bfloat16 and d < 32:
@@ -308,7 +309,7 @@ def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     assert torch.equal(v_t[..., :S], v.transpose(-1, -2))
     o = torch.empty(B * S, Hq * d, dtype=dtype, device="cuda")
     lse = torch.empty(B, Hq, S, device="cuda")
-    ops.attn_fwd(qt, kt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
+    ops.attn_fwd(qt, kt, vt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
     s, p, o_ref, vis, rep = _attn_ref(f64(q), f64(k), f64(v), scale, causal, window)
     assert nmax(o, _tm(o_ref)) < tol
     lse_ref = torch.logsumexp((s * scale).masked_fill(~vis, float("-inf")), -1)
@@ -378,7 +379,8 @@ def _intervals(kind, B, S):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["left_pad", "right_pad", "packed", "image_block"])
-@pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40)])
+@pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40),
+                                                 (2, 330, 4, 2, 128, 0), (2, 300, 2, 1, 128, 70)])
 def test_attention_row_intervals(ops, dtype, kind, B, S, Hq, Hkv, d, window):
     """per-row key intervals (padding / packed sequences / bidirectional blocks) against an fp64 eager attention with
     the same boolean mask; rows with an empty interval must come out as exact zeros and stay NaN-free"""
@@ -393,7 +395,7 @@ def test_attention_row_intervals(ops, dtype, kind, B, S, Hq, Hkv, d, window):
     v_t = ops.transpose_heads(vt, B, S, Hkv, d)
     o = torch.empty(B * S, Hq * d, dtype=dtype, device="cuda")
     lse = torch.empty(B, Hq, S, device="cuda")
-    ops.attn_fwd(qt, kt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
+    ops.attn_fwd(qt, kt, vt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window, row_iv=row_iv)
     j = torch.arange(S, device="cuda")
     vis = (j[None, None, :] >= row_iv[0][:, :, None]) & (j[None, None, :] < row_iv[1][:, :, None])      # [B,S,S]
     if causal:

@@ -68,7 +68,7 @@ def bench_attn(dtype, B, S, Hq, Hkv, d):
     lse = torch.empty(B, Hq, S, device="cuda")
     sc = d ** -0.5
     fl = 2 * 2 * B * Hq * S * S * d / 2
-    t = timeit(lambda: ops.attn_fwd(q, k, v_t, o, lse, B, S, Hq, Hkv, d, sc, True, 0))
+    t = timeit(lambda: ops.attn_fwd(q, k, v, v_t, o, lse, B, S, Hq, Hkv, d, sc, True, 0))
     print(f"attn fwd  {str(dtype)[6:]:8s} B={B} S={S} Hq={Hq} d={d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s (causal flops)", flush=True)
     Go = torch.randn_like(q)
     Gho, D = torch.empty_like(q), torch.empty(B, Hq, S, device="cuda")
