@@ -16,6 +16,10 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+// bf16 256x256 kernel on 32x32x16 MFMAs (gemm32.hip)
+int lrp_gemm_m32(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                 int64_t ldc, int out_f32, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, KB = 128;     // KB: bytes of K per stage and per row
@@ -1423,6 +1427,12 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // form with software-pipelined fragments and hand-counted lgkmcnt waits (+4.5 % in situ over cfg 7: 1307 vs 1250 TFLOP/s)
     static const int big_cfg = [] { const char* e = getenv("LRP_GEMM_BIG"); return e ? atoi(e) : 28; }();
     if (cfg == 0) cfg = ntiles(256, 256) >= 190 ? big_cfg : 1;
+    if (cfg == 30) {
+        if constexpr (!dtype_is_f32<T>()) {
+            if (batch == 1) return lrp_gemm_m32(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4, st);
+        }
+        cfg = 28;
+    }
     if (cfg == 16) {   // 32-bit lane offsets: the clamped tile must span < 4 Gi elements
         const int nkt16 = K / ((dtype_is_f32<T>()) ? 32 : 64);
         if ((int64_t)256 * lda < (int64_t)1 << 31 && (int64_t)256 * ldb < (int64_t)1 << 31 && nkt16 >= 2 && (nkt16 % 2) == 0)

@@ -92,19 +92,43 @@ class LlamaLRP:
         self.act = cfg.get("act", "silu")
         dev = self.device
 
-        def put(t):
-            return t.to(device=dev, dtype=dtype).contiguous()
+        # ONE flat device buffer holds every weight in its forward layout (embedding, norms, LM head, per layer the fused
+        # [q;k;v] and [gate;up] matrices, o, down): the tensors below are views into it, so the multi-GPU start-up is a
+        # single broadcast of `self.flat` (lxt_amd.dist.broadcast_weights) followed by the LOCAL W^T copies
+        H, I, nq, nk, hd, V = cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv"], cfg["head_dim"], cfg["vocab"]
+        nqkv = (nq + 2 * nk) * hd
+        up = lambda n: (n + 63) // 64 * 64                                   # noqa: E731  (every view starts 128-byte aligned)
+        per_layer = 2 * up(H) + up(nqkv * H) + up(H * nq * hd) + up(2 * I * H) + up(H * I)
+        total = 2 * up(V * H) + up(H) + len(W["layers"]) * per_layer
+        self.flat = torch.empty(total, device=dev, dtype=dtype)
+        cursor = [0]
 
-        self.embed, self.norm, self.lm_head = put(W["embed"]), put(W["norm"]), put(W["lm_head"])
-        self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
+        def take(*shape):
+            n = 1
+            for s_ in shape:
+                n *= s_
+            v = self.flat[cursor[0]: cursor[0] + n].view(*shape)
+            cursor[0] += up(n)
+            return v
+
+        def put(dst, *srcs):
+            o = 0
+            for t in srcs:
+                rows = t.shape[0]
+                dst[o: o + rows].copy_(t.to(device=dev, dtype=dtype, non_blocking=True))
+                o += rows
+            return dst
+
+        self.embed, self.lm_head = put(take(V, H), W["embed"]), put(take(V, H), W["lm_head"])
+        self.norm = put(take(H), W["norm"])
         self.lm_head_t = None                        # [H, V] copy, made on the first dense-seed explanation
         self.layers = []
         for L in W["layers"]:
-            wqkv = torch.cat([put(L["wq"]), put(L["wk"]), put(L["wv"])], dim=0)
-            wgu = torch.cat([put(L["wg"]), put(L["wu"])], dim=0)
-            wo, wd = put(L["wo"]), put(L["wd"])
-            self.layers.append(dict(ln1=put(L["ln1"]), ln2=put(L["ln2"]), wqkv=wqkv, wqkv_t=ops.transpose(wqkv), wo=wo,
-                                    wo_t=ops.transpose(wo), wgu=wgu, wgu_t=ops.transpose(wgu), wd=wd, wd_t=ops.transpose(wd)))
+            self.layers.append(dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
+                                    wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
+                                    wgu=put(take(2 * I, H), L["wg"], L["wu"]), wd=put(take(H, I), L["wd"])))
+        self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
+        self.build_transposes()
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
         if inv is None:
@@ -117,6 +141,13 @@ class LlamaLRP:
         self.sin = (emb.sin() * att).to(dtype).to(torch.float32).to(dev).contiguous()
         self.max_seq = max_seq
         torch.cuda.synchronize(dev)
+
+    def build_transposes(self):
+        """W^T ([in, out]) copies for the dgrad GEMMs, made locally from the forward layouts (after a weight broadcast too)"""
+        for L in self.layers:
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                L[k + "_t"] = ops.transpose(L[k])
+        self.lm_head_t = None
 
     @classmethod
     def from_hf(cls, model, **kw):
