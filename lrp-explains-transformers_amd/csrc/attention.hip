@@ -18,7 +18,6 @@
 // next tile (global loads are issued before the MFMAs of the current tile).
 #include "common.hpp"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace {
 
@@ -585,7 +584,7 @@ LRP_DEVICE void glds_stats(const float* base, int r0, int S, char* lds, int lane
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + r), (lds_ptr_t)lds, 4, 0, 0);
 }
 
-template <typename T, int D, bool EXPL, bool HOIST = false>
+template <typename T, int D, bool EXPL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ qt,
     const T* __restrict__ gho, const T* __restrict__ ghot, const float* __restrict__ lse, const float* __restrict__ Dd,
@@ -664,31 +663,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_v2_kernel(
         f32x4 pp[NC16];
         // interior tiles (every query of the tile sees every key of the wave) skip the per-element mask predicate
         const bool tile_masked = (qt0 + CT > S) || (causal && qt0 < kw_max) || (window > 0) || (row_lo != nullptr);
-        auto elems = [&](auto masked_c) {
-            constexpr bool MASKED = decltype(masked_c)::value;
-#pragma unroll
-            for (int t = 0; t < NC16; ++t) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + t * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s_raw = st[t][r];
-                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(l4[r] * LRP_LOG2E)));
-                    if constexpr (MASKED) {
-                        const int qi = qt0 + t * 16 + g * 4 + r;
-                        int ivlo = 0, ivhi = S;
-                        if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-                        if (!((qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi))) p = 0.f;
-                    }
-                    pp[t][r] = p;
-                    if constexpr (EXPL) st[t][r] = lrp_ds2<true>(s_raw, p, dp[t][r], d4[r], scale, eps_mask, eps_qk);
-                    else st[t][r] = p * (dp[t][r] - d4[r]);      // * scale/2 folded into the dK store
-                }
-            }
-        };
-        if constexpr (HOIST) {         // ONE wave-uniform branch per tile step (dev knob LRP_ATTN_HOIST=1)
-            if (tile_masked) elems(std::true_type{}); else elems(std::false_type{});
-        } else {
+        {
 #pragma unroll
         for (int t = 0; t < NC16; ++t) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + t * 16 + g * 4);
@@ -869,11 +844,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
 }
 
 // ---- v2 dQ: 8 waves x (16*QS) queries, K + V + K^T tiles, two LDS stages ---------------------------------
-// QS = 2 (dev knob LRP_ATTN_DQ_QS=2): two 16-row sub-tiles per wave.  With 16 rows per wave every column-side fragment read
-// feeds ONE MFMA (48 ds_read_b128 : 48 MFMA per tile step and wave) and the kernel is LDS-bandwidth-bound (8 waves x 48 x 8
-// clk = 3072 clk of LDS per workgroup step vs 1536 clk of MFMA per SIMD); with two sub-tiles each fragment feeds two MFMAs
-// at the same occupancy (96 KiB of LDS allow one workgroup per CU either way; 2 waves per SIMD = 256 VGPRs).
-template <typename T, int D, bool EXPL, int QS, bool HOIST = false>
+// (16 rows per wave: every column-side fragment read feeds ONE MFMA, the kernel is LDS-bandwidth-bound -- the bf16 / d = 128
+// shapes that matter run on the 32x32x16 kernels of attention32.hip instead; this form serves fp32 and the other head dims)
+template <typename T, int D, bool EXPL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ kt,
     const T* __restrict__ gho, const float* __restrict__ lse, const float* __restrict__ Dd, T* __restrict__ dq,
@@ -883,6 +856,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
     typedef AT<T> A;
     typedef typename Mma16<T>::frag frag_t;
     constexpr int SZ = A::SZ, CT = A::CT, NC16 = A::NC16, NDC = D * SZ / 64, ND16 = D / 16;
+    constexpr int QS = 1;                                  // 16-row sub-tiles per wave
     constexpr int NW = 8, BQ = NW * 16 * QS;
     constexpr int TILE = 128 * D, STAGE = 3 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -957,24 +931,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_v2_kernel(
         for (int s = 0; s < QS; ++s) {
             // interior tiles (every key visible to every row of the sub-tile) skip the per-element mask predicate altogether
             const bool tile_masked = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw + s * 16) || (window > 0) || (row_lo != nullptr);
-            auto elems = [&](auto masked_c) {
-                constexpr bool MASKED = decltype(masked_c)::value;
-#pragma unroll
-                for (int t = 0; t < NC16; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float s_raw = st[s][t][r];
-                        float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2_q[s]));
-                        if constexpr (MASKED) {
-                            if (!visible(qi[s], kt0 + t * 16 + g * 4 + r, S, causal, window, ivlo[s], ivhi[s])) p = 0.f;
-                        }
-                        if constexpr (EXPL) st[s][t][r] = lrp_ds2<true>(s_raw, p, dp[s][t][r], D_q[s], scale, eps_mask, eps_qk);
-                        else st[s][t][r] = p * (dp[s][t][r] - D_q[s]);        // * scale/2 folded into the final store
-                    }
-            };
-            if constexpr (HOIST) {     // ONE wave-uniform branch per tile step instead of one per element (dev knob LRP_ATTN_HOIST=1)
-                if (tile_masked) elems(std::true_type{}); else elems(std::false_type{});
-            } else {
+            {
 #pragma unroll
                 for (int t = 0; t < NC16; ++t)
 #pragma unroll
@@ -1121,8 +1078,7 @@ static int attn_fwd_t(const void* q, const void* k, const void* vt, void* o, flo
                       int d, int64_t ldq, int64_t ldk, int64_t ldt, int64_t ldo, float scale, int causal, int window,
                       int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
-    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
-    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
+    if ((ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
         ATT_DISPATCH_D(T, d, {
             if constexpr (DD <= 128) {
                 const size_t lds = 2 * (2 * (size_t)128 * DD);
@@ -1194,33 +1150,19 @@ static int attn_dq_t(const void* q, const void* k, const void* v, const void* kt
                      int64_t ldt, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
                      int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
-    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
-    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
+    if ((ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128) {
         ATT_DISPATCH_D(T, d, {
             if constexpr (DD <= 128) {
                 const size_t lds = 2 * (3 * (size_t)128 * DD);
-                // LRP_ATTN_DQ_QS=2: two 16-row sub-tiles per wave (dev knob, efficient mode only)
-                static const int qs2 = [] { const char* e = getenv("LRP_ATTN_DQ_QS"); return e ? atoi(e) : 1; }();
-                static const int hoist = [] { const char* e = getenv("LRP_ATTN_HOIST"); return e ? atoi(e) : 0; }();
+                dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
                 if (eps_mask != 0.f || eps_qk != 0.f) {
-                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
-                    auto kern = attn_bwd_dq_v2_kernel<T, DD, true, 1>;
-                    set_lds(kern, lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
-                                       (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
-                                       eps_qk, causal, window, B, q_begin, row_lo, row_hi);
-                } else if (qs2 == 2 || hoist) {
-                    const int bq = qs2 == 2 ? 256 : 128;
-                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + bq - 1) / bq)));
-                    auto kern = qs2 == 2 ? (hoist ? attn_bwd_dq_v2_kernel<T, DD, false, 2, true> : attn_bwd_dq_v2_kernel<T, DD, false, 2, false>)
-                                         : attn_bwd_dq_v2_kernel<T, DD, false, 1, true>;
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, true>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
                                        eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
-                    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 127) / 128)));
-                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false, 1>;
+                    auto kern = attn_bwd_dq_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)kt,
                                        (const T*)gho, lse, D, (T*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldt, ldg, lddq, scale, eps_mask,
@@ -1268,8 +1210,7 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                       int64_t ldk, int64_t ldv, int64_t ldt, int64_t ldg, int64_t lddk, int64_t lddv, float scale,
                       float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi, hipStream_t st) {
     constexpr int SZ = sizeof(T), CT = 128 / SZ;
-    static const int force_v1 = [] { const char* e = getenv("LRP_ATTN_V1"); return e ? atoi(e) : 0; }();
-    if (!force_v1 && (ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128 && S >= 1) {
+    if ((ldt % CT) == 0 && ((size_t)d * SZ >= 64) && d <= 128 && S >= 1) {
         ATT_DISPATCH_D(T, d, {
             if constexpr (DD <= 128) {
                 const size_t lds = 2 * (4 * (size_t)128 * DD + 512);
@@ -1281,8 +1222,7 @@ static int attn_dkv_t(const void* q, const void* k, const void* v, const void* q
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,
                                        ldg, lddk, lddv, scale, eps_mask, eps_qk, causal, window, B, q_begin, row_lo, row_hi);
                 } else {
-                    static const int hoist = [] { const char* e = getenv("LRP_ATTN_HOIST"); return e ? atoi(e) : 0; }();
-                    auto kern = hoist ? attn_bwd_dkv_v2_kernel<T, DD, false, true> : attn_bwd_dkv_v2_kernel<T, DD, false, false>;
+                    auto kern = attn_bwd_dkv_v2_kernel<T, DD, false>;
                     set_lds(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const T*)q, (const T*)k, (const T*)v, (const T*)qt,
                                        (const T*)gho, (const T*)ghot, lse, D, (T*)dk, (T*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldt,

@@ -5,7 +5,7 @@
 // the 32-row fragment read (lane = row l & 31, 16-byte chunk 2 k16 + (l >> 5)) is conflict-free for every ds_read_b128
 // lane group (8 even + 8 odd rows per group, the two parities sit in the two 128-byte halves of a 256-byte bank row).
 // Operands are swapped in the MFMA (a = B rows, b = A rows) so that a lane owns 4 consecutive output columns.
-#include "common.hpp"
+#include "../common.hpp"
 
 namespace gemm32 {
 
@@ -77,21 +77,27 @@ __global__ __launch_bounds__(1024, 4) void gemm_nt_m32_kernel(
     stage(0, 0);
     __syncthreads();
     int cur = 0;
+    // fragments double-buffered in registers: the reads of K sub-step k16+1 are issued before the MFMAs of sub-step k16
+    bf16x8 fa[2][2], fb[2][2];
+    auto rd = [&](int buf, int k16, int slot) {
+        const char* sa = smem + buf * STAGE + offA;
+        const char* sb = smem + buf * STAGE + offB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * KB + fo[k16]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * KB + fo[k16]);
+    };
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-        const char* sa = smem + cur * STAGE + offA;
-        const char* sb = smem + cur * STAGE + offB;
+        rd(cur, 0, 0);
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * KB + fo[k16]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * KB + fo[k16]);
+            if (k16 < 3) rd(cur, k16 + 1, (k16 + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fb[k16 & 1][j], fa[k16 & 1][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         cur ^= 1;

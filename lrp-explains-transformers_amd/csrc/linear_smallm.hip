@@ -12,7 +12,6 @@
 // <= 256 slabs (L2-resident, just written) and applies the optional (*) x.
 // Algorithmic HBM bytes = sizeof(T)*(N*K + 2*M*K + M*N): W is read exactly once.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -148,8 +147,7 @@ __global__ void smallm_reduce_kernel(const float* __restrict__ ws, const T* __re
 }
 
 inline int smallm_blocks(int N) {
-    // LRP_SMALLM_BLOCKS overrides the cap (dev knob); default 256 = one workgroup per CU (measured: 512 / 1024 are 30 % / 90 % slower -- per-workgroup fold + slab cost)
-    static const int cap = [] { const char* e = getenv("LRP_SMALLM_BLOCKS"); return e ? atoi(e) : 256; }();
+    constexpr int cap = 256;     // one workgroup per CU (measured: 512 / 1024 are 30 % / 90 % slower -- per-workgroup fold + slab cost)
     int nb = (N + 15) / 16;
     return nb > cap ? cap : (nb < 1 ? 1 : nb);
 }
