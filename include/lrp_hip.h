@@ -83,6 +83,23 @@ int lrp_linear_eps_smallm(const void* x, const void* W, const void* bias, const 
                           float* out, float* z_out, float* workspace, int M, int N, int K,
                           float eps, int relevance_in, int relevance_out, int dtype, void* stream);
 
+/* Small-M Linear (M <= 16) as W-streaming kernels -- what the engine runs for its one-row-per-prompt top layer, the
+ * last-token LM head and dense logit seeds, and lxt_amd.explicit.functional.linear_epsilon for M <= 16.  W [N,K] row-major is
+ * read ONCE per call and no W^T copy is needed in either direction (HBM-bound: roofline 8 TB/s).
+ *   fwd  : z[M,N] = x[M,K] W^T (+ bias)                 z dtype = out_dtype (dtype or LRP_F32), row strides ldx / ldz
+ *   dgrad: s = g                       (z == NULL)
+ *          s = g (*) z/(z+eps)          (z given, relevance_in == 0; eps == 0 -> g)
+ *          s = g / (z+eps)              (z given, relevance_in == 1: g is the relevance R_out)
+ *          out[M,K] = s W  [ (*) x if relevance_out ]   out dtype = out_dtype, contiguous [M,K]; g/z row strides ldg / ldz
+ *   workspace: fp32 scratch of lrp_linear_smallm_ws(M,N,K,dtype) floats (k-slab / row-range partials, no atomics).
+ * ref: lxt/explicit/functional.py:345-364 (forward :351, backward :355-364). */
+int64_t lrp_linear_smallm_ws(int M, int N, int K, int dtype);
+int lrp_linear_smallm_fwd(const void* x, const void* W, const void* bias, void* z, float* workspace,
+                          int M, int N, int K, int64_t ldx, int64_t ldz, int dtype, int out_dtype, void* stream);
+int lrp_linear_smallm_dgrad(const void* g, const void* z, const void* W, const void* x, void* out,
+                            float* workspace, int M, int N, int K, int64_t ldg, int64_t ldz, float eps,
+                            int relevance_in, int relevance_out, int dtype, int out_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K2/K6  RMSNorm identity rule + residual add.
  *   ref: lxt/efficient/patches.py:111-123, lxt/explicit/functional.py:481-495 (norm),

@@ -193,7 +193,254 @@ int launch_k(int kch, const void* x, const void* W, const void* bias, const void
     return LRP_ESHAPE;
 }
 
+
+// =====================================================================================================================
+// Small-M forward and dgrad as pure W-streaming kernels (M <= 16).  One WAVE per workgroup owns a [rows x 512 columns]
+// panel of W (1 KiB per row and load instruction, fully coalesced), 16 rows in flight per wave, nothing shared: no LDS, no
+// barrier.  The 2-D decomposition (k-slabs x row ranges) keeps the cross-workgroup reduction small in BOTH directions:
+//   dgrad   c[m,k] = sum_n s[m,n] W[n,k] : lane-local accumulators for the lane's 8 columns; row ranges are summed from
+//           fp32 slabs [n_ranges][M][K] by a second tiny kernel (s = g z/(z+eps) or r/(z+eps) is formed on the fly from the
+//           stashed z -- the eps-rule's "redistribution" half with W read exactly once and NO W^T copy);
+//   forward z[m,n]  = sum_k x[m,k] W[n,k] : per-row dot over the lane's columns + wave reduction; k-slab partials
+//           [k_slabs][M][N] fp32 are summed (+ bias, cast) by the same kind of tiny kernel.
+// Algorithmic HBM bytes: sizeof(T) * N * K (+ the M-row operands).  ref: lxt/explicit/functional.py:345-364.
+// =====================================================================================================================
+constexpr int SM_R = 16;            // rows of W in flight per wave
+
+template <typename T, int MM, bool RATIO>
+__global__ __launch_bounds__(64) void smallm_dgrad_kernel(
+    const T* __restrict__ W, const T* __restrict__ g, const T* __restrict__ z, float* __restrict__ slab, int M, int N, int K,
+    int64_t ldg, int64_t ldz, int rows_per, float eps, int rel_in) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x;
+    const int k = (blockIdx.x * 64 + lane) * EPC;
+    const bool kok = k < K;
+    const int n0 = blockIdx.y * rows_per, n1 = min(N, n0 + rows_per);
+    float acc[MM][EPC];
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[m][e] = 0.f;
+    for (int nb = n0; nb < n1; nb += SM_R) {
+        Vec16<T> w[SM_R];
+#pragma unroll
+        for (int r = 0; r < SM_R; ++r) {
+            const int n = nb + r;
+            if (kok && n < n1) w[r] = ld16(W + (int64_t)n * K + k);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) w[r].set(e, 0.f);
+            }
+        }
+        // s[m][n] of the batch: value v = r * MM + m is computed by lane (v & 63) of vector (v >> 6) from ONE load of g (and z)
+        // each, then handed to every lane through v_readlane (an SGPR operand of the FMAs below)
+        constexpr int NV = (SM_R * MM + 63) / 64;
+        float svec[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = j * 64 + lane, r = v / MM, m = v % MM, n = nb + r;
+            float sv = 0.f;
+            if (v < SM_R * MM && m < M && n < n1) {
+                const float gv = to_f32(g[(int64_t)m * ldg + n]);
+                if constexpr (RATIO) {
+                    const float zv = to_f32(z[(int64_t)m * ldz + n]);
+                    sv = rel_in ? gv / (zv + eps) : gv * eps_ratio(zv, 1.f, eps);
+                } else sv = gv;
+            }
+            svec[j] = sv;
+        }
+#pragma unroll
+        for (int r = 0; r < SM_R; ++r)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int v = r * MM + m;
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, svec[v >> 6]), v & 63));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[m][e] += sv * w[r].get(e);
+            }
+    }
+    if (kok) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < M) {
+                float* dst = slab + ((int64_t)blockIdx.y * M + m) * K + k;
+#pragma unroll
+                for (int e4 = 0; e4 < EPC / 4; ++e4)
+                    *reinterpret_cast<f32x4*>(dst + 4 * e4) = f32x4{acc[m][4 * e4], acc[m][4 * e4 + 1], acc[m][4 * e4 + 2], acc[m][4 * e4 + 3]};
+            }
+    }
+}
+
+// out[i] = (sum_b slab[b][i]) (* x[i]) for i < MK, out dtype TO
+template <typename T, typename TO>
+__global__ void smallm_slab_sum_kernel(const float* __restrict__ slab, const T* __restrict__ x, TO* __restrict__ out, int nslab,
+                                       int64_t MK, int rel_out) {
+    __shared__ f32x4 part[16][16];
+    const int ql = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)blockIdx.x * 16 + ql) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < MK) {
+#pragma unroll 4
+        for (int b = sg; b < nslab; b += 16) s += *reinterpret_cast<const f32x4*>(slab + (int64_t)b * MK + i);
+    }
+    part[sg][ql] = s;
+    __syncthreads();
+    if (sg == 0 && i < MK) {
+#pragma unroll
+        for (int kk = 1; kk < 16; ++kk) s += part[kk][ql];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[i + e] = from_f32<TO>(rel_out ? s[e] * to_f32(x[i + e]) : s[e]);
+    }
+}
+
+template <typename T, int MM>
+__global__ __launch_bounds__(64) void smallm_fwd_kernel(const T* __restrict__ W, const T* __restrict__ x, float* __restrict__ part,
+                                                        int M, int N, int K, int64_t ldx, int rows_per) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x;
+    const int k = (blockIdx.x * 64 + lane) * EPC;
+    const bool kok = k < K;
+    const int n0 = blockIdx.y * rows_per, n1 = min(N, n0 + rows_per);
+    float xv[MM][EPC];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        Vec16<T> t;
+        if (kok && m < M) t = ld16(x + (int64_t)m * ldx + k);
+        else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) t.set(e, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) xv[m][e] = t.get(e);
+    }
+    for (int nb = n0; nb < n1; nb += SM_R) {
+        Vec16<T> w[SM_R];
+#pragma unroll
+        for (int r = 0; r < SM_R; ++r) {
+            const int n = nb + r;
+            if (kok && n < n1) w[r] = ld16(W + (int64_t)n * K + k);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) w[r].set(e, 0.f);
+            }
+        }
+        // partial dots; the 16 x MM values of a batch are reduced across the wave and lane (r*MM + m) keeps value (r, m)
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < SM_R; ++r)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d += w[r].get(e) * xv[m][e];
+                d = wave_sum(d);
+                if (lane == ((r * MM + m) & 63)) mine = d;
+                if constexpr (SM_R * MM > 64) {                      // more values than lanes: store each 64-value group as it completes
+                    if (((r * MM + m) & 63) == 63 || (r == SM_R - 1 && m == MM - 1)) {
+                        const int v = ((r * MM + m) & ~63) + lane, rr = v / MM, mm = v % MM;
+                        if (v <= r * MM + m && mm < M && nb + rr < n1) part[((int64_t)blockIdx.x * M + mm) * N + nb + rr] = mine;
+                    }
+                }
+            }
+        if constexpr (SM_R * MM <= 64) {
+            const int rr = lane / MM, mm = lane % MM;
+            if (lane < SM_R * MM && mm < M && nb + rr < n1) part[((int64_t)blockIdx.x * M + mm) * N + nb + rr] = mine;
+        }
+    }
+}
+
+// z[m,n] = sum_ks part[ks][m][n] + bias[n]
+template <typename T, typename TO>
+__global__ void smallm_fwd_sum_kernel(const float* __restrict__ part, const T* __restrict__ bias, TO* __restrict__ z, int nks, int M,
+                                      int N, int64_t ldz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = bias ? to_f32(bias[n]) : 0.f;
+    for (int b = 0; b < nks; ++b) s += part[(int64_t)b * M * N + i];
+    z[(int64_t)m * ldz + n] = from_f32<TO>(s);
+}
+
+inline int smallm_row_ranges(int N, int kslabs) {
+    // ~1024 one-wave workgroups on the chip (4 per CU), at least 2 batches of 16 rows each
+    int nr = (1024 + kslabs - 1) / kslabs;
+    const int max_nr = (N + 2 * SM_R - 1) / (2 * SM_R);
+    if (nr > max_nr) nr = max_nr;
+    return nr < 1 ? 1 : nr;
+}
+
+template <typename T, typename TO, int MM>
+int launch_dgrad(const void* W, const void* g, const void* z, const void* x, void* out, float* ws, int M, int N, int K, int64_t ldg,
+                 int64_t ldz, float eps, int rel_in, int rel_out, hipStream_t st) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int ks = (K + 64 * EPC - 1) / (64 * EPC), nr = smallm_row_ranges(N, ks);
+    const int rows_per = ((N + nr - 1) / nr + SM_R - 1) / SM_R * SM_R;
+    const int nr2 = (N + rows_per - 1) / rows_per;
+    dim3 grid(ks, nr2);
+    if (z) hipLaunchKernelGGL((smallm_dgrad_kernel<T, MM, true>), grid, dim3(64), 0, st, (const T*)W, (const T*)g, (const T*)z, ws, M, N, K, ldg, ldz, rows_per, eps, rel_in);
+    else hipLaunchKernelGGL((smallm_dgrad_kernel<T, MM, false>), grid, dim3(64), 0, st, (const T*)W, (const T*)g, (const T*)nullptr, ws, M, N, K, ldg, ldz, rows_per, eps, rel_in);
+    const int64_t MK = (int64_t)M * K;
+    hipLaunchKernelGGL((smallm_slab_sum_kernel<T, TO>), dim3((unsigned)((MK + 63) / 64)), dim3(256), 0, st, ws, (const T*)x, (TO*)out, nr2, MK, (x && rel_out) ? 1 : 0);
+    return lrp_check_launch();
+}
+
+template <typename T, typename TO, int MM>
+int launch_fwd(const void* W, const void* x, const void* bias, void* z, float* ws, int M, int N, int K, int64_t ldx, int64_t ldz,
+               hipStream_t st) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int ks = (K + 64 * EPC - 1) / (64 * EPC), nr = smallm_row_ranges(N, ks);
+    const int rows_per = ((N + nr - 1) / nr + SM_R - 1) / SM_R * SM_R;
+    const int nr2 = (N + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL((smallm_fwd_kernel<T, MM>), dim3(ks, nr2), dim3(64), 0, st, (const T*)W, (const T*)x, ws, M, N, K, ldx, rows_per);
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL((smallm_fwd_sum_kernel<T, TO>), dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, ws, (const T*)bias, (TO*)z, ks, M, N, ldz);
+    return lrp_check_launch();
+}
+
+#define SMALLM_MM(M_, CALL)                      \
+    if (M_ <= 1) { constexpr int MM = 1; CALL }  \
+    else if (M_ <= 2) { constexpr int MM = 2; CALL } \
+    else if (M_ <= 4) { constexpr int MM = 4; CALL } \
+    else if (M_ <= 8) { constexpr int MM = 8; CALL } \
+    else { constexpr int MM = 16; CALL }
+
 }  // namespace
+
+extern "C" int64_t lrp_linear_smallm_ws(int M, int N, int K, int dtype) {
+    const int epc = dtype == LRP_F32 ? 4 : 8;
+    const int ks = (K + 64 * epc - 1) / (64 * epc);
+    const int nr = smallm_row_ranges(N, ks);
+    const int64_t dgrad = (int64_t)nr * M * K, fwd = (int64_t)ks * M * N;
+    return dgrad > fwd ? dgrad : fwd;
+}
+
+extern "C" int lrp_linear_smallm_fwd(const void* x, const void* W, const void* bias, void* z, float* workspace, int M, int N, int K,
+                                     int64_t ldx, int64_t ldz, int dtype, int out_dtype, void* stream) {
+    if (!x || !W || !z || !workspace || M < 1 || N < 1 || K < 1) return LRP_EINVAL;
+    if ((dtype != LRP_F32 && dtype != LRP_BF16) || (out_dtype != dtype && out_dtype != LRP_F32)) return LRP_EINVAL;
+    const int epc = dtype == LRP_F32 ? 4 : 8;
+    if ((K % epc) || (ldx % epc) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(x) & 15)) return LRP_EALIGN;
+    if (M > 16) return LRP_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LRP_F32) { SMALLM_MM(M, return (launch_fwd<float, float, MM>(W, x, bias, z, workspace, M, N, K, ldx, ldz, st));) }
+    if (out_dtype == LRP_F32) { SMALLM_MM(M, return (launch_fwd<bf16_t, float, MM>(W, x, bias, z, workspace, M, N, K, ldx, ldz, st));) }
+    SMALLM_MM(M, return (launch_fwd<bf16_t, bf16_t, MM>(W, x, bias, z, workspace, M, N, K, ldx, ldz, st));)
+}
+
+extern "C" int lrp_linear_smallm_dgrad(const void* g, const void* z, const void* W, const void* x, void* out, float* workspace,
+                                       int M, int N, int K, int64_t ldg, int64_t ldz, float eps, int relevance_in, int relevance_out,
+                                       int dtype, int out_dtype, void* stream) {
+    if (!g || !W || !out || !workspace || M < 1 || N < 1 || K < 1) return LRP_EINVAL;
+    if ((dtype != LRP_F32 && dtype != LRP_BF16) || (out_dtype != dtype && out_dtype != LRP_F32)) return LRP_EINVAL;
+    const int epc = dtype == LRP_F32 ? 4 : 8;
+    if ((K % epc) || (reinterpret_cast<uintptr_t>(W) & 15)) return LRP_EALIGN;
+    if (M > 16) return LRP_ESHAPE;
+    if (relevance_out && !x) return LRP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LRP_F32) { SMALLM_MM(M, return (launch_dgrad<float, float, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));) }
+    if (out_dtype == LRP_F32) { SMALLM_MM(M, return (launch_dgrad<bf16_t, float, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));) }
+    SMALLM_MM(M, return (launch_dgrad<bf16_t, bf16_t, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));)
+}
 
 extern "C" int64_t lrp_linear_eps_smallm_ws(int M, int N, int K) { return (int64_t)smallm_blocks(N) * M * K; }
 

@@ -142,6 +142,18 @@ class LlamaLRP:
         self.max_seq = max_seq
         torch.cuda.synchronize(dev)
 
+    # rows-per-call <= ops.SMALLM_MAX (the one-row-per-prompt top layer, the last-token head): W-streaming kernels, W read
+    # once from its stored layout in both directions; above that the MFMA GEMM (forward: W, backward: the W^T copy)
+    def _lin_fwd(self, x, W, out):
+        if x.shape[0] <= ops.SMALLM_MAX:
+            return ops.linear_smallm_fwd(x, W, out=out)
+        return ops.gemm_nt_2d(x, W, out)
+
+    def _lin_bwd(self, A, W, W_t, out):
+        if A.shape[0] <= ops.SMALLM_MAX:
+            return ops.linear_smallm_dgrad(A, W, out=out)
+        return ops.gemm_nt_2d(A, W_t, out)
+
     def build_transposes(self):
         """W^T ([in, out]) copies for the dgrad GEMMs, made locally from the forward layouts (after a weight broadcast too)"""
         for L in self.layers:
@@ -193,12 +205,12 @@ class LlamaLRP:
             if top:
                 ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1, row_iv=row_iv)
                 o_l, h_l = o.index_select(0, last), st["h"].index_select(0, last)
-                a_l = ops.gemm_nt_2d(o_l, Lw["wo"], new(B, H))
+                a_l = self._lin_fwd(o_l, Lw["wo"], new(B, H))
                 h1_l = new(B, H)
                 x2_l, rstd2_l = ops.add_rmsnorm_fwd(h_l, a_l, Lw["ln2"], c["rms_eps"], hsum_out=h1_l)
-                gu_l = ops.gemm_nt_2d(x2_l, Lw["wgu"], new(B, 2 * I))
+                gu_l = self._lin_fwd(x2_l, Lw["wgu"], new(B, 2 * I))
                 m_l = ops.gated_act_fwd(gu_l[:, :I], gu_l[:, I:], new(B, I), self.act)
-                dn_l = ops.gemm_nt_2d(m_l, Lw["wd"], new(B, H))
+                dn_l = self._lin_fwd(m_l, Lw["wd"], new(B, H))
                 st.update(top=True, qkv=qkv, qkr=qkr, lse=lse, o_l=o_l, a_l=a_l, h1_l=h1_l, rstd2_l=rstd2_l, gu_l=gu_l, dn_l=dn_l)
                 stash.append(st)
                 h_prev, branch = h1_l, dn_l
@@ -220,7 +232,7 @@ class LlamaLRP:
             h1_last, dn_last = h_prev.index_select(0, last), branch.index_select(0, last)
         hL_last = new(B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h1_last, dn_last, self.norm, c["rms_eps"], hsum_out=hL_last)
-        logits = ops.gemm_nt_2d(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
+        logits = self._lin_fwd(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
         return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
 
     # ---------------------------------------------------------------------------------------------
@@ -237,15 +249,18 @@ class LlamaLRP:
             Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
         else:
             # dense seed over the last-position logits (contrastive explanations): gradient in efficient mode, relevance
-            # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm on the GEMM (W_lm^T copy made on first use: 1 GB
-            # at V = 128k, HBM is not the constraint), then the final norm's identity rule as a row scale
-            if self.lm_head_t is None:
-                self.lm_head_t = ops.transpose(self.lm_head)
+            # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm (W-streaming dgrad for B <= 16, else the GEMM on a
+            # W_lm^T copy made on first use), then the final norm's identity rule (row scale, rmsnorm_bwd_add2 without a residual)
             coef = seed.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()
             if E["lin"] != 0.0:
                 coef = ops.eps_scale(coef, fw["logits"], 1.0, E["lin"], relevance=True)
-            g_xn = ops.gemm_nt_2d(coef.to(dt), self.lm_head_t, torch.empty(B, H, device=dev, dtype=torch.float32))
-            Gh_last = (g_xn * self.norm.float()[None] * fw["rstd_f"].reshape(B, 1)).to(dt)
+            if B <= ops.SMALLM_MAX:
+                g_xn = ops.linear_smallm_dgrad(coef.to(dt), self.lm_head, out_dtype=torch.float32)
+            else:
+                if self.lm_head_t is None:
+                    self.lm_head_t = ops.transpose(self.lm_head)
+                g_xn = ops.gemm_nt_2d(coef.to(dt), self.lm_head_t, torch.empty(B, H, device=dev, dtype=torch.float32))
+            Gh_last = ops.head_norm_bwd(g_xn, self.norm, fw["rstd_f"], new(B, H))
         # add2 at h_L = h1 + dn and the eps scale of the last down_proj, still one row per prompt
         Gs_last, A_last = new(B, H), new(B, H)
         rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
@@ -265,14 +280,14 @@ class LlamaLRP:
             if st.get("top", False):
                 # ---- one row per prompt through MLP, norm/add2 and o-proj; scatter into the dense attention inputs
                 gu_l = st["gu_l"]
-                Gm = ops.gemm_nt_2d(A_last, Lw["wd_t"], new(B, I))
+                Gm = self._lin_bwd(A_last, Lw["wd"], Lw["wd_t"], new(B, I))
                 Agu = new(B, 2 * I)
                 ops.gated_act_bwd(Gm, gu_l[:, :I], gu_l[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-                Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(B, H))
+                Gx2 = self._lin_bwd(Agu, Lw["wgu"], Lw["wgu_t"], new(B, H))
                 Gs1_l, Aa_l = new(B, H), new(B, H)
                 ops.rmsnorm_bwd_add2(Gs_last, Gx2, Lw["ln2"], st["rstd2_l"], st["h1_l"], st["a_l"], Gs1_l, Aa_l, None, 0.0,
                                      E["add"], E["lin"])
-                Gof_l = ops.gemm_nt_2d(Aa_l, Lw["wo_t"], new(B, nq * d))
+                Gof_l = self._lin_bwd(Aa_l, Lw["wo"], Lw["wo_t"], new(B, nq * d))
                 Gho_l = new(B, nq * d)
                 D_l = torch.empty(B, nq, 1, device=dev, dtype=torch.float32)
                 ops.attn_bwd_prep(Gof_l, st["o_l"], Gho_l, D_l, B, 1, nq, d, E["pv"], 0.5)

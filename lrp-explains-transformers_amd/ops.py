@@ -292,6 +292,13 @@ def rmsnorm_bwd_add2(Gres, Gx, w, rstd, hsum, branch, Gs_out, A_out, rel_out=Non
     return Gs_out, A_out
 
 
+def head_norm_bwd(g_xn, w, rstd, out, w_offset=0.0):
+    """final-norm identity rule on the head rows: out = g_xn * (w + w_offset) * rstd  (g_xn fp32 or model dtype [B,H])"""
+    g = g_xn if g_xn.dtype == out.dtype else cast(g_xn, out.dtype)
+    rmsnorm_bwd_add2(None, g, w, rstd, None, None, out, None, None, w_offset, 0.0, 0.0)
+    return out
+
+
 def layernorm_fwd(x, w, b, eps):
     x = _c(x)
     H = x.shape[-1]
@@ -375,6 +382,50 @@ def linear_eps_smallm(x, W, bias, g, eps, relevance_in=False, relevance_out=True
     check(lib.lrp_linear_eps_smallm(p(_c(x)), p(_c(W)), p(bias), p(_c(g)), p(out), p(z), p(workspace), M, N, K, eps,
                                     int(relevance_in), int(relevance_out), dt(x), stream()), "lrp_linear_eps_smallm")
     return (out, z) if want_z else out
+
+
+SMALLM_MAX = 16          # rows the W-streaming small-M kernels serve (above: the MFMA GEMM)
+_SMALLM_WS = {}
+
+
+def _smallm_ws(M, N, K, ref):
+    """per-device fp32 scratch for the small-M kernels, grown on demand and reused (stream-ordered use only)"""
+    need = lib.lrp_linear_smallm_ws(M, N, K, dt(ref))
+    ws = _SMALLM_WS.get(ref.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), device=ref.device, dtype=torch.float32)
+        _SMALLM_WS[ref.device] = ws
+    return ws
+
+
+def linear_smallm_fwd(x, W, bias=None, out=None, out_dtype=None):
+    """z [M,N] = x [M,K] @ W[N,K]^T (+ bias), M <= 16, W streamed once (no MFMA tile padding to 128 rows)"""
+    M, K = x.shape
+    N = W.shape[0]
+    same(x, W)
+    odt = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=odt)
+    check(lib.lrp_linear_smallm_fwd(p(x), p(W), p(aux(bias, x, N)), p(out), p(_smallm_ws(M, N, K, x)), M, N, K, x.stride(0),
+                                    out.stride(0), dt(x), _DT[out.dtype], stream()), "lrp_linear_smallm_fwd")
+    return out
+
+
+def linear_smallm_dgrad(g, W, z=None, x=None, eps=0.0, relevance_in=False, relevance_out=False, out=None, out_dtype=None):
+    """out [M,K] = s @ W[N,K] (* x) with s = g, g*z/(z+eps) or g/(z+eps): the eps-rule backward of a Linear for M <= 16 rows
+    from the STORED weight layout (no W^T copy), W streamed once"""
+    M, N = g.shape
+    K = W.shape[1]
+    same(W, g, z, x)
+    odt = out_dtype or W.dtype
+    if out is None:
+        out = torch.empty(M, K, device=W.device, dtype=odt)
+    if x is not None and not x.is_contiguous():
+        x = x.contiguous()
+    check(lib.lrp_linear_smallm_dgrad(p(g), p(z), p(W), p(x), p(out), p(_smallm_ws(M, N, K, W)), M, N, K, g.stride(0),
+                                      z.stride(0) if z is not None else 0, eps, int(relevance_in), int(relevance_out), dt(W),
+                                      _DT[out.dtype], stream()), "lrp_linear_smallm_dgrad")
+    return out
 
 
 # -------------------------------------------------------------------------------------- attention

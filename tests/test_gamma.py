@@ -69,12 +69,12 @@ def test_gamma_composite_on_mini_vit():
 import sys, types, torch
 sys.path.insert(0, %r)
 from torch import nn
-from lxt_amd.efficient import monkey_patch
+from lxt_amd.efficient import monkey_patch, adopt
 from lxt_amd.efficient.models.vit_torch import cp_LRP
 from lxt_amd.efficient.gamma import GammaComposite
 from tests.golden.hf_models import build_mini_vit
 monkey_patch(types.ModuleType("mini_vit"), cp_LRP)
-model = build_mini_vit().cuda()
+model = adopt(build_mini_vit().cuda())          # plain torch.nn model: its Linear / LayerNorm / Conv2d join the HIP path
 x0 = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(32)).cuda()
 def explain():
     x = x0.clone().requires_grad_()

@@ -108,6 +108,14 @@ def test_linear_eps_c1_golden(ops):
                 R1, z1 = ops.linear_eps_smallm(x, W, b, g, eps, relevance_in=False, relevance_out=True, want_z=True)
                 assert nmax(z1, z) < 1e-5
                 assert nmax(R1, fx[f"lin_{tag}_{eps_tag}_Rin"]) < 5e-5, (tag, eps_tag)
+            if x.shape[0] <= 16:  # W-streaming forward + dgrad pair (what linear_epsilon / the engine's top rows run)
+                z2 = ops.linear_smallm_fwd(x, W, b)
+                assert nmax(z2, z) < 1e-5
+                # (the relevance R_out = z (*) g was formed from the GEMM's z: divide by THAT z -- z/(z2+eps) is O(1)-sensitive
+                # to the last-bit differences between two fp32 evaluations wherever |z| ~ eps)
+                R2 = ops.linear_smallm_dgrad(R_out, W, z=z, x=x, eps=eps, relevance_in=True, relevance_out=True, out_dtype=torch.float32)
+                R3 = ops.linear_smallm_dgrad(g, W, z=z2, x=x, eps=eps, relevance_out=True, out_dtype=torch.float32)
+                assert nmax(R2, fx[f"lin_{tag}_{eps_tag}_Rin"]) < 2e-5 and nmax(R3, fx[f"lin_{tag}_{eps_tag}_Rin"]) < 2e-5, (tag, eps_tag)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -126,6 +134,36 @@ def test_linear_eps_smallm(ops, dtype, M, N, K):
     ref = ((f64(g) * z / (z + eps)) @ f64(W)) * f64(x)
     out = ops.linear_eps_smallm(x, W, None, g, eps)
     assert nmax(out, ref) < (5e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (3, 1000, 520), (4, 14336, 4096), (16, 4096, 14336), (8, 300, 4096), (5, 33, 72),
+                                   (2, 128256, 1024)])
+def test_linear_smallm_fwd_dgrad(ops, dtype, M, N, K):
+    """the W-streaming small-M kernels (M <= 16, any N, K a multiple of 16 bytes) against fp64: forward with bias, dgrad in its
+    three input forms (plain gradient, gradient x z/(z+eps), relevance / (z+eps)), both output forms, strided g / z rows"""
+    e = 16 // torch.empty(0, dtype=dtype).element_size()
+    K = -(-K // e) * e
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    x, W = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=dtype, seed=4)
+    z = ops.linear_smallm_fwd(x, W, b)
+    zf = ops.linear_smallm_fwd(x, W, None, out_dtype=torch.float32)
+    zref = f64(x) @ f64(W).T
+    assert nmax(z, zref + f64(b)) < tol and nmax(zf, zref) < (2e-5 if dtype == torch.float32 else 2e-3)
+    assert z.dtype == dtype and zf.dtype == torch.float32
+    g2 = rnd(M, 2 * N, dtype=dtype, seed=3)
+    g = g2[:, N:] if N % e == 0 else g2[:, N:].contiguous()        # a strided view where the alignment allows it
+    zs = z.double()
+    for eps in (0.0, 1e-6):
+        ref_plain = f64(g) @ f64(W)
+        assert nmax(ops.linear_smallm_dgrad(g, W), ref_plain) < tol
+        ratio = zs / (zs + eps) if eps else 1.0
+        out = ops.linear_smallm_dgrad(g, W, z=z, eps=eps, out_dtype=torch.float32)
+        assert out.dtype == torch.float32 and nmax(out, (f64(g) * ratio) @ f64(W)) < tol
+        if eps:
+            outR = ops.linear_smallm_dgrad(g, W, z=z, x=x, eps=eps, relevance_in=True, relevance_out=True, out_dtype=torch.float32)
+            assert nmax(outR, ((f64(g) / (zs + eps)) @ f64(W)) * f64(x)) < tol
 
 
 # ----------------------------------------------------------------------------------- element-wise

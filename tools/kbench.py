@@ -117,6 +117,23 @@ def bench_smallm(dtype, M, N, K):
         print("linear_eps_smallm", M, N, K, "->", e)
 
 
+def bench_smallm_stream(dtype, M, N, K):
+    """W-streaming forward and dgrad (lrp_linear_smallm_fwd / _dgrad): algorithmic bytes = sizeof * N * K (+ M-row operands)"""
+    x, W = torch.randn(M, K, device="cuda").to(dtype), (torch.randn(N, K, device="cuda") * K ** -0.5).to(dtype)
+    g = torch.randn(M, N, device="cuda").to(dtype)
+    es = x.element_size()
+    z = ops.linear_smallm_fwd(x, W)
+    t = timeit(lambda: ops.linear_smallm_fwd(x, W, out=z))
+    print(f"smallm fwd   {str(dtype)[6:]} M={M:2d} N={N} K={K}: {t*1e6:8.1f} us  {es*(N*K+M*K+M*N)/t/1e9:7.1f} GB/s algorithmic", flush=True)
+    out = ops.linear_smallm_dgrad(g, W, z=z, eps=1e-6)
+    t = timeit(lambda: ops.linear_smallm_dgrad(g, W, z=z, eps=1e-6, out=out))
+    print(f"smallm dgrad {str(dtype)[6:]} M={M:2d} N={N} K={K}: {t*1e6:8.1f} us  {es*(N*K+M*K+2*M*N)/t/1e9:7.1f} GB/s algorithmic", flush=True)
+    if M <= 4 and K <= 4096:
+        bench_smallm(dtype, M, N, K)
+    tt = timeit(lambda: torch.matmul(x, W.T))
+    print(f"   (torch.matmul forward, same shape: {tt*1e6:8.1f} us  {es*N*K/tt/1e9:7.1f} GB/s)", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="gemm,attn,row,smallm")
@@ -142,6 +159,13 @@ if __name__ == "__main__":
         bench_attn(torch.float32, 1, 2048, 32, 8, 128)
     if "row" in a.what:
         bench_row(torch.bfloat16, 2048, 4096, 14336)
+    if "stream" in a.what:
+        for M in (1, 2, 4, 8, 16):
+            bench_smallm_stream(torch.bfloat16, M, 14336, 4096)
+        for M in (1, 4, 16):
+            bench_smallm_stream(torch.bfloat16, M, 4096, 14336)
+        bench_smallm_stream(torch.bfloat16, 4, 128256, 4096)
+        bench_smallm_stream(torch.float32, 1, 768, 768)
     if "smallm" in a.what:
         bench_smallm(torch.float32, 1, 768, 768)
         bench_smallm(torch.float32, 1, 4096, 4096)
