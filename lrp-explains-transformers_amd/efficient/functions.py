@@ -76,16 +76,25 @@ class LinearFn(Function):
     def forward(ctx, x, weight, bias, weight_t):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        z = ops.gemm_nt(x2, weight, bias)
-        ctx.save_for_backward(weight_t)
+        ctx.small = ops.smallm_ok(x2.shape[0], weight, x2 if x2.is_contiguous() else None) and x2.is_contiguous()
+        if ctx.small:       # <= 16 rows (e.g. a last-token head): W-streaming kernels, no W^T needed
+            z = ops.linear_smallm_fwd(x2, weight, bias)
+            ctx.save_for_backward(weight)
+        else:
+            z = ops.gemm_nt(x2, weight, bias)
+            ctx.save_for_backward(weight_t if weight_t is not None else ops.weight_t(weight))
         return z.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, gz):
-        (weight_t,) = ctx.saved_tensors
+        (w,) = ctx.saved_tensors
         shp = gz.shape
-        gx = ops.gemm_nt(gz.reshape(-1, shp[-1]), weight_t)
-        return gx.view(*shp[:-1], weight_t.shape[0]), None, None, None
+        g2 = gz.reshape(-1, shp[-1])
+        if ctx.small:
+            gx = ops.linear_smallm_dgrad(g2.contiguous(), w)
+            return gx.view(*shp[:-1], w.shape[1]), None, None, None
+        gx = ops.gemm_nt(g2, w)
+        return gx.view(*shp[:-1], w.shape[0]), None, None, None
 
 
 def _kernel_head_dim(d, dtype):

@@ -137,7 +137,10 @@ def linear_forward(self, x):
         return self.original_forward(x)
     _need_cuda(x, "linear_forward")
     wd = w.detach()
-    return LinearFn.apply(x, wd, self.bias.detach() if self.bias is not None else None, _weight_t(self, wd))
+    from .. import ops
+    rows = x.numel() // x.shape[-1] if x.numel() else 0
+    wt = None if ops.smallm_ok(rows, wd) else _weight_t(self, wd)         # <= 16 rows: W-streaming kernels, no W^T copy at all
+    return LinearFn.apply(x, wd, self.bias.detach() if self.bias is not None else None, wt)
 
 
 def conv1d_forward(self, x):

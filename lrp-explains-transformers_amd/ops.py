@@ -398,6 +398,17 @@ def _smallm_ws(M, N, K, ref):
     return ws
 
 
+def smallm_ok(M, W, x=None):
+    """can the W-streaming small-M kernels serve this call?  (M <= 16 rows, W contiguous [N,K] with K a multiple of 16 bytes,
+    16-byte aligned operands -- anything else goes to the GEMM path, which pads)"""
+    e = epc(W)
+    ok = (0 < M <= SMALLM_MAX and W.dim() == 2 and W.is_contiguous() and W.shape[1] % e == 0 and W.data_ptr() % 16 == 0
+          and W.dtype in _DT)
+    if ok and x is not None:
+        ok = x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % e == 0 and x.data_ptr() % 16 == 0 and x.dtype == W.dtype
+    return ok
+
+
 def linear_smallm_fwd(x, W, bias=None, out=None, out_dtype=None):
     """z [M,N] = x [M,K] @ W[N,K]^T (+ bias), M <= 16, W streamed once (no MFMA tile padding to 128 rows)"""
     M, K = x.shape
