@@ -54,7 +54,7 @@ def cpu_baseline(cfg, S, budget_s=30.0):
     cores; extrapolate to the full depth.  Bounded: a single timed pass after one warm-up if it fits
     the budget."""
     from oracle import llama as ol
-    c1 = dict(cfg, n_layers=1, vocab=min(cfg["vocab"], 32768))
+    c1 = dict(cfg, n_layers=1)
     W = ol.random_weights(c1, seed=0)
     ids = torch.randint(0, c1["vocab"], (S,), generator=torch.Generator().manual_seed(1234))
     cores = torch.get_num_threads()
@@ -84,30 +84,61 @@ def pmc_traffic():
         return None
 
 
-def smallm_roofline(ops, dtype, device):
-    """secondary roofline: the Linear eps-rule in its HBM-bound regime (north star: ">= 60 % HBM roofline on the
-    Linear eps-rule kernel").  One row (M=1) through Llama-3-8B's gate/up-sized weight [14336, 4096]: W is
-    streamed ONCE (z recompute + relevance redistribution in one pass, lrp_linear_eps_smallm).  Algorithmic bytes
-    = sizeof*(N*K + 2*M*K + M*N); duration from HIP events over 20 launches on the launching stream."""
-    M, N, K = 1, 14336, 4096
+def smallm_roofline(ops, dtype, device, cfg, batch):
+    """secondary roofline: the Linear eps-rule in its HBM-bound regime (north star: ">= 60 % HBM roofline on the Linear eps-rule
+    kernel").  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
+    [vocab, hidden] at M = prompts per step -- forward z = x W^T (lrp_linear_smallm_fwd) and eps-rule redistribution
+    c = (g z/(z+eps)) W (lrp_linear_smallm_dgrad), each streaming W ONCE from its stored layout (no W^T copy).  Algorithmic bytes
+    = sizeof * (N K + M K + M N) forward, sizeof * (N K + M K + 2 M N) backward; durations from HIP events on the launching stream,
+    20 launches each.  `table` adds M = 1, 2, 4, 8, 16 on the gate/up-sized weight [14336, 4096] and the one-pass fused kernel
+    (z recompute + redistribution in ONE pass over W, lrp_linear_eps_smallm, M <= 4)."""
     g = torch.Generator(device=device).manual_seed(3)
-    x = torch.randn(M, K, generator=g, device=device).to(dtype)
-    W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
-    gg = torch.randn(M, N, generator=g, device=device).to(dtype)
-    ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(M, N, K), device=device)
-    for _ in range(3):
-        ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(20):
-        ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / 20
-    nbytes = x.element_size() * (N * K + 2 * M * K + M * N)
-    return {"bound": "hbm", "kernel": "linear_eps_smallm_kernel + slab reduce (M=1, W [14336,4096])", "achieved": nbytes / sec / 1e9,
-            "peak": 8000.0, "unit": "GB/s", "frac": nbytes / sec / 1e9 / 8000.0, "avg_launch_us": sec * 1e6, "traffic": None}
+    es = torch.empty(0, dtype=dtype).element_size()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / 20
+
+    def pair(M, N, K):
+        x = torch.randn(M, K, generator=g, device=device).to(dtype)
+        W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
+        gg = torch.randn(M, N, generator=g, device=device).to(dtype)
+        z = ops.linear_smallm_fwd(x, W)
+        out = ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6)
+        tf = timed(lambda: ops.linear_smallm_fwd(x, W, out=z))
+        tb = timed(lambda: ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out))
+        bf, bb = es * (N * K + M * K + M * N), es * (N * K + M * K + 2 * M * N)
+        return dict(M=M, N=N, K=K, fwd_us=tf * 1e6, fwd_GBs=bf / tf / 1e9, dgrad_us=tb * 1e6, dgrad_GBs=bb / tb / 1e9,
+                    pair_GBs=(bf + bb) / (tf + tb) / 1e9, pair_frac=(bf + bb) / (tf + tb) / 1e9 / 8000.0)
+
+    M = min(batch, ops.SMALLM_MAX)
+    head = pair(M, cfg["vocab"], cfg["hidden"])
+    table = [pair(m, 2 * cfg["inter"] // 2, cfg["hidden"]) for m in (1, 2, 4, 8, 16)]
+    fused = None
+    try:
+        Mf, N, K = 1, cfg["inter"], cfg["hidden"]
+        x = torch.randn(Mf, K, generator=g, device=device).to(dtype)
+        W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
+        gg = torch.randn(Mf, N, generator=g, device=device).to(dtype)
+        ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(Mf, N, K), device=device)
+        t = timed(lambda: ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws))
+        nb = es * (N * K + 2 * Mf * K + Mf * N)
+        fused = dict(M=Mf, N=N, K=K, us=t * 1e6, GBs=nb / t / 1e9, frac=nb / t / 1e9 / 8000.0)
+    except RuntimeError:
+        pass
+    return {"bound": "hbm", "kernel": f"lrp_linear_smallm_fwd + lrp_linear_smallm_dgrad (Linear eps-rule, M={M} rows, W [{cfg['vocab']},{cfg['hidden']}] "
+                                      "= the LM head, the largest one-row-per-prompt Linear explain() runs)",
+            "achieved": head["pair_GBs"], "peak": 8000.0, "unit": "GB/s", "frac": head["pair_frac"],
+            "avg_launch_us": (head["fwd_us"] + head["dgrad_us"]) / 2, "traffic": None, "head": head, "table_gate_up_sized": table,
+            "one_pass_fused": fused}
 
 
 def dry_run(args):
@@ -188,10 +219,11 @@ def main():
     del W
     torch.cuda.empty_cache()
     if world > 1:
-        # weights are generated from the same seed on every rank; the broadcast from rank 0 makes
-        # the replica identity explicit (C1 of SURVEY.md 8e) -- outside the timed region
-        flat = [eng.embed, eng.norm, eng.lm_head] + [t for L in eng.layers for t in L.values()]
-        D.broadcast_weights(flat, src=0)
+        # weights are generated from the same seed on every rank; the broadcast from rank 0 makes the replica identity explicit
+        # (C1 of SURVEY.md 8e): ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB), the W^T
+        # copies of the dgrad GEMMs are rebuilt locally -- outside the timed region
+        D.broadcast_weights([eng.flat], src=0)
+        eng.build_transposes()
 
     B, S = args.batch, args.seq
     n_total = world * B
@@ -201,8 +233,7 @@ def main():
     def step(i):
         chunk = ids_all[i * n_total: (i + 1) * n_total]
         lo, hi = D.shard_range(n_total, rank, world)
-        out = eng.explain(chunk[lo:hi])
-        return D.gather_relevance(out["R_tok"], n_total)      # C2: all-gather of token relevances
+        return eng.explain(chunk[lo:hi])["R_tok"]               # this rank's shard; the all-gather (C2) is per JOB, below
 
     for i in range(args.warmup):
         R = step(i)
@@ -215,8 +246,9 @@ def main():
     t0 = time.perf_counter()
     per_step = []
     done = []                                               # one marker event per step
+    shards = []
     for i in range(args.steps):
-        R = step(args.warmup + i)
+        shards.append(step(args.warmup + i))
         ev = torch.cuda.Event()
         ev.record()
         done.append(ev)
@@ -229,12 +261,14 @@ def main():
         if os.environ.get("LRP_BENCH_PER_STEP"):            # dev: per-step wall times (adds a full sync per step)
             torch.cuda.synchronize()
             per_step.append(time.perf_counter() - t0)
+    # C2: ONE all-gather of the job's [steps * prompts_per_rank, S] fp32 token relevances, inside the timed region
+    R = D.gather_relevance(torch.cat(shards, 0), n_total * args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.GEMM_TIMER = None
-    assert torch.isfinite(R).all()
+    assert R.shape[0] == n_total * args.steps and torch.isfinite(R).all()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,7 +295,7 @@ def main():
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
                          "gemm_time_frac_of_step": secs / elapsed, "traffic": pmc_traffic()},
         }
-        line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev)
+        line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)

@@ -3,7 +3,9 @@
 The path shards embarrassingly: every prompt's explanation is independent, so there
 is NO collective on the data path.  RCCL (torch.distributed backend "nccl" on ROCm) over xGMI is used
 for exactly two things, neither per layer:
-  * broadcast_weights : rank 0's weights -> every rank, once at start-up (flat per-tensor broadcasts);
+  * broadcast_weights : rank 0's weights -> every rank, once at start-up: the engine keeps every weight in ONE flat buffer
+                        (LlamaLRP.flat, forward layouts only), so this is a single collective; the W^T copies of the dgrad
+                        GEMMs are rebuilt locally (LlamaLRP.build_transposes);
   * gather_relevance  : all-gather of the [n_local, S] fp32 token relevances at the end of a job.
 Correctness contract: the rank-sharded relevance of prompt p equals the single-GPU relevance of p bit
 for bit (same kernels, same order) -- tests/test_dist_cpu.py checks the partition/gather logic with the
@@ -67,13 +69,17 @@ def gather_relevance(R_local, n_total):
     return torch.cat(rows, 0)
 
 
-def explain_sharded(explain_fn, ids, batch):
+def explain_sharded(explain_fn, ids, batch, rank=None, world=None, gather=True):
     """Run explain_fn(ids_chunk [b,S]) -> R [b,S] over this rank's shard of `ids` [n,S] in chunks of
-    `batch`, then all-gather.  Returns R [n,S] (global order) on every rank."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    `batch`, then all-gather ONCE per job.  Returns R [n,S] (global order) on every rank.
+    rank / world override the process group's (gather=False: return only the local shard) -- used to check on ONE device that
+    the shards of a job reproduce the un-sharded result bit for bit."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_range(ids.shape[0], rank, world)
     outs = [explain_fn(ids[i: min(i + batch, hi)]) for i in range(lo, hi, batch)]
     S = ids.shape[1]
     R_local = torch.cat(outs, 0) if outs else torch.zeros(0, S, dtype=torch.float32, device=ids.device)
-    return gather_relevance(R_local, ids.shape[0])
+    return gather_relevance(R_local, ids.shape[0]) if gather else R_local

@@ -183,3 +183,55 @@ def test_top_layer_sparsity_equals_dense(eng_mod, mode):
     sparse = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=512, sparse_top=True).explain(ids2, layer_relevance=True)
     assert torch.equal(dense["idx"], sparse["idx"])
     assert nmax(sparse["R_tok"], dense["R_tok"]) < 1e-5 and nmax(sparse["layer_R"], dense["layer_R"]) < 1e-5
+
+
+def test_job_sharded_over_fake_ranks_equals_unsharded(eng_mod):
+    """SURVEY 8e correctness contract on ONE device: the shards two ranks would compute (lxt_amd.dist.explain_sharded with the
+    rank / world overridden, chunks of 2 prompts) concatenate to the un-sharded job bit for bit -- same kernels, same order"""
+    import lxt_amd.dist as D
+    cfg, W, ids, fx = llama_case("mid")
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=512)
+    job = torch.stack([torch.roll(ids, k) for k in range(7)])                     # 7 prompts: uneven shards (4 + 3)
+    whole = torch.cat([eng.explain(job[i:i + 1])["R_tok"] for i in range(7)])
+    fn = lambda x: eng.explain(x)["R_tok"]                                        # noqa: E731
+    parts = [D.explain_sharded(fn, job, batch=2, rank=r, world=2, gather=False) for r in (0, 1)]
+    assert [p.shape[0] for p in parts] == [4, 3]
+    assert torch.equal(torch.cat(parts), whole)
+
+
+def test_two_rank_job_on_two_gpus(tmp_path):
+    """world-2 run of the REAL engine (gloo rendezvous, one rank per visible GPU): weight broadcast of the flat buffer, local W^T
+    rebuild, sharded explanations, per-job all-gather == rank 0's own un-sharded result.  Skipped on 1-GPU boxes."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs")
+    import os, socket, subprocess, sys, textwrap
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, %r)
+        import lxt_amd.dist as D, lxt_amd.engine as E
+        import torch.distributed as dist
+        from tests.util import llama_case
+        rank, world, local = D.init()
+        cfg, W, ids, fx = llama_case("mid")
+        if rank != 0:
+            W = {k: (torch.zeros_like(v) if torch.is_tensor(v) else [{kk: torch.zeros_like(vv) for kk, vv in L.items()} for L in v]) for k, v in W.items()}
+        eng = E.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=512, device=f"cuda:{local}")
+        D.broadcast_weights([eng.flat], src=0)
+        eng.build_transposes()
+        job = torch.stack([torch.roll(ids, k) for k in range(5)]).to(f"cuda:{local}")
+        R = D.explain_sharded(lambda x: eng.explain(x)["R_tok"], job, batch=2)
+        if rank == 0:
+            whole = torch.cat([eng.explain(job[i:i + 1])["R_tok"] for i in range(5)])
+            assert torch.equal(R, whole), "sharded != single"
+        dist.barrier()
+        open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok%%d" %% rank), "w").write("ok")
+    """) % root)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists(), r.stdout[-2000:] + r.stderr[-2000:]
