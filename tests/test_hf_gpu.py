@@ -85,3 +85,53 @@ def test_model_family_maps(which):
                        timeout=600, cwd=root)
     print(r.stdout[-600:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bert_base_explicit_full_model_relevance():
+    """BASELINE config 2 in lxt.explicit semantics (ref lxt/explicit/models/bert.py:60-65,249-253,338-373,396): nn.Linear eps rule
+    with bias, LayerNormEpsilon, lf.matmul (R/(2 O + eps)) on BOTH attention contractions, add2 residuals, GELU / Tanh identity
+    rules -- against the relevance the reference's own Functions produced (bert_base_explicit.npz, fp32 and fp64) and the fp64
+    oracle.  Two product paths: (1) the SAME composition code the fixture was made with, over lxt_amd.explicit.{functional,rules}
+    (the drop-in claim of the explicit API), (2) an unmodified HF BertForSequenceClassification re-wired in place by
+    lxt_amd.explicit.models.bert.attnlrp.  Bar: 1e-4, or 3x the reference's own fp32-vs-fp64 gap on this instance (the explicit
+    stabilisers have poles)."""
+    _need_gpu()
+    import lxt_amd.explicit.functional as lf
+    import lxt_amd.explicit.rules as rules
+    from lxt_amd.explicit.models import bert as xb
+    from oracle import bert as ob
+    from tests.golden import bert_explicit_compose as C
+    fx = load("bert_base_explicit.npz")
+    ids = t(fx["ids"])
+    model = build_bert(seed=0, attn="eager")
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    bar = max(1e-4, 3 * float(fx["cond_gap"]))
+    o64 = ob.explain(C.weights_from_hf(model, torch.float64), ids, target=int(fx["idx"]), dtype=torch.float64)
+    assert nmax(o64["R_tok"], fx["R_tok_fp64"]) < 1e-9
+    # (1) same composition, HIP backend
+    W = C.weights_from_hf(model, torch.float32, device="cuda")
+    r = C.explain(lf, rules, W, ids[None].cuda())
+    assert r["idx"] == int(fx["idx"]) and abs(r["logit"] - float(fx["logit"])) < 1e-4
+    e1 = nmax(r["R_tok"], fx["R_tok_fp64"])
+    print(f"[bert-base explicit / composed over lxt_amd.explicit] token vs reference fp64 {e1:.2e} | vs reference fp32 "
+          f"{nmax(r['R_tok'], fx['R_tok']):.2e} | neuron {nmax(r['R_emb'], fx['R_emb_fp64']):.2e} (reference's own gap {float(fx['cond_gap']):.1e})")
+    assert e1 < bar
+    # (2) HF instance re-wired in place
+    model = model.cuda()
+    xb.attnlrp.register(model)
+    try:
+        e = model.get_input_embeddings()(ids[None].cuda()).detach().requires_grad_()
+        logits = model(inputs_embeds=e).logits
+        idx = int(logits[0].argmax())
+        assert idx == int(fx["idx"]) and abs(float(logits[0, idx]) - float(fx["logit"])) < 1e-4
+        logits[0, idx].backward(logits[0, idx].detach())
+        R = e.grad[0].sum(-1)
+        e2 = nmax(R, fx["R_tok_fp64"])
+        print(f"[bert-base explicit / HF instance + attnlrp.register] token vs reference fp64 {e2:.2e} | sum R {float(R.sum()):.6f} "
+              f"(reference {float(t(fx['R_tok_fp64']).sum()):.6f})")
+        assert e2 < bar
+    finally:
+        xb.attnlrp.remove()
+    with torch.no_grad():
+        plain = model(input_ids=ids[None].cuda()).logits[0]
+    assert nmax(plain, fx["logits"]) < 1e-5                      # remove() restores the plain model

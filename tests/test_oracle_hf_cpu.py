@@ -74,3 +74,25 @@ def test_gemma3_image_branch_oracle_vs_reference(impl):
     last[idx].backward()
     assert nmax((e * e.grad)[0].sum(-1), fx[f"{impl}_R_tok"]) < 5e-6
     assert nmax((px * px.grad)[0], fx[f"{impl}_R_pix"]) < 5e-6
+
+
+def test_bert_explicit_oracle_vs_reference_fixture():
+    """BASELINE config 2 in lxt.explicit semantics: oracle/bert.py (gradient form, fp64) against the per-token / per-neuron
+    relevance the reference's own explicit Functions produced (tests/golden/make_golden_bert_explicit.py, BERT-base S = 128)"""
+    import numpy as np
+    import torch
+    from oracle import bert as ob
+    from tests.golden import bert_explicit_compose as C
+    from tests.golden.hf_models import build_bert, wsum
+    from tests.util import load, nmax, t
+    fx = load("bert_base_explicit.npz")
+    model = build_bert(seed=0, attn="eager")
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    W = C.weights_from_hf(model, torch.float64)
+    o = ob.explain(W, t(fx["ids"]), dtype=torch.float64)
+    assert o["idx"] == int(fx["idx"]) and abs(o["logit"] - float(fx["logit"])) < 1e-9
+    assert nmax(o["R_tok"], fx["R_tok_fp64"]) < 1e-9 and nmax(o["R_emb"], fx["R_emb_fp64"]) < 1e-6      # (R_emb stored as fp32)
+    o32 = ob.explain(W, t(fx["ids"]), target=o["idx"], dtype=torch.float32)
+    gap = nmax(o32["R_tok"], o["R_tok"])
+    print(f"oracle fp32 vs fp64 {gap:.2e} (reference's own gap {float(fx['cond_gap']):.2e})")
+    assert gap < 10 * float(fx["cond_gap"])
