@@ -74,9 +74,9 @@ def cpu_baseline(cfg, S, budget_s=30.0):
 
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r01_gemm_traffic.json); None if absent.
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r02_gemm_traffic.json); None if absent.
     PMC counters cannot be collected inside the timed run itself."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
     try:
         with open(path) as f:
             return float(json.load(f)["traffic_bytes_per_launch"])

@@ -822,14 +822,34 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_v2_kernel(
         for (int s = 0; s < QSUB; ++s)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) pf[s][kc] = PackCols<T>::pack(st[s], kc);
+        if constexpr (sizeof(T) == 4) {
+            // fp32 (parity path): the tile's P.V goes into a fresh accumulator that is then ADDED to the running one -- an fp32
+            // MFMA chain is a sequential fmaf chain, and o = sum over ALL keys in one chain carries ~3x the rounding error of a
+            // blocked sum; the explicit P.V rule o/(o + 1e-6) amplifies exactly that error next to its pole
 #pragma unroll
-        for (int dt = 0; dt < ND16; ++dt)
+            for (int dt = 0; dt < ND16; ++dt) {
+                f32x4 part[QSUB];
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const frag_t vf = tr_frag<T>(sV, dt, kc, lane);
+                for (int s = 0; s < QSUB; ++s) part[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < QSUB; ++s) oacc[s][dt] = Mma16<T>::mma(vf, pf[s][kc], oacc[s][dt]);
+                for (int kc = 0; kc < 2; ++kc) {
+                    const frag_t vf = tr_frag<T>(sV, dt, kc, lane);
+#pragma unroll
+                    for (int s = 0; s < QSUB; ++s) part[s] = Mma16<T>::mma(vf, pf[s][kc], part[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < QSUB; ++s) oacc[s][dt] += part[s];
             }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < ND16; ++dt)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const frag_t vf = tr_frag<T>(sV, dt, kc, lane);
+#pragma unroll
+                    for (int s = 0; s < QSUB; ++s) oacc[s][dt] = Mma16<T>::mma(vf, pf[s][kc], oacc[s][dt]);
+                }
+        }
         __syncthreads();
         cur ^= 1;
     }

@@ -211,11 +211,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)kt * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[FM][FN];
+    // fp32 operands (the parity path): BLOCKED accumulation.  An fp32 MFMA chain is a k-ordered fmaf chain (one rounding per
+    // product, no wider internal accumulator), so a plain K loop is a sequential sum of K terms -- ~3x the rounding error of a
+    // CPU BLAS (which keeps ~100 partial sums), and the explicit rules' z/(z+eps) poles amplify exactly that error
+    // (tools/explicit_forward_error.py).  Here two K steps (64 terms) go into a short accumulator that is folded into the long
+    // one: error ~ eps (sqrt(64) + sqrt(K/64)) instead of eps sqrt(K).  bf16 operands keep the single accumulator.
+    constexpr bool BLOCKED = (sizeof(T) == 4) && (FM * FN <= 16);
+    f32x4 acc[FM][FN], lo[BLOCKED ? FM : 1][BLOCKED ? FN : 1];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BLOCKED) lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     stage(0, 0);
     __syncthreads();
@@ -238,7 +247,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : 2)) void gemm_nt
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (BLOCKED) lo[i][j] = Mma16<T>::mma(fb[j], fa[i], lo[i][j]);
+                    else acc[i][j] = Mma16<T>::mma(fb[j], fa[i], acc[i][j]);
+                }
+        }
+        if constexpr (BLOCKED) {
+            if ((kt & 1) == 1 || kt + 1 == nkt) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { acc[i][j] += lo[i][j]; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
         }
         __syncthreads();        // drains the LDS-DMA queue: tile kt+1 has landed, stage `cur` is free
         cur ^= 1;
@@ -476,7 +496,9 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * batch;
     constexpr int KE = KB / (int)sizeof(T);
-    if (tiles256 >= 190) {
+    // fp32 is the parity path, not the throughput path (1/16 of the bf16 MFMA rate): always the 128x128 kernel, whose fp32
+    // instantiation accumulates in blocks
+    if (sizeof(T) == 2 && tiles256 >= 190) {
         if (batch == 1 && K / KE >= 2) return launch_swp<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }

@@ -110,7 +110,37 @@ def mini_vit():
     return 0 if worst < 1e-4 else 1
 
 
+def bert_explicit():
+    """unmodified HF BertForSequenceClassification re-wired in place by lxt_amd.explicit.models.bert.attnlrp (explicit protocol:
+    seed the logit with its value, relevance = inputs_embeds.grad) against the reference's own Functions (bert_base_explicit.npz)"""
+    from lxt_amd.explicit.models import bert as xb
+    from tests.golden.hf_models import build_bert
+    fx = load("bert_base_explicit.npz")
+    ids = t(fx["ids"])
+    model = build_bert(seed=0, attn="eager")
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    model = model.cuda()
+    xb.attnlrp.register(model)
+    e = model.get_input_embeddings()(ids[None].cuda()).detach().requires_grad_()
+    logits = model(inputs_embeds=e).logits
+    idx = int(logits[0].argmax())
+    assert idx == int(fx["idx"]) and abs(float(logits[0, idx]) - float(fx["logit"])) < 1e-4
+    logits[0, idx].backward(logits[0, idx].detach())
+    R = e.grad[0].sum(-1)
+    err = nmax(R, fx["R_tok_fp64"])
+    print(f"[bert-base explicit / HF instance + attnlrp.register] token vs reference fp64 {err:.2e} | vs reference fp32 {nmax(R, fx['R_tok']):.2e} "
+          f"| sum R {float(R.sum()):.6f} (reference {float(t(fx['R_tok_fp64']).sum()):.6f}; reference's own fp32 gap {float(fx['cond_gap']):.1e})")
+    xb.attnlrp.remove()
+    with torch.no_grad():
+        plain = model(input_ids=ids[None].cuda()).logits[0]
+    ok = err < max(1e-4, 3 * float(fx["cond_gap"])) and nmax(plain, fx["logits"]) < 1e-5       # remove() restores the plain model
+    print(f"WORST {err:.3e}")
+    return 0 if ok else 1
+
+
 def main(which):
+    if which == "bert_explicit":
+        return bert_explicit()
     if which == "mini_vit":
         return mini_vit()
     if which == "gemma3_mm":

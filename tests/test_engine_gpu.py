@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import llama as ol
-from tests.util import nmax, llama_case
+from tests.util import nmax, llama_case, fp32_conditioning
 
 pytestmark = pytest.mark.gpu
 
@@ -90,10 +90,11 @@ def test_llama_ragged_lengths(eng_mod, S, B, mode):
     out = eng.explain(ids)
     for b in range(B):
         ref = ol.explain(cfg, W, ids=ids[b], target=int(out["idx"][b]), mode=mode, dtype=torch.float64)
-        ref32 = ol.explain(cfg, W, ids=ids[b], target=int(out["idx"][b]), mode=mode, dtype=torch.float32)
-        gap = nmax(ref32["R_tok"], ref["R_tok"])             # the oracle's own fp32-vs-fp64 conditioning on this instance
         err = nmax(out["R_tok"][b], ref["R_tok"])
-        assert err < max(1e-4, 20 * gap), (S, b, err, gap)
+        # 1e-4 wherever fp32 can resolve the instance; next to a pole of z/(z+eps) the bar follows the instance's own fp32
+        # conditioning (tests/util.fp32_conditioning: fp64 oracle under fp32-sized activation noise)
+        cond = fp32_conditioning(cfg, W, ids[b], int(out["idx"][b]), mode, ref64=ref["R_tok"]) if err >= 1e-4 else 0.0
+        assert err < max(1e-4, 5 * cond), (S, b, err, cond)
 
 
 @pytest.mark.parametrize("mode", ["explicit", "efficient"])
@@ -143,11 +144,10 @@ def test_llama_dense_seed_contrastive(eng_mod, mode):
     for b in range(2):
         assert nmax(out1["R_tok"][b], base["R_tok"][b]) < 1e-5               # a one-hot seed is the target path
         ref = ol.explain(cfg, W, ids=ids[b], mode=mode, dtype=torch.float64, seed=seed[b].double())
-        ref32 = ol.explain(cfg, W, ids=ids[b], mode=mode, dtype=torch.float32, seed=seed[b])
-        gap = nmax(ref32["R_tok"], ref["R_tok"])
         err = nmax(out["R_tok"][b], ref["R_tok"])
-        print(f"[dense seed {mode} prompt {b}] engine vs oracle fp64 {err:.2e} (oracle fp32-vs-fp64 {gap:.1e})")
-        assert err < max(1e-4, 20 * gap)
+        cond = fp32_conditioning(cfg, W, ids[b], None, mode, ref64=ref["R_tok"], seed=seed[b].double()) if err >= 1e-4 else 0.0
+        print(f"[dense seed {mode} prompt {b}] engine vs oracle fp64 {err:.2e} (instance fp32 conditioning {cond:.1e})")
+        assert err < max(1e-4, 5 * cond)
 
 
 def test_full_width_properties_bf16(eng_mod):

@@ -116,22 +116,11 @@ def test_bert_base_explicit_full_model_relevance():
     print(f"[bert-base explicit / composed over lxt_amd.explicit] token vs reference fp64 {e1:.2e} | vs reference fp32 "
           f"{nmax(r['R_tok'], fx['R_tok']):.2e} | neuron {nmax(r['R_emb'], fx['R_emb_fp64']):.2e} (reference's own gap {float(fx['cond_gap']):.1e})")
     assert e1 < bar
-    # (2) HF instance re-wired in place
-    model = model.cuda()
-    xb.attnlrp.register(model)
-    try:
-        e = model.get_input_embeddings()(ids[None].cuda()).detach().requires_grad_()
-        logits = model(inputs_embeds=e).logits
-        idx = int(logits[0].argmax())
-        assert idx == int(fx["idx"]) and abs(float(logits[0, idx]) - float(fx["logit"])) < 1e-4
-        logits[0, idx].backward(logits[0, idx].detach())
-        R = e.grad[0].sum(-1)
-        e2 = nmax(R, fx["R_tok_fp64"])
-        print(f"[bert-base explicit / HF instance + attnlrp.register] token vs reference fp64 {e2:.2e} | sum R {float(R.sum()):.6f} "
-              f"(reference {float(t(fx['R_tok_fp64']).sum()):.6f})")
-        assert e2 < bar
-    finally:
-        xb.attnlrp.remove()
-    with torch.no_grad():
-        plain = model(input_ids=ids[None].cuda()).logits[0]
-    assert nmax(plain, fx["logits"]) < 1e-5                      # remove() restores the plain model
+    # (2) an unmodified HF instance re-wired in place -- in a fresh process: the efficient-mode tests above patch BERT's classes
+    # process-wide (as the reference's monkey_patch does), the explicit wiring is meant for an un-patched transformers
+    import os, subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "hf_family_worker.py"), "bert_explicit"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    print(r.stdout[-600:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

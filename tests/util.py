@@ -39,3 +39,24 @@ def llama_case(name):
     if "W_embed" in fx:  # self-contained fixture: the carried weights must equal the regenerated ones
         assert np.array_equal(fx["W_embed"], W["embed"].numpy())
     return cfg, W, t(fx["ids"]), fx
+
+
+def fp32_conditioning(cfg, W, ids, target, mode, ref64=None, draws=3, rel=3e-7, seed=None, emb=None):
+    """How far can an fp32 evaluation of THIS instance be from the exact result?  The explicit rules multiply by z/(z + eps),
+    which has a pole at z = -eps: an activation that lands within a fraction of a percent of it turns an fp32-rounding-sized
+    perturbation of z into an O(1) change of that element's relevance, and whether a given fp32 implementation (the reference's
+    own included) is hit depends on its summation order -- one implementation's fp32-vs-fp64 gap is therefore NOT a stable scale
+    for another's.  This estimates the scale itself: the fp64 oracle is re-run with every stored activation multiplied by
+    (1 + rel * N(0,1)) (rel ~ a few fp32 ulps: storage rounding + a K-term accumulation) and the largest normalised deviation of
+    the token relevance over `draws` noise seeds is returned.  ~1e-7 on well-conditioned instances (and always for mode
+    'efficient'), 1e-4 ... 1e-2 where a pole is near."""
+    from oracle import llama as ol
+    if ref64 is None:
+        ref64 = ol.explain(cfg, W, ids=ids, emb=emb, target=target, mode=mode, dtype=torch.float64, seed=seed)["R_tok"]
+    worst = 0.0
+    for d in range(draws):
+        g = torch.Generator().manual_seed(1000 + d)
+        noisy = ol.explain(cfg, W, ids=ids, emb=emb, target=target, mode=mode, dtype=torch.float64, seed=seed,
+                           rnd=lambda x: x * (1 + rel * torch.randn(x.shape, generator=g, dtype=x.dtype)))
+        worst = max(worst, nmax(noisy["R_tok"], ref64))
+    return worst
