@@ -25,7 +25,12 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-constexpr int NW = 8;              // waves per workgroup
+constexpr int NW = 8;              // waves per workgroup of the dK/dV kernel (256 keys)
+#ifndef A32_NWQ
+#define A32_NWQ 4
+#endif
+constexpr int NWQ = A32_NWQ;       // waves per workgroup of the forward / dQ kernels: 128 queries, TWO workgroups per CU, so that
+                                   // one workgroup's prologue / store tail and barrier waits run under the other's MFMAs
 constexpr int CT = 64;             // column-side rows per tile
 constexpr int D = 128;             // head dim
 constexpr int KP = D * 2;          // bytes per tile row
@@ -45,11 +50,12 @@ LRP_DEVICE bool xcd_group_decode(int L, int ngroups, int per_group, int& group, 
 }
 inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
 
-// stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, two per wave
+// stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, 16 / NWV per wave
+template <int NWV = NW>
 LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int grp = g * NW + wave;
+    for (int g = 0; g < 16 / NWV; ++g) {
+        const int grp = g * NWV + wave;
         const int row = grp * 4 + (lane >> 4), slot = lane & 15;
         const int chunk = slot ^ rot4(row);
         int gr = row0 + row;
@@ -109,6 +115,80 @@ LRP_DEVICE bf16x8 pack8(const f32x16& x, int j) {
 // column-side row of accumulator register r in lane-half hi
 LRP_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// ---- hand-issued LDS reads ---------------------------------------------------------------------------------------------
+// The compiler's own bookkeeping puts s_waitcnt lgkmcnt(0) behind every fresh fragment read, i.e. {read, wait the full LDS
+// latency, MFMA} per contraction step.  The LDS returns in order, so "the fragment I need" = "all but the n younger reads":
+// reads are issued a few steps ahead as inline asm and waited for with hand-counted s_waitcnt lgkmcnt(n); sched_barrier(0)
+// keeps the groups in program order.  (Outstanding scalar loads or compiler-issued LDS operations can only make a counted
+// wait more conservative.)  A side effect: the compiler no longer sees LDS reads that might alias the in-flight
+// direct-to-LDS loads of the next tile and stops draining vmcnt in the middle of the tile.
+#define A32_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
+#define A32_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
+#define A32_WAIT(n, ...) asm volatile("s_waitcnt lgkmcnt(" #n ")" : __VA_ARGS__)
+#define A32_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the 8 transpose reads (4 head-dim blocks x 2 halves) of one 16-row group
+#define A32_TR8(dst, adr, off)                                                                              \
+    A32_RDTR(dst[0][0], adr[0][0], off); A32_RDTR(dst[0][1], adr[0][1], off); A32_RDTR(dst[1][0], adr[1][0], off); \
+    A32_RDTR(dst[1][1], adr[1][1], off); A32_RDTR(dst[2][0], adr[2][0], off); A32_RDTR(dst[2][1], adr[2][1], off); \
+    A32_RDTR(dst[3][0], adr[3][0], off); A32_RDTR(dst[3][1], adr[3][1], off)
+#define A32_TRV(t) "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1])
+// Measured and NOT adopted (profiles/r02_attention_experiments.txt): s_setprio schemes that favour one of the two waves of a
+// SIMD (static, or high priority in the MFMA phases only) change nothing -- tools/attn_timeline.py shows the MFMA phases of a
+// wave already running at close to their single-wave time, i.e. the two waves of a SIMD are complementary; what is left is the
+// per-wave cost of the element-wise phase (VALU issue beside the other wave's MFMAs), the LDS-DMA issue cost of the staging
+// loads and the per-workgroup prologue / store tail.
+// dev builds only (-DA32_TIMELINE, tools/attn_timeline.py): per-wave shader-clock totals of the dQ kernel's loop segments, written
+// over the first words of the wave's first output row
+#ifdef A32_TIMELINE
+#define A32_TS(slot)                                                          \
+    {                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+        const uint32_t now_ = (uint32_t)__builtin_readcyclecounter();         \
+        tl_acc[slot] += now_ - tl_prev;                                       \
+        tl_prev = now_;                                                       \
+    }
+#else
+#define A32_TS(slot)
+#endif
+template <int V> struct IC { static constexpr int value = V; };
+template <int I, int N, typename F> LRP_DEVICE void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        sfor<I + 1, N>(static_cast<F&&>(f));
+    }
+}
+// value of the other lane half (lane ^ 32) combined with one's own: v_permlane32_swap (upper 32 lanes of the first operand
+// <-> lower 32 lanes of the second) instead of an LDS round trip.  Inline asm: the builtin's second result was folded away
+// by the compiler when both operands are the same value; s_nop 1 = the VALU-write -> permlane-read wait states.
+LRP_DEVICE void half_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+LRP_DEVICE float half_max(float x) {
+    float a = x, b = x;
+    half_swap(a, b);
+    return fmaxf(a, b);
+}
+LRP_DEVICE float half_sum(float x) {
+    float a = x, b = x;
+    half_swap(a, b);
+    return a + b;
+}
+// row-fragment address of contraction step ks from the step-0 address: chunk (2 ks + hi) ^ rot = (2 ks) ^ (hi ^ rot), so the
+// eight addresses differ by an XOR of ks << 5 (tile rows are 256-byte aligned).  Kept opaque (asm volatile) so that the
+// compiler recomputes it next to the read instead of keeping eight address registers live across the kernel.
+template <int KS> LRP_DEVICE uint32_t frag_addr(uint32_t a0) {
+    if constexpr (KS == 0) return a0;
+    else {
+        uint32_t r;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(KS << 5), "v"(a0));
+        return r;
+    }
+}
+LRP_DEVICE uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_ptr_t)p; }
+// the two halves of a transpose-read fragment as one MFMA operand
+LRP_DEVICE bf16x8 join_tr(u32x2 a, u32x2 b) {
+    const u32x4 v = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 LRP_DEVICE void load_row_frags(bf16x8* f, const bf16_t* base, int64_t ld, int row, int S, int hi) {
     const bool ok = row < S;
 #pragma unroll
@@ -135,7 +215,7 @@ LRP_DEVICE void store_rows(bf16_t* base, int64_t ld, int row, int S, const f32x1
 }
 
 LRP_DEVICE bool visible(int q, int key, int S, int causal, int window, int lo, int hi) {
-    return key < S && (!causal || key <= q) && (window <= 0 || key > q - window) && key >= lo && key < hi;
+    return (key < S) & (!causal | (key <= q)) & ((window <= 0) | (key > q - window)) & (key >= lo) & (key < hi);   // no branches
 }
 // explicit stabilisers folded into ONE reciprocal (as attention.hip: lrp_ds2)
 template <bool EXPL>
@@ -150,11 +230,11 @@ LRP_DEVICE float lrp_ds(float s_raw, float p, float dp, float Dq, float scale, f
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-__global__ __launch_bounds__(512, 2) void fwd_kernel(
+__global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
     float* __restrict__ lse, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
     int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
-    constexpr int BQ = NW * 32, STAGE = 2 * TILE;
+    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -172,8 +252,6 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(
     load_row_frags(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, hi);
     int ivlo = 0, ivhi = S;
     if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-    LaneAddr la;
-    la.init(lane);
     f32x16 oacc[ND32];
 #pragma unroll
     for (int db = 0; db < ND32; ++db) oacc[db] = zero16();
@@ -186,40 +264,66 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
-        stage_tile(kb_, ldk, kt0, S, sb, wave, lane);
-        stage_tile(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+        stage_tile<NWQ>(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile<NWQ>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
     };
     if (kbeg < kend) stage(kbeg, 0);
     __syncthreads();
+    // absolute LDS addresses of the current tile's fragments (K tile; V tile = + TILE; 32-row block kb = + kb * 8192)
+    uint32_t arm[NK], atr[ND32][2];
+    {
+        const uint32_t sbase = lds_addr(smem);
+        LaneAddr la;
+        la.init(lane);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) arm[ks] = sbase + la.rm[ks];
+#pragma unroll
+        for (int db = 0; db < ND32; ++db) { atr[db][0] = sbase + la.tr[db][0]; atr[db][1] = sbase + la.tr[db][1]; }
+    }
     int cur = 0;
     for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
         if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
-        const char* sK = smem + cur * STAGE;
-        const char* sV = sK + TILE;
         // this wave's rows see nothing of the tile (causal: every key beyond the wave's last query): skip its arithmetic
         const bool dead = causal && kt0 > qw + 31;
         if (!dead) {
-            f32x16 st[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                st[kb] = zero16();
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) st[kb] = mfma32(lds_frag(sK + kb * 32 * KP, la.rm[ks]), qf[ks], st[kb]);
-            }
+            // ---- S^T of both 32-key blocks: 8 steps x 2 K fragments, read two steps ahead
+            f32x16 st[2] = {zero16(), zero16()};
+            bf16x8 f0[3], f1[3];
+            A32_RD128(f0[0], arm[0], 0); A32_RD128(f1[0], arm[0], 32 * KP);
+            A32_RD128(f0[1], arm[1], 0); A32_RD128(f1[1], arm[1], 32 * KP);
+            sfor<0, NK>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                if constexpr (ks + 2 < NK) {
+                    A32_RD128(f0[nx], arm[ks + 2], 0); A32_RD128(f1[nx], arm[ks + 2], 32 * KP);
+                    A32_WAIT(4, "+v"(f0[cu]), "+v"(f1[cu]));
+                } else if constexpr (ks + 1 < NK) {
+                    A32_WAIT(2, "+v"(f0[cu]), "+v"(f1[cu]));
+                } else {
+                    A32_WAIT(0, "+v"(f0[cu]), "+v"(f1[cu]));
+                }
+                st[0] = mfma32(f0[cu], qf[ks], st[0]);
+                st[1] = mfma32(f1[cu], qf[ks], st[1]);
+                A32_FENCE();
+            });
+            // ---- V^T fragments of the first key block: in flight under the softmax
+            u32x2 tv0[2][ND32][2], tv1[2][ND32][2];
+            A32_TR8(tv0[0], atr, TILE);
+            A32_TR8(tv0[1], atr, TILE + 16 * KP);
+            A32_FENCE();
             const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
             if (need_mask) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (!visible(qi, kt0 + kb * 32 + crow(r, hi), S, causal, window, ivlo, ivhi)) st[kb][r] = -INFINITY;
+                        st[kb][r] = visible(qi, kt0 + kb * 32 + crow(r, hi), S, causal, window, ivlo, ivhi) ? st[kb][r] : -INFINITY;
             }
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = half_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float nm2 = -m_use * c1;
@@ -232,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(
                     st[kb][r] = p;
                     rs += p;
                 }
-            rs += __shfl_xor(rs, 32, 64);
+            rs = half_sum(rs);
             // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
             if (__any(m_new != m_run)) {
                 const float alpha = fast_exp2((m_run - m_use) * c1);
@@ -241,17 +345,36 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(
                 for (int db = 0; db < ND32; ++db) oacc[db] *= alpha;
             } else l_run += rs;
             m_run = m_new;
+            const bf16x8 p00 = pack8(st[0], 0), p01 = pack8(st[0], 1), p10 = pack8(st[1], 0), p11 = pack8(st[1], 1);
+            A32_FENCE();
+            // (lgkmcnt is a 4-bit counter on gfx9: never count on more than 15 outstanding reads)
+            A32_TR8(tv1[0], atr, TILE + 32 * KP);
+            A32_WAIT(8, A32_TRV(tv0[0]), A32_TRV(tv0[1]));
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv0[0][db][0], tv0[0][db][1]), p00, oacc[db]);
+            A32_FENCE();
+            A32_TR8(tv1[1], atr, TILE + 48 * KP);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8 pf = pack8(st[kb], j);
-                    const char* grp = sV + (kb * 32 + j * 16) * KP;
+            for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv0[1][db][0], tv0[1][db][1]), p01, oacc[db]);
+            A32_FENCE();
+            A32_WAIT(8, A32_TRV(tv1[0]));
 #pragma unroll
-                    for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(lds_frag_tr(grp, la.tr[db][0], la.tr[db][1]), pf, oacc[db]);
-                }
+            for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv1[0][db][0], tv1[0][db][1]), p10, oacc[db]);
+            A32_FENCE();
+            A32_WAIT(0, A32_TRV(tv1[1]));
+#pragma unroll
+            for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv1[1][db][0], tv1[1][db][1]), p11, oacc[db]);
+            A32_FENCE();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next tile has landed (this wave's pieces)
         __syncthreads();
+        {
+            const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) arm[ks] += delta;
+#pragma unroll
+            for (int db = 0; db < ND32; ++db) { atr[db][0] += delta; atr[db][1] += delta; }
+        }
         cur ^= 1;
     }
     const float inv = (l_run > 0.f) ? 1.f / l_run : 0.f;
@@ -263,12 +386,12 @@ __global__ __launch_bounds__(512, 2) void fwd_kernel(
 // dQ: row side = 32 queries per wave; K and V tiles stream
 // =====================================================================================================================
 template <bool EXPL>
-__global__ __launch_bounds__(512, 2) void dq_kernel(
+__global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
     int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
     int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
-    constexpr int BQ = NW * 32, STAGE = 2 * TILE;
+    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -289,8 +412,6 @@ __global__ __launch_bounds__(512, 2) void dq_kernel(
     const float Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
     int ivlo = 0, ivhi = S;
     if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-    LaneAddr la;
-    la.init(lane);
     f32x16 acc[ND32];
 #pragma unroll
     for (int db = 0; db < ND32; ++db) acc[db] = zero16();
@@ -302,26 +423,60 @@ __global__ __launch_bounds__(512, 2) void dq_kernel(
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
-        stage_tile(kb_, ldk, kt0, S, sb, wave, lane);
-        stage_tile(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+        stage_tile<NWQ>(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile<NWQ>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
     };
     if (kbeg < kend) stage(kbeg, 0);
     __syncthreads();
+    // absolute LDS addresses of the current tile's fragments (K tile; V tile = + TILE; 32-row block kb = + kb * 8192), moved
+    // from stage to stage with the loop
+    uint32_t arm[NK], atr[ND32][2];
+    {
+        const uint32_t sbase = lds_addr(smem);
+        LaneAddr la;
+        la.init(lane);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) arm[ks] = sbase + la.rm[ks];
+#pragma unroll
+        for (int db = 0; db < ND32; ++db) { atr[db][0] = sbase + la.tr[db][0]; atr[db][1] = sbase + la.tr[db][1]; }
+    }
+#ifdef A32_TIMELINE
+    uint32_t tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_prev = (uint32_t)__builtin_readcyclecounter();
+    const uint32_t tl_start = tl_prev;
+#endif
     int cur = 0;
     for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
         if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
-        const char* sK = smem + cur * STAGE;
-        const char* sV = sK + TILE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        A32_TS(0);                                                       // 0: loop overhead + staging issue
+        sfor<0, 2>([&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value, KO = kb * 32 * KP;
             const int kk0 = kt0 + kb * 32;
-            if ((causal && kk0 > qw + 31) || kk0 >= S) continue;        // block invisible to every row of this wave
+            if ((causal && kk0 > qw + 31) || kk0 >= S) return;          // block invisible to every row of this wave
+            // ---- S^T and dP^T: 8 steps x {K fragment, V fragment}, read two steps ahead
             f32x16 st = zero16(), dp = zero16();
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                st = mfma32(lds_frag(sK + kb * 32 * KP, la.rm[ks]), qf[ks], st);
-                dp = mfma32(lds_frag(sV + kb * 32 * KP, la.rm[ks]), gf[ks], dp);
-            }
+            bf16x8 fk[3], fv[3];
+            A32_RD128(fk[0], arm[0], KO); A32_RD128(fv[0], arm[0], KO + TILE);
+            A32_RD128(fk[1], arm[1], KO); A32_RD128(fv[1], arm[1], KO + TILE);
+            sfor<0, NK>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                if constexpr (ks + 2 < NK) {
+                    A32_RD128(fk[nx], arm[ks + 2], KO); A32_RD128(fv[nx], arm[ks + 2], KO + TILE);
+                    A32_WAIT(4, "+v"(fk[cu]), "+v"(fv[cu]));
+                } else if constexpr (ks + 1 < NK) {
+                    A32_WAIT(2, "+v"(fk[cu]), "+v"(fv[cu]));
+                } else {
+                    A32_WAIT(0, "+v"(fk[cu]), "+v"(fv[cu]));
+                }
+                st = mfma32(fk[cu], qf[ks], st);
+                dp = mfma32(fv[cu], gf[ks], dp);
+                A32_FENCE();
+            });
+            A32_TS(1);                                                   // 1: S / dP phase
+            // ---- K^T fragments of the dQ contraction: issued before the element-wise work that hides their latency
+            u32x2 tk[2][ND32][2];
+            A32_TR8(tk[0], atr, KO);
+            A32_TR8(tk[1], atr, KO + 16 * KP);
+            A32_FENCE();
             const bool masked = (kk0 + 32 > S) || (causal && kk0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
             if (masked) {
 #pragma unroll
@@ -339,18 +494,42 @@ __global__ __launch_bounds__(512, 2) void dq_kernel(
                     st[r] = lrp_ds<EXPL>(s_raw, p, dp[r], Dq, scale, eps_mask, eps_qk);
                 }
             }
+            const bf16x8 df0 = pack8(st, 0), df1 = pack8(st, 1);
+            A32_FENCE();
+            A32_TS(2);                                                   // 2: element-wise
+            A32_WAIT(8, A32_TRV(tk[0]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bf16x8 df = pack8(st, j);
-                const char* grp = sK + (kb * 32 + j * 16) * KP;
+            for (int db = 0; db < ND32; ++db) acc[db] = mfma32(join_tr(tk[0][db][0], tk[0][db][1]), df0, acc[db]);
+            A32_FENCE();
+            A32_WAIT(0, A32_TRV(tk[1]));
 #pragma unroll
-                for (int db = 0; db < ND32; ++db) acc[db] = mfma32(lds_frag_tr(grp, la.tr[db][0], la.tr[db][1]), df, acc[db]);
-            }
-        }
+            for (int db = 0; db < ND32; ++db) acc[db] = mfma32(join_tr(tk[1][db][0], tk[1][db][1]), df1, acc[db]);
+            A32_FENCE();
+            A32_TS(3);                                                   // 3: dQ phase (issue)
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next tile has landed (this wave's pieces)
+        A32_TS(4);                                                       // 4: wait for the next tile
         __syncthreads();
+        A32_TS(5);                                                       // 5: barrier
+        {
+            const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) arm[ks] += delta;
+#pragma unroll
+            for (int db = 0; db < ND32; ++db) { atr[db][0] += delta; atr[db][1] += delta; }
+        }
         cur ^= 1;
     }
     store_rows(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+#ifdef A32_TIMELINE
+    if (lane == 0 && qw < S) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(dq + ((int64_t)b * S + qw) * lddq + (int64_t)h * D);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = tl_acc[i];
+        w[6] = (uint32_t)__builtin_readcyclecounter() - tl_start;
+        w[7] = (uint32_t)((kend - kbeg + CT - 1) / CT);
+    }
+#endif
 }
 
 // =====================================================================================================================
@@ -374,6 +553,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * D;
     const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
     const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
+    const int* rlo_b = row_lo ? row_lo + (int64_t)b * S : nullptr;
+    const int* rhi_b = row_lo ? row_hi + (int64_t)b * S : nullptr;
 
     // K fragments of the wave's 32 keys live in registers; the V fragments (32 more registers: with two 128-register
     // accumulators the kernel would spill) live in a per-wave [32 rows][256 B] LDS block in the tile layout
@@ -390,8 +571,6 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (int64_t)gr * ldv + ((slot ^ rot4(row)) * 8)), (lds_ptr_t)(sVw + g * 1024), 16, 0, 0);
         }
     }
-    LaneAddr la;
-    la.init(lane);
     f32x16 dkacc[ND32], dvacc[ND32];
 #pragma unroll
     for (int db = 0; db < ND32; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
@@ -410,60 +589,144 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     };
     if (qbeg < qend) stage(qbeg, 0);
     __syncthreads();
+    // absolute LDS addresses of the current stage (Q tile; Gho tile = + TILE; 32-row block qb = + qb * 8192; statistics at
+    // + 2 TILE), moved from stage to stage with the loop; the wave's V block sits at a fixed address
+    uint32_t arm0, avw0, atr[ND32][2], ast;
+    {
+        const uint32_t sbase = lds_addr(smem);
+        LaneAddr la;
+        la.init(lane);
+        arm0 = sbase + la.rm[0];
+        avw0 = arm0 + 2 * STAGE + wave * VROWS;                  // the wave's V block (fixed)
+#pragma unroll
+        for (int db = 0; db < ND32; ++db) { atr[db][0] = sbase + la.tr[db][0]; atr[db][1] = sbase + la.tr[db][1]; }
+        ast = sbase + 2 * TILE + hi * 16;
+    }
     int cur = 0;
     for (int qt0 = qbeg; qt0 < qend; qt0 += CT) {
         if (qt0 + CT < qend) stage(qt0 + CT, cur ^ 1);
-        const char* sQ = smem + cur * STAGE;
-        const char* sG = sQ + TILE;
-        const float* sL = reinterpret_cast<const float*>(sQ + 2 * TILE);
-        const float* sD = sL + 64;
-#pragma unroll 1
-        for (int qb = 0; qb < 2; ++qb) {
+        sfor<0, 2>([&](auto qbc) {
+            constexpr int qb = decltype(qbc)::value, QO = qb * 32 * KP, SO = qb * 128;
             const int qq0 = qt0 + qb * 32;
-            if ((causal && qq0 + 31 < kw) || qq0 >= S) continue;        // every query of the block precedes every key of the wave
+            if ((causal && qq0 + 31 < kw) || qq0 >= S) return;          // every query of the block precedes every key of the wave
+            // ---- S^T (8 steps x Q fragment), then dP^T (8 steps x {Gho fragment, V fragment}), read one step ahead; the two
+            // contractions run one after the other so that only 16 fragment registers are in flight (register budget)
             f32x16 st = zero16(), dp = zero16();
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                st = mfma32(lds_frag(sQ + qb * 32 * KP, la.rm[ks]), kf[ks], st);
-                dp = mfma32(lds_frag(sG + qb * 32 * KP, la.rm[ks]), lds_frag(sVw, la.rm[ks]), dp);
-            }
-            // lane (key, hi) holds queries qq0 + 8 i + 4 hi + e (i = r >> 2, e = r & 3): four 16-byte statistic reads each;
-            // the element-wise work is done per group of 8 registers (= one MFMA k-step of the dV / dK contractions) right
-            // before the MFMAs that consume it, so only 8 + 8 probabilities / gradients are live at a time
+            bf16x8 fq[2], fg[2], fv[2];
+            f32x4 sl[2], sd[2];                                         // lse / D of the queries 8 i + 4 hi + 0..3, double-buffered
+            A32_RD128(fq[0], arm0, QO);
+            sfor<0, NK>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks & 1, nx = cu ^ 1;
+                if constexpr (ks + 1 < NK) {
+                    { const uint32_t aq = frag_addr<ks + 1>(arm0); A32_RD128(fq[nx], aq, QO); }
+                    A32_WAIT(1, "+v"(fq[cu]));
+                } else {
+                    A32_RD128(fg[0], arm0, QO + TILE);
+                    A32_RD128(fv[0], avw0, 0);
+                    A32_WAIT(2, "+v"(fq[cu]));
+                }
+                st = mfma32(fq[cu], kf[ks], st);
+                A32_FENCE();
+            });
+            sfor<0, NK>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks & 1, nx = cu ^ 1;
+                if constexpr (ks + 1 < NK) {
+                    { const uint32_t ag = frag_addr<ks + 1>(arm0); A32_RD128(fg[nx], ag, QO + TILE); }
+                    { const uint32_t av = frag_addr<ks + 1>(avw0); A32_RD128(fv[nx], av, 0); }
+                    A32_WAIT(2, "+v"(fg[cu]), "+v"(fv[cu]));
+                } else {
+                    A32_RD128(sl[0], ast, SO); A32_RD128(sd[0], ast, SO + 256);
+                    A32_WAIT(2, "+v"(fg[cu]), "+v"(fv[cu]));
+                }
+                dp = mfma32(fg[cu], fv[cu], dp);
+                A32_FENCE();
+            });
+            // ---- element-wise work and the dV / dK contractions, one 16-query group j at a time:
+            //   B(j): P and dS of the group's 8 accumulator registers (statistics double-buffered, one read pair ahead);
+            //   C(j): dV^T += Gho^T P^T, dK^T += Q^T dS^T over the four head-dim blocks, transpose-read group g = (j, db)
+            //         issued one group ahead (two 128-register accumulators + the K fragments leave room for two groups).
+            // The first group of C(j) is in flight under B(j).
+            u32x2 tg[2][2], tq[2][2];
+#define A32_TRG(slot, jj, dbb)                                                                                        \
+    A32_RDTR(tg[slot][0], atr[dbb][0], QO + TILE + (jj) * 16 * KP); A32_RDTR(tg[slot][1], atr[dbb][1], QO + TILE + (jj) * 16 * KP); \
+    A32_RDTR(tq[slot][0], atr[dbb][0], QO + (jj) * 16 * KP); A32_RDTR(tq[slot][1], atr[dbb][1], QO + (jj) * 16 * KP)
+#define A32_TIE(sl_) "+v"(tg[sl_][0]), "+v"(tg[sl_][1]), "+v"(tq[sl_][0]), "+v"(tq[sl_][1])
+#define A32_DKV_STEP(g, wait_stmt)                                                                     \
+    {                                                                                                  \
+        constexpr int j_ = (g) >> 2, db_ = (g)&3, sl_ = (g)&1;                                         \
+        wait_stmt;                                                                                     \
+        dvacc[db_] = mfma32(join_tr(tg[sl_][0], tg[sl_][1]), pf[j_], dvacc[db_]);                      \
+        dkacc[db_] = mfma32(join_tr(tq[sl_][0], tq[sl_][1]), df[j_], dkacc[db_]);                      \
+        A32_FENCE();                                                                                   \
+    }
+            // lane (key, hi) holds queries qq0 + 8 i + 4 hi + e (i = r >> 2, e = r & 3)
             const bool masked = (qq0 + 32 > S) || (causal && qq0 < kw + 31) || (window > 0) || (row_lo != nullptr);
+            bf16x8 pf[2], df[2];
+            auto elementwise = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, cu = i & 1, nx = cu ^ 1;
+                // reads younger than the statistics of group i at this point: see the issue order below
+                if constexpr (i == 0) {
+                    A32_RD128(sl[nx], ast, SO + 32); A32_RD128(sd[nx], ast, SO + 32 + 256);
+                    A32_WAIT(6, "+v"(sl[cu]), "+v"(sd[cu]));
+                } else if constexpr (i == 1) {
+                    A32_RD128(sl[nx], ast, SO + 64); A32_RD128(sd[nx], ast, SO + 64 + 256);
+                    A32_WAIT(2, "+v"(sl[cu]), "+v"(sd[cu]), A32_TIE(0));
+                } else if constexpr (i == 2) {
+                    A32_RD128(sl[nx], ast, SO + 96); A32_RD128(sd[nx], ast, SO + 96 + 256);
+                    A32_WAIT(6, "+v"(sl[cu]), "+v"(sd[cu]));
+                } else {
+                    A32_WAIT(0, "+v"(sl[cu]), "+v"(sd[cu]), A32_TIE(0));
+                }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x8 pf, df;
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    const int i = 2 * j + ii;
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + qb * 32 + 8 * i + 4 * hi);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + qb * 32 + 8 * i + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * i + e;
-                        const float s_raw = st[r];
-                        float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(l4[e] * LRP_LOG2E)));
-                        if (masked) {
-                            const int qi = qq0 + 8 * i + 4 * hi + e;
-                            int ivlo = 0, ivhi = S;
-                            if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
-                            if (!((qi < S) && visible(qi, ki, S, causal, window, ivlo, ivhi))) p = 0.f;
-                        }
-                        pf[4 * ii + e] = (bf16_t)p;
-                        df[4 * ii + e] = (bf16_t)lrp_ds<EXPL>(s_raw, p, dp[r], d4[e], scale, eps_mask, eps_qk);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * i + e;
+                    const float s_raw = st[r];
+                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(sl[cu][e] * LRP_LOG2E)));
+                    if (masked) {
+                        const int qi = qq0 + 8 * i + 4 * hi + e;
+                        int ivlo = 0, ivhi = S;
+                        if (rlo_b != nullptr && qi < S) { ivlo = rlo_b[qi]; ivhi = rhi_b[qi]; }
+                        p = ((qi < S) & visible(qi, ki, S, causal, window, ivlo, ivhi)) ? p : 0.f;
                     }
+                    pf[i >> 1][4 * (i & 1) + e] = (bf16_t)p;
+                    df[i >> 1][4 * (i & 1) + e] = (bf16_t)lrp_ds<EXPL>(s_raw, p, dp[r], sd[cu][e], scale, eps_mask, eps_qk);
                 }
-                const char* gq = sQ + (qb * 32 + j * 16) * KP;
-                const char* gg = sG + (qb * 32 + j * 16) * KP;
-#pragma unroll
-                for (int db = 0; db < ND32; ++db) {
-                    dvacc[db] = mfma32(lds_frag_tr(gg, la.tr[db][0], la.tr[db][1]), pf, dvacc[db]);
-                    dkacc[db] = mfma32(lds_frag_tr(gq, la.tr[db][0], la.tr[db][1]), df, dkacc[db]);
-                }
-            }
-        }
+                A32_FENCE();
+            };
+            A32_TRG(0, 0, 0);                                           // g = 0
+            A32_FENCE();
+            elementwise(IC<0>{});
+            elementwise(IC<1>{});
+            A32_TRG(1, 0, 1);
+            A32_DKV_STEP(0, (void)0);
+            A32_TRG(0, 0, 2);
+            A32_DKV_STEP(1, A32_WAIT(4, A32_TIE(1)));
+            A32_TRG(1, 0, 3);
+            A32_DKV_STEP(2, A32_WAIT(4, A32_TIE(0)));
+            A32_TRG(0, 1, 0);                                           // g = 4: in flight under B(1)
+            A32_DKV_STEP(3, A32_WAIT(4, A32_TIE(1)));
+            elementwise(IC<2>{});
+            elementwise(IC<3>{});
+            A32_TRG(1, 1, 1);
+            A32_DKV_STEP(4, (void)0);
+            A32_TRG(0, 1, 2);
+            A32_DKV_STEP(5, A32_WAIT(4, A32_TIE(1)));
+            A32_TRG(1, 1, 3);
+            A32_DKV_STEP(6, A32_WAIT(4, A32_TIE(0)));
+            A32_DKV_STEP(7, A32_WAIT(0, A32_TIE(1)));
+#undef A32_DKV_STEP
+#undef A32_TIE
+#undef A32_TRG
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next tile has landed (this wave's pieces)
         __syncthreads();
+        {
+            const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+            arm0 += delta;
+#pragma unroll
+            for (int db = 0; db < ND32; ++db) { atr[db][0] += delta; atr[db][1] += delta; }
+            ast += delta;
+        }
         cur ^= 1;
     }
     store_rows(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, hi);
@@ -484,8 +747,8 @@ int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* 
     const size_t lds = 2 * (2 * (size_t)TILE);
     auto kern = fwd_kernel;
     set_lds(kern, lds);
-    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
+    hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
                        Hkv, ldq, ldk, ldv, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
     return lrp_check_launch();
 }
@@ -496,17 +759,17 @@ int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, 
                   hipStream_t st) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE);
-    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + 255) / 256)));
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
     if (eps_mask != 0.f || eps_qk != 0.f) {
         auto kern = dq_kernel<true>;
         set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
                            lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
                            q_begin, row_lo, row_hi);
     } else {
         auto kern = dq_kernel<false>;
         set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
                            lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
                            q_begin, row_lo, row_hi);
     }
