@@ -39,6 +39,7 @@ extern "C" {
 #define LRP_ACT_SILU 0
 #define LRP_ACT_GELU_TANH 1
 #define LRP_ACT_GELU 2
+#define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
 int lrp_version(void);                 /* ABI version, currently 2 (lrp_attn_fwd takes v and v_t) */
@@ -149,6 +150,10 @@ int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, vo
 int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
 int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, float eps_g, int act,
                 int dtype, void* stream);
+/* forward sums of the encoder families: out[m,:] = x[m,:] + y[m % period,:]  (period 1: a bias / token-type row, period S: position
+ * embeddings, period M: a residual sum; the summands of lf.add2, ref: lxt/explicit/models/bert.py:249-253,:396).  x, y, out [.,H]
+ * contiguous; out may alias x.                                                                                                    */
+int lrp_add_bcast(const void* x, const void* y, void* out, int M, int H, int period, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K5  RoPE (rotate-half convention).  ref: HF apply_rotary_pos_emb;

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "liblrp_hip.so")
 HEADER_PATH = os.path.abspath(os.path.join(_HERE, "..", "include", "lrp_hip.h"))
 
 F32, BF16 = 0, 1
-ACT = {"silu": 0, "gelu_tanh": 1, "gelu_pytorch_tanh": 1, "gelu": 2}
+ACT = {"silu": 0, "gelu_tanh": 1, "gelu_pytorch_tanh": 1, "gelu": 2, "tanh": 3}
 ERRORS = {-1: "LRP_EINVAL (bad argument)", -2: "LRP_EALIGN (pointer / leading dimension alignment)",
           -3: "LRP_ESHAPE (unsupported shape)", -4: "LRP_ELAUNCH (HIP launch failed)"}
 

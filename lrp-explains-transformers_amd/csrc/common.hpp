@@ -99,6 +99,7 @@ LRP_DEVICE float act_apply(float x, int act) {
         const float k0 = 0.7978845608028654f, k1 = 0.044715f;
         return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
     }
+    if (act == LRP_ACT_TANH) return tanhf(x);
     return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
 }
 

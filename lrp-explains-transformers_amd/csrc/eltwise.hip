@@ -77,6 +77,23 @@ __global__ void mul_kernel(const T* a_, const T* b_, T* out, int64_t n) {
     }
 }
 
+// out[m,:] = x[m,:] + y[m % period,:]
+template <typename T, int W>
+__global__ void add_bcast_kernel(const T* x, const T* y, T* out, int M, int H, int period) {
+    const int cpr = H / W;
+    const int64_t total = (int64_t)M * cpr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * W;
+        Chunk<T, W> a, b, o;
+        a.load(x + r * H + c);
+        b.load(y + (r % period) * H + c);
+#pragma unroll
+        for (int k = 0; k < W; ++k) o.v[k] = a.v[k] + b.v[k];
+        o.store(out + r * H + c);
+    }
+}
+
 template <typename T, int W>
 __global__ void add2_rule_kernel(const T* a_, const T* b_, const T* R_, T* Ra, T* Rb, int64_t n, float eps) {
     const int64_t nchunk = n / W;
@@ -339,6 +356,20 @@ extern "C" int lrp_mul(const void* a, const void* b, void* out, int64_t n, int d
     return lrp_check_launch();
 }
 
+extern "C" int lrp_add_bcast(const void* x, const void* y, void* out, int M, int H, int period, int dtype, void* stream) {
+    if (!x || !y || !out || M < 0 || H < 0 || period <= 0) return LRP_EINVAL;
+    if (M == 0 || H == 0) return LRP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        if (al16(x) && al16(y) && al16(out) && (H % EPC == 0))
+            hipLaunchKernelGGL((add_bcast_kernel<T, EPC>), dim3(grid_for((int64_t)M * H / EPC)), dim3(ENT), 0, st, (const T*)x, (const T*)y, (T*)out, M, H, period);
+        else
+            hipLaunchKernelGGL((add_bcast_kernel<T, 1>), dim3(grid_for((int64_t)M * H)), dim3(ENT), 0, st, (const T*)x, (const T*)y, (T*)out, M, H, period);
+    })
+    return lrp_check_launch();
+}
+
 extern "C" int lrp_add2_rule_bwd(const void* a, const void* b, const void* R, void* Ra, void* Rb,
                                  int64_t n, float eps, int dtype, void* stream) {
     if (!a || !b || !R || !Ra || n < 0) return LRP_EINVAL;
@@ -376,7 +407,7 @@ extern "C" int lrp_cast(const void* in, void* out, int64_t n, int in_dtype, int 
 }
 
 extern "C" int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream) {
-    if (!x || !y || n < 0 || act < 0 || act > 2) return LRP_EINVAL;
+    if (!x || !y || n < 0 || act < 0 || act > 3) return LRP_EINVAL;
     if (n == 0) return LRP_OK;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
@@ -395,7 +426,7 @@ extern "C" int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype
 
 extern "C" int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, float eps_g, int act,
                            int dtype, void* stream) {
-    if (!Gy || !x || !Gx || n < 0 || act < 0 || act > 2) return LRP_EINVAL;
+    if (!Gy || !x || !Gx || n < 0 || act < 0 || act > 3) return LRP_EINVAL;
     if (n == 0) return LRP_OK;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
@@ -416,7 +447,7 @@ static inline bool ld_ok(int64_t ld, int epc) { return (ld % epc) == 0; }
 
 extern "C" int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64_t ldg,
                                  int64_t ldu, int64_t ldm, int act, int dtype, void* stream) {
-    if (!g || !u || !m || M < 0 || I < 0 || act < 0 || act > 2) return LRP_EINVAL;
+    if (!g || !u || !m || M < 0 || I < 0 || act < 0 || act > 3) return LRP_EINVAL;
     if (M == 0 || I == 0) return LRP_OK;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
@@ -431,7 +462,7 @@ extern "C" int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, i
 extern "C" int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, void* Au,
                                  int M, int I, int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag,
                                  int64_t ldau, float eps_g, float eps_lin, int act, int dtype, void* stream) {
-    if (!Gm || !g || !u || !Ag || !Au || M < 0 || I < 0 || act < 0 || act > 2) return LRP_EINVAL;
+    if (!Gm || !g || !u || !Ag || !Au || M < 0 || I < 0 || act < 0 || act > 3) return LRP_EINVAL;
     if (M == 0 || I == 0) return LRP_OK;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {

@@ -208,6 +208,19 @@ def mul(a, b, out=None):
     return out
 
 
+def add_bcast(x, y, out=None):
+    """out[m,:] = x[m,:] + y[m % period,:], period = rows of y (1: a row vector, S: per-position rows, M: a full residual sum)"""
+    x, y = _c(x), _c(y)
+    H = x.shape[-1]
+    M, period = x.numel() // H, y.numel() // H
+    out = torch.empty_like(x) if out is None else out
+    same(x, y, out)
+    if y.shape[-1] != H or M % period:
+        raise ValueError(f"add_bcast: x {tuple(x.shape)} vs y {tuple(y.shape)}")
+    check(lib.lrp_add_bcast(p(x), p(y), p(out), M, H, period, dt(x), stream()), "lrp_add_bcast")
+    return out
+
+
 def add2_rule_bwd(a, b, R, eps=1e-8, need_b=True):
     a, b, R = _c(a), _c(b), _c(R)
     Ra = torch.empty_like(a)

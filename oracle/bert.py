@@ -46,36 +46,41 @@ def cast(W, dtype):
     return out
 
 
-def forward(W, ids):
-    """ids [S] -> cache (one prompt)"""
+def forward(W, ids, rnd=None):
+    """ids [S] -> cache (one prompt).  rnd: optional hook applied to every stored activation (tests/util.py:
+    fp32_conditioning_bert models fp32-sized evaluation noise with it)"""
+    rnd = rnd or (lambda x: x)
     S = ids.shape[0]
     H, nh = W["word"].shape[1], W["heads"]
     d = H // nh
     c = {}
     word = W["word"][ids]
-    e1 = word + W["tt"][0][None]
-    e2 = e1 + W["pos"][:S]
+    e1 = rnd(word + W["tt"][0][None])
+    e2 = rnd(e1 + W["pos"][:S])
     h, std0 = _ln(e2, W["eln_w"], W["eln_b"], W["ln_eps"])
+    h = rnd(h)
     c.update(word=word, e1=e1, e2=e2, h0=h, std0=std0)
     layers = []
     scale = 1 / math.sqrt(d)
     for L in W["layers"]:
         lc = dict(h=h)
-        q = (F.linear(h, L["wq"], L["bq"])).view(S, nh, d).transpose(0, 1)
-        k = (F.linear(h, L["wk"], L["bk"])).view(S, nh, d).transpose(0, 1)
-        v = (F.linear(h, L["wv"], L["bv"])).view(S, nh, d).transpose(0, 1)
-        s = q @ k.transpose(-1, -2)
+        q = rnd(F.linear(h, L["wq"], L["bq"])).view(S, nh, d).transpose(0, 1)
+        k = rnd(F.linear(h, L["wk"], L["bk"])).view(S, nh, d).transpose(0, 1)
+        v = rnd(F.linear(h, L["wv"], L["bv"])).view(S, nh, d).transpose(0, 1)
+        s = rnd(q @ k.transpose(-1, -2))
         p = F.softmax(s * scale, dim=-1)
-        o = p @ v
+        o = rnd(p @ v)
         of = o.transpose(0, 1).reshape(S, H)
-        a = F.linear(of, L["wo"], L["bo"])
-        r1 = a + h
+        a = rnd(F.linear(of, L["wo"], L["bo"]))
+        r1 = rnd(a + h)
         h1, std1 = _ln(r1, L["ln1_w"], L["ln1_b"], W["ln_eps"])
-        zi = F.linear(h1, L["wi"], L["bi"])
+        h1 = rnd(h1)
+        zi = rnd(F.linear(h1, L["wi"], L["bi"]))
         m = F.gelu(zi)
-        dn = F.linear(m, L["wd"], L["bd"])
-        r2 = dn + h1
+        dn = rnd(F.linear(m, L["wd"], L["bd"]))
+        r2 = rnd(dn + h1)
         h2, std2 = _ln(r2, L["ln2_w"], L["ln2_b"], W["ln_eps"])
+        h2 = rnd(h2)
         lc.update(q=q, k=k, v=v, s=s, p=p, o=o, of=of, a=a, r1=r1, h1=h1, std1=std1, zi=zi, m=m, dn=dn, r2=r2, h2=h2, std2=std2)
         layers.append(lc)
         h = h2
@@ -131,9 +136,9 @@ def backward(W, c, target):
     return Gword, layer_R[::-1]
 
 
-def explain(W, ids, target=None, dtype=torch.float64):
+def explain(W, ids, target=None, dtype=torch.float64, rnd=None):
     Wd = cast(W, dtype)
-    c = forward(Wd, ids)
+    c = forward(Wd, ids, rnd)
     if target is None:
         target = int(c["logits"].argmax())
     G, layer_R = backward(Wd, c, target)

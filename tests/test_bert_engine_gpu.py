@@ -1,0 +1,96 @@
+"""GPU: the fused BERT driver (lxt_amd.engine_bert.BertLRP, BASELINE config 2: BERT-base, S = 128, fp32) against the fixtures
+captured from the reference's own primitives -- efficient placement (bert_base.npz, tests/golden/make_golden_hf.py) and the explicit
+composite (bert_base_explicit.npz, tests/golden/make_golden_bert_explicit.py) -- and against the fp64 oracle (oracle/bert.py),
+including the per-layer latent relevance.  Bars: 1e-4 normalised max error per token (fp32); explicit: 1e-4 or the instance's own fp32
+conditioning (tests/util.py: fp32_conditioning_bert -- the fp64 oracle under fp32-sized activation noise; the LayerNormEpsilon
+stabiliser 1e-6 sits only one decade above the absolute fp32 error of a LayerNorm output), with the reference's
+own fp32-vs-fp64 gap printed beside it."""
+import pytest
+import torch
+
+from tests.golden.hf_models import build_bert, wsum
+from tests.util import nmax, load, t, fp32_conditioning_bert
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+
+
+@pytest.fixture(scope="module")
+def bert():
+    _need_gpu()
+    model = build_bert(seed=0, attn="eager")
+    return model
+
+
+def test_bert_engine_efficient_fp32_vs_reference(bert):
+    from lxt_amd.engine_bert import BertLRP
+    fx = load("bert_base.npz")
+    assert abs(wsum(bert) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    eng = BertLRP.from_hf(bert, dtype=torch.float32, mode="efficient")
+    ids = t(fx["ids"])[None].cuda()
+    r = eng.explain(ids)
+    assert int(r["idx"][0]) == int(fx["idx"]) and abs(float(r["logit"][0]) - float(fx["logit"])) < 1e-4
+    e1, e2 = nmax(r["R_tok"][0], fx["R_tok"]), nmax(r["R_tok"][0], fx["R_tok_fp64"])
+    print(f"[BertLRP efficient fp32] token vs reference fp32 {e1:.2e} | vs reference fp64 {e2:.2e}")
+    assert e1 < 1e-4 and e2 < 1e-4
+
+
+def test_bert_engine_explicit_fp32_vs_reference_and_oracle(bert):
+    from lxt_amd.engine_bert import BertLRP
+    from oracle import bert as ob
+    from tests.golden import bert_explicit_compose as C
+    fx = load("bert_base_explicit.npz")
+    eng = BertLRP.from_hf(bert, dtype=torch.float32, mode="explicit")
+    ids = t(fx["ids"])
+    r = eng.explain(ids[None].cuda(), layer_relevance=True)
+    assert int(r["idx"][0]) == int(fx["idx"]) and abs(float(r["logit"][0]) - float(fx["logit"])) < 1e-4
+    W64 = C.weights_from_hf(bert, torch.float64)
+    o64 = ob.explain(W64, ids, target=int(fx["idx"]), dtype=torch.float64)
+    cond = fp32_conditioning_bert(W64, ids, int(fx["idx"]), o64["R_tok"], draws=3, rel=1e-7)
+    bar = max(1e-4, cond)
+    # the engine propagates a UNIT gradient on the logit; the explicit protocol seeds with the logit's value
+    R = r["R_tok"][0].double().cpu()
+    e1, e2 = nmax(R, fx["R_tok_fp64"]), nmax(R, o64["R_tok"])
+    eL = nmax(r["layer_R"][0], torch.tensor(o64["layer_R"]))
+    print(f"[BertLRP explicit fp32] token vs reference fp64 {e1:.2e} | vs oracle fp64 {e2:.2e} | per-layer latent relevance {eL:.2e} "
+          f"(instance fp32 conditioning {cond:.1e}; reference's own fp32 gap {float(fx['cond_gap']):.1e})")
+    assert e1 < bar and e2 < bar and eL < bar
+
+
+def test_bert_engine_batch_targets_and_graph(bert):
+    """a batch is B independent explanations; a given target is honoured; the hipGraph replay reproduces the eager launches bit
+    for bit, also after the static inputs are overwritten with another batch"""
+    from lxt_amd.engine_bert import BertLRP
+    eng = BertLRP.from_hf(bert, dtype=torch.float32, mode="efficient")
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, bert.config.vocab_size, (3, 128), generator=g).cuda()
+    full = eng.explain(ids)
+    for b in range(3):
+        one = eng.explain(ids[b: b + 1])
+        assert int(one["idx"][0]) == int(full["idx"][b])
+        assert nmax(full["R_tok"][b], one["R_tok"][0]) < 1e-5
+    tgt = 1 - full["idx"]
+    other = eng.explain(ids, target=tgt)
+    assert torch.equal(other["idx"], tgt) and nmax(other["R_tok"], full["R_tok"]) > 1e-3
+    with pytest.raises(ValueError):
+        eng.explain(ids, target=[0, 1, 2])
+    gr = eng.explain(ids, graph=True)
+    assert torch.equal(gr["R_tok"], full["R_tok"]) and torch.equal(gr["idx"], full["idx"])
+    ids2 = torch.randint(0, bert.config.vocab_size, (3, 128), generator=g).cuda()
+    eager2 = eng.explain(ids2)["R_tok"].clone()
+    gr2 = eng.explain(ids2, graph=True)                                     # replay of the captured graph on new inputs
+    assert torch.equal(gr2["R_tok"], eager2)
+
+
+def test_bert_engine_bf16_close_to_fp32(bert):
+    from lxt_amd.engine_bert import BertLRP
+    ids = t(load("bert_base.npz")["ids"])[None].cuda()
+    r32 = BertLRP.from_hf(bert, dtype=torch.float32, mode="efficient").explain(ids)
+    r16 = BertLRP.from_hf(bert, dtype=torch.bfloat16, mode="efficient").explain(ids)
+    e = nmax(r16["R_tok"], r32["R_tok"])
+    print(f"[BertLRP efficient bf16 vs fp32] token {e:.2e}")
+    assert e < 8e-2

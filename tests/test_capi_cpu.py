@@ -160,3 +160,13 @@ def test_rope_scaling_tables_match_hf():
     from transformers import Qwen2Config
     with pytest.raises(NotImplementedError, match="model_type"):
         E.config_from_hf(Qwen2Config(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=8))
+
+
+def test_bert_engine_refuses_to_run_without_a_device():
+    """BertLRP (like LlamaLRP) has no CPU path: constructing it without a HIP device raises"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from lxt_amd.engine_bert import BertLRP
+    with pytest.raises(RuntimeError):
+        BertLRP(dict(hidden=8, inter=16, n_layers=0, n_heads=2, ln_eps=1e-12, act="gelu", labels=2), {})

@@ -60,3 +60,21 @@ def fp32_conditioning(cfg, W, ids, target, mode, ref64=None, draws=3, rel=3e-7, 
                            rnd=lambda x: x * (1 + rel * torch.randn(x.shape, generator=g, dtype=x.dtype)))
         worst = max(worst, nmax(noisy["R_tok"], ref64))
     return worst
+
+
+def fp32_conditioning_bert(W64, ids, target, ref64=None, draws=3, rel=3e-7):
+    """fp32_conditioning for the explicit BERT composite (oracle/bert.py).  The noise of a stored activation is relative to its
+    ROW's scale, not to the element: LayerNorm outputs and residual sums reach |y| ~ 1e-6 (the LayerNormEpsilon stabiliser!) by
+    cancellation of O(1) terms, so their fp32 error is ~1e-7 absolute however small they are."""
+    from oracle import bert as ob
+    if ref64 is None:
+        ref64 = ob.explain(W64, ids, target=target, dtype=torch.float64)["R_tok"]
+    worst = 0.0
+    for d in range(draws):
+        g = torch.Generator().manual_seed(2000 + d)
+
+        def rnd(x):
+            scale = x.pow(2).mean(-1, keepdim=True).sqrt()
+            return x + rel * scale * torch.randn(x.shape, generator=g, dtype=x.dtype)
+        worst = max(worst, nmax(ob.explain(W64, ids, target=target, dtype=torch.float64, rnd=rnd)["R_tok"], ref64))
+    return worst
