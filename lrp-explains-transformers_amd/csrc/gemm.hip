@@ -502,6 +502,14 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
         if (batch == 1 && K / KE >= 2) return launch_swp<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }
+    // small problems (BERT-sized M = 128: 6..24 tiles of 128x128 on 256 CUs, each walking the whole K alone): 64x64 or 32x32
+    // tiles give 4x / 16x the workgroups; same K order per output element, so the results do not change
+    const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (tiles128 < 96) {
+        const int64_t tiles64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch;
+        if (tiles64 < 96) return launch_glds<T, TO, 32, 32, 1, 1>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+        return launch_glds<T, TO, 64, 64, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
+    }
     return launch_glds<T, TO, 128, 128, 2, 2>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
 }
 

@@ -35,7 +35,8 @@ def f64(x):
 
 # ----------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (128, 128, 64), (200, 136, 264), (257, 129, 72), (2048, 512, 1024), (64, 1000, 4096)])
+@pytest.mark.parametrize("M,N,K", [(1, 768, 768), (128, 128, 64), (200, 136, 264), (257, 129, 72), (2048, 512, 1024), (64, 1000, 4096),
+                                   (128, 768, 768), (128, 3072, 768), (128, 768, 3072), (100, 70, 128), (300, 200, 256), (33, 31, 64)])
 def test_gemm_nt(ops, dtype, M, N, K):
     a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
     bias = rnd(N, dtype=dtype, seed=3)
