@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
     const int64_t ld = stB ? ldb : lda;
     uint32_t voff[16];                                                   // per-lane byte offset of this lane's piece of block q
 #pragma unroll
+    // (measured: the order of rows ACROSS consecutive pieces matters as much as within one -- with the N-side blocks permuted so that
+    // a store instruction writes 64 contiguous bytes per row, consecutive pieces jump 32 rows and the kernel drops from 1.24 to 0.97
+    // PFLOP/s: the LDS-DMA issue cost follows the address-translation locality of the rows, 8 KB .. 28 KB apart)
     for (int q = 0; q < 16; ++q) voff[q] = (uint32_t)(((int64_t)(8 * q + (lane >> 3)) * ld) * 2 + (lane & 7) * 16);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t st_dst = lds0 + (stB ? W4_OPND : 0) + half * 16 * W4_BLK;   // + stage * W4_STAGE + q * W4_BLK
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
 // dev builds only (-DW4_TIMELINE, tools/gemm_w4_timeline.py): shader-clock totals of the loop's wait points
 #ifdef W4_TIMELINE
 #define W4_TS(k) { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl[k] += (uint32_t)now_ - tl_prev; tl_prev = (uint32_t)now_; }
-    uint32_t tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_prev = 0;
+    uint32_t tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_prev = 0, tl_tile = 0, tl_kernel = 0;
+    { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl_kernel = tl_tile = (uint32_t)now_; }
 #else
 #define W4_TS(k)
 #endif
@@ -130,6 +134,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
 
     int it = blockIdx.x;
     if (it >= ntile) return;
+#ifdef W4_SKEW
+    // all workgroups walk equally long tiles in lock step, so their C store bursts (32 MiB at once) coincide and are bandwidth-
+    // bound; a one-off start skew of (workgroup mod 8) / 8 of a tile time spreads them (only worth it with many tiles per CU)
+    if (ntile >= 8 * (int)gridDim.x) {
+        const int naps = ((blockIdx.x >> 3) & 7) * nkt * 2900 / 8 / (64 * 127);
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     int m0, n0;
     tile_origin(it, m0, n0);
     {   // the very first output tile: K tiles 0 and 1 in flight
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
 #ifdef W4_TIMELINE
         { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl_prev = (uint32_t)now_; }
         const uint32_t tl_start = tl_prev;
+        tl[8] += tl_start - tl_tile;                                     // 8: tile prologue (wait for K tile 0, first reads, zeroing)
 #endif
 
         // ---- one K tile t.  MODE 0: tile t+2 exists (its 16 pieces go into tile t's stage); 1: only tile t+1 exists;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
         W4_BODY(2)                                                       // t = nkt - 1
 #undef W4_BODY
 #ifdef W4_TIMELINE
-        { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl[6] += (uint32_t)now_ - tl_start; tl[7] += (uint32_t)nkt; }
+        { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl[6] += (uint32_t)now_ - tl_start; tl[7] += (uint32_t)nkt; tl_tile = (uint32_t)now_; }
 #endif
 
         // ---- epilogue: lane (row slot q = l&15, column group fq = l>>4) holds, for M-tile i, row 8 q + i of its wave's 128 and,
@@ -246,13 +259,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
                 TO* dstp = C + (int64_t)gm * ldc + gn;
                 if (vec_ok && gn + 7 < N) {
                     if constexpr (sizeof(TO) == 4) {
-                        *reinterpret_cast<f32x4*>(dstp) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(dstp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(dstp));
+                        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(dstp + 4));
                     } else {
                         bf16x8 o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-                        *reinterpret_cast<bf16x8*>(dstp) = o;
+                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dstp));
                     }
                 } else {
 #pragma unroll
@@ -262,10 +275,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
             }
         }
 #ifdef W4_TIMELINE
+        { uint64_t now_; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); tl[9] += (uint32_t)now_ - tl_tile; tl_tile = (uint32_t)now_; tl[10] += 1; tl[11] = (uint32_t)now_ - tl_kernel; }   // 9: epilogue incl. store drain
         if (lane == 0 && !has_next) {                                     // over the wave's first output row (dev build only)
             uint32_t* w = reinterpret_cast<uint32_t*>(C + (int64_t)(m0 + wm * 128) * ldc + n0 + wn * 128);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = tl[i];
+            for (int i = 0; i < 12; ++i) w[i] = tl[i];
         }
 #endif
         m0 = nm0;
