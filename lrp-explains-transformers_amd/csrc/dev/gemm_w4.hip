@@ -56,18 +56,36 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
     const int ntile = tiles_m * tiles_n;
     const int nkt = K / W4_KT;                                          // host guarantees nkt >= 2
 
+#ifndef W4_SPLIT
+#define W4_SPLIT 0
+#endif
+#if W4_SPLIT
+    // ---- staging role (variant): EVERY wave stages both operands -- rows 64 w .. 64 w + 63 of A (pieces 0..7) and of B (pieces 8..15)
+    uint32_t voff[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        voff[q] = (uint32_t)(((int64_t)(64 * wave + 8 * (q & 7) + (lane >> 3)) * (q < 8 ? lda : ldb)) * 2 + (lane & 7) * 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t st_dst = lds0 + wave * 8 * W4_BLK;                    // + stage * W4_STAGE + (q < 8 ? 0 : W4_OPND) + (q & 7) * W4_BLK
+#define W4_DSTOFF(q) (((q) < 8 ? 0 : W4_OPND) + ((q)&7) * W4_BLK)
+#define W4_RS(rsrc, q) ((q) < 8 ? rsrc.a : rsrc.b)
+#else
     // ---- staging role: waves 0, 1 stage the two 128-row halves of A, waves 2, 3 those of B: 16 blocks per wave and K tile
     const bool stB = wave >= 2;
     const int half = wave & 1;
     const int64_t ld = stB ? ldb : lda;
     uint32_t voff[16];                                                   // per-lane byte offset of this lane's piece of block q
-#pragma unroll
     // (measured: the order of rows ACROSS consecutive pieces matters as much as within one -- with the N-side blocks permuted so that
     // a store instruction writes 64 contiguous bytes per row, consecutive pieces jump 32 rows and the kernel drops from 1.24 to 0.97
     // PFLOP/s: the LDS-DMA issue cost follows the address-translation locality of the rows, 8 KB .. 28 KB apart)
+#pragma unroll
     for (int q = 0; q < 16; ++q) voff[q] = (uint32_t)(((int64_t)(8 * q + (lane >> 3)) * ld) * 2 + (lane & 7) * 16);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t st_dst = lds0 + (stB ? W4_OPND : 0) + half * 16 * W4_BLK;   // + stage * W4_STAGE + q * W4_BLK
+#define W4_DSTOFF(q) ((q) * W4_BLK)
+#define W4_RS(rsrc, q) rsrc.a
+#endif
+    struct Srd2 { i32x4 a, b; };
 
     // ---- fragment addresses of this wave in stage 0; the stage is switched by XOR with (addr0 ^ addr1)
     const uint32_t vA0 = lds0 + (wm * 16 + (lane & 15)) * W4_BLK + (lane >> 4) * 16;
@@ -83,11 +101,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
 #define W4_RDB(s, j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[s][j]) : "v"(vB), "n"((j) * 128 + (s) * 64))
 // one direct-to-LDS piece: block q of this wave's operand half, into the stage at byte address `stg` (an SGPR), through `rsrc`.
 // In the K loop the M0 update and the load sit in two different MFMA gaps (no s_nop for the M0 hazard, one instruction per gap)
-#define W4_M0(stg, q) asm volatile("s_add_u32 m0, %0, %1" : : "s"(stg), "n"((q) * W4_BLK) : "scc")
-#define W4_LD(rsrc, q) asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff[q]), "s"(rsrc) : "memory")
+#define W4_M0(stg, q) asm volatile("s_add_u32 m0, %0, %1" : : "s"(stg), "n"(W4_DSTOFF(q)) : "scc")
+#define W4_LD(rsrc, q) asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff[q]), "s"(W4_RS(rsrc, q)) : "memory")
 #define W4_DMA(rsrc, stg, q)                                                                                        \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"                       \
-                 : : "s"(stg), "n"((q) * W4_BLK), "v"(voff[q]), "s"(rsrc) : "memory", "scc")   /* s_add_u32 writes SCC */
+                 : : "s"(stg), "n"(W4_DSTOFF(q)), "v"(voff[q]), "s"(W4_RS(rsrc, q)) : "memory", "scc")   /* s_add_u32 writes SCC */
 #define W4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define W4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define W4_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -119,16 +137,25 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
         m0 = tm * 256;
         n0 = tn * 256;
     };
-    auto make_srd = [&](int m0, int n0, int kt, bool live = true) {
-        const int row0 = (stB ? n0 : m0) + half * 128;
-        int rows_left = live ? (stB ? N : M) - row0 : 0;                 // !live: every access out of range (zeros, no traffic)
-        rows_left = rows_left < 0 ? 0 : (rows_left > 128 ? 128 : rows_left);
-        const uint64_t base = reinterpret_cast<uint64_t>((stB ? B : A) + (int64_t)row0 * ld) + (uint64_t)kt * 128;
+    auto one_srd = [&](const bf16_t* p, int64_t ld_, int row0, int rows_total, int span, int kt, bool live) {
+        int rows_left = live ? rows_total - row0 : 0;                    // !live: every access out of range (zeros, no traffic)
+        rows_left = rows_left < 0 ? 0 : (rows_left > span ? span : rows_left);
+        const uint64_t base = reinterpret_cast<uint64_t>(p + (int64_t)row0 * ld_) + (uint64_t)kt * 128;
         i32x4 r;                                                         // (readfirstlane: keeps the tuple in SGPRs for the asm)
         r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
         r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));   // stride 0 (raw buffer)
-        r[2] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)rows_left * ld * 2));
+        r[2] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)rows_left * ld_ * 2));
         r[3] = 0x00020000;
+        return r;
+    };
+    auto make_srd = [&](int m0, int n0, int kt, bool live = true) {
+        Srd2 r;
+#if W4_SPLIT
+        r.a = one_srd(A, lda, m0, M, 256, kt, live);
+        r.b = one_srd(B, ldb, n0, N, 256, kt, live);
+#else
+        r.a = r.b = one_srd(stB ? B : A, ld, (stB ? n0 : m0) + half * 128, stB ? N : M, 128, kt, live);
+#endif
         return r;
     };
 
@@ -145,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
     int m0, n0;
     tile_origin(it, m0, n0);
     {   // the very first output tile: K tiles 0 and 1 in flight
-        const i32x4 s0 = make_srd(m0, n0, 0), s1 = make_srd(m0, n0, 1);
+        const Srd2 s0 = make_srd(m0, n0, 0), s1 = make_srd(m0, n0, 1);
         const uint32_t d0 = st_dst, d1 = st_dst + W4_STAGE;
         W4_DMA16(s0, d0);
         W4_DMA16(s1, d1);
@@ -180,8 +207,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
         uint32_t cur = 0;                                                // byte offset of tile t's stage
 #define W4_BODY(MODE)                                                                                                \
     {                                                                                                                \
-        const i32x4 srd = (MODE == 0) ? make_srd(m0, n0, t + 2) : make_srd(nm0, nn0, 0, has_next);                   \
-        const i32x4 srd1 = make_srd(nm0, nn0, 1, has_next);                                                          \
+        const Srd2 srd = (MODE == 0) ? make_srd(m0, n0, t + 2) : make_srd(nm0, nn0, 0, has_next);                    \
+        const Srd2 srd1 = make_srd(nm0, nn0, 1, has_next);                                                           \
         const uint32_t dst = (MODE == 0) ? st_dst + cur : st_dst, dst1 = st_dst + W4_STAGE;                          \
         /* sub-step 0: 64 MFMAs; the 16 fragments of sub-step 1 are read under the first 32 */                       \
         W4_ROW(0, 0, W4_RDB(1, 0), W4_NOP, W4_RDB(1, 1), W4_NOP, W4_RDB(1, 2), W4_NOP, W4_RDB(1, 3), W4_NOP);         \
@@ -259,13 +286,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
                 TO* dstp = C + (int64_t)gm * ldc + gn;
                 if (vec_ok && gn + 7 < N) {
                     if constexpr (sizeof(TO) == 4) {
-                        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(dstp));
-                        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(dstp + 4));
+                        *reinterpret_cast<f32x4*>(dstp) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dstp + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     } else {
                         bf16x8 o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(dstp));
+                        *reinterpret_cast<bf16x8*>(dstp) = o;      // (non-temporal 16-byte stores: -15 %, measured)
                     }
                 } else {
 #pragma unroll
@@ -298,6 +325,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
 #undef W4_BARRIER
 #undef W4_SWAP
 #undef W4_TS
+#undef W4_DSTOFF
+#undef W4_RS
 }
 
 template <typename TO>

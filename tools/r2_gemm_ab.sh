@@ -12,5 +12,4 @@ for rep in 1 2; do
     cp $f $L; echo "== $(basename $f .so)"; timeout 300 python tools/kbench.py --what onegemm 2>&1 | grep "gemm"
   done
 done | tee -a $O/ab.txt
-if [ -f tools/ab/dev_tl.so ]; then cp tools/ab/dev_tl.so $L; python tools/gemm_w4_timeline.py | tee $O/timeline.txt; fi
 cp /tmp/product.so $L
