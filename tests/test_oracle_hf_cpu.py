@@ -96,3 +96,22 @@ def test_bert_explicit_oracle_vs_reference_fixture():
     gap = nmax(o32["R_tok"], o["R_tok"])
     print(f"oracle fp32 vs fp64 {gap:.2e} (reference's own gap {float(fx['cond_gap']):.2e})")
     assert gap < 10 * float(fx["cond_gap"])
+
+
+def test_bert_conditioning_estimate_is_deterministic_and_zero_without_noise():
+    """tests/util.fp32_conditioning_bert (the bar of the explicit BERT GPU tests): seeded noise -> reproducible estimate; rel = 0
+    reproduces the oracle exactly; the estimate grows with the noise level"""
+    import torch
+    from transformers import BertConfig, BertForSequenceClassification
+    from tests.golden import bert_explicit_compose as C
+    from tests.util import fp32_conditioning_bert
+    torch.manual_seed(3)
+    model = BertForSequenceClassification(BertConfig(vocab_size=200, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                                     intermediate_size=64, max_position_embeddings=64, num_labels=2)).eval()
+    W64 = C.weights_from_hf(model, torch.float64)
+    ids = torch.randint(0, 200, (24,), generator=torch.Generator().manual_seed(4))
+    a = fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-7)
+    b = fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-7)
+    assert a == b and a > 0
+    assert fp32_conditioning_bert(W64, ids, 0, draws=1, rel=0.0) == 0.0
+    assert fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-5) > a
