@@ -63,11 +63,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
     // ---- staging role (variant): EVERY wave stages both operands -- rows 64 w .. 64 w + 63 of A (pieces 0..7) and of B (pieces 8..15)
     uint32_t voff[16];
 #pragma unroll
+#if W4_SPLIT == 2
+    // (W4_SPLIT == 2: the vendor kernel's walk -- at any time the four waves cover 32 CONSECUTIVE rows (8 each) and step 32 rows
+    // per piece: piece p of wave w = rows 32 p + 8 w .. + 7 = LDS block 4 p + w)
+    for (int q = 0; q < 16; ++q)
+        voff[q] = (uint32_t)(((int64_t)(32 * (q & 7) + 8 * wave + (lane >> 3)) * (q < 8 ? lda : ldb)) * 2 + (lane & 7) * 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t st_dst = lds0 + wave * W4_BLK;
+#define W4_DSTOFF(q) (((q) < 8 ? 0 : W4_OPND) + ((q)&7) * 4 * W4_BLK)
+#else
     for (int q = 0; q < 16; ++q)
         voff[q] = (uint32_t)(((int64_t)(64 * wave + 8 * (q & 7) + (lane >> 3)) * (q < 8 ? lda : ldb)) * 2 + (lane & 7) * 16);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t st_dst = lds0 + wave * 8 * W4_BLK;                    // + stage * W4_STAGE + (q < 8 ? 0 : W4_OPND) + (q & 7) * W4_BLK
 #define W4_DSTOFF(q) (((q) < 8 ? 0 : W4_OPND) + ((q)&7) * W4_BLK)
+#endif
 #define W4_RS(rsrc, q) ((q) < 8 ? rsrc.a : rsrc.b)
 #else
     // ---- staging role: waves 0, 1 stage the two 128-row halves of A, waves 2, 3 those of B: 16 blocks per wave and K tile
