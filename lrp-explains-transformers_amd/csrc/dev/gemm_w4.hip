@@ -16,15 +16,16 @@
 //     register + an immediate, every global address a per-lane offset register + a buffer resource whose base the scalar
 //     unit advances; fragment reads, direct-to-LDS loads, waits and barriers are placed BY HAND between the MFMAs, at most
 //     one per gap (inline asm, all volatile: the order below is the order in the binary);
-//   * LDS image per operand and 64-element K tile: 32 blocks of [8 rows][128 B] + 16 B pad (1040 B).  Block (h, q) holds the
+//   * LDS image per operand and 64-element K tile: 32 blocks of [8 rows][128 B] + 32 B pad (1056 B).  Block (h, q) holds the
 //     EIGHT CONSECUTIVE rows h*128 + 8 q + i, i = 0..7, of the operand's 256 tile rows: ONE direct-to-LDS wave instruction
 //     (lane l -> row 8 q + (l>>3), bytes 16 (l&7)) fills it with eight full 128-byte lines.  MFMA fragment i of a wave is the
 //     row set {8 q + i, q = 0..15} (any bijection works: the accumulator layout follows from it), so fragment (i, sub-step s)
 //     of lane l (row slot q = l&15, k-chunk l>>4) sits at  block(q) + i*128 + s*64 + (l>>4)*16 : the sixteen row slots of a
-//     fragment are 1040 B apart = 4 banks, every ds_read_b128 lane group covers the 64 banks exactly once.  With the same
+//     fragment are 1056 B apart = 8 banks (mod 64); with the hardware's ds_read_b128 lane groups (which mix k-chunks) that is the
+//     conflict-free pad, 1040 B is not (tests/test_layout_maps_cpu.py).  With the same
 //     bijection on the N side a lane's 64 accumulator tiles hold, for each of its 8 rows, 4 runs of 8 CONSECUTIVE columns:
 //     32 sixteen-byte stores per lane;
-//   * two LDS stages (2 x 66,560 B), tiles prefetched TWO ahead: the loads of tile t+2 go into tile t's stage as soon as every
+//   * two LDS stages (2 x 67,584 B), tiles prefetched TWO ahead: the loads of tile t+2 go into tile t's stage as soon as every
 //     wave has read tile t's last fragments (barrier in the middle of sub-step 0); tile t+1 is waited for (counted vmcnt) and
 //     published (barrier) in the middle of sub-step 1, ~1.5 iterations after its loads were issued;
 //   * persistent: one workgroup per CU walks the output tiles; the first two K tiles of the NEXT output tile are issued in the
@@ -38,7 +39,11 @@
 namespace {
 
 constexpr int W4_KT = 64;                  // K elements per tile (128 B per row)
-constexpr int W4_BLK = 1040;               // one LDS block: 8 rows x 128 B + 16 B pad
+#ifndef W4_BLK_BYTES
+#define W4_BLK_BYTES 1056
+#endif
+constexpr int W4_BLK = W4_BLK_BYTES;       // one LDS block: 8 rows x 128 B + pad (16 B as the vendor kernel; 32 B is the conflict-free pad
+                                           // under the ds_read_b128 lane groups of MI355X_MICROARCH.md: tests/test_layout_maps_cpu.py)
 constexpr int W4_OPND = 32 * W4_BLK;       // one operand of one stage
 constexpr int W4_STAGE = 2 * W4_OPND;      // 66,560 B
 
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(
     const int nkt = K / W4_KT;                                          // host guarantees nkt >= 2
 
 #ifndef W4_SPLIT
-#define W4_SPLIT 0
+#define W4_SPLIT 2                          // best measured form (profiles/r02_gemm_experiments.txt)
 #endif
 #if W4_SPLIT
     // ---- staging role (variant): EVERY wave stages both operands -- rows 64 w .. 64 w + 63 of A (pieces 0..7) and of B (pieces 8..15)
