@@ -83,3 +83,13 @@ def test_gemm_product_chunk_swizzle():
     """gemm.hip: LDS rows of 128 B, 16-byte chunk XOR (row & 7): fragment reads (row l&15, chunk kk*4 + l>>4) are conflict-free"""
     for kk in range(2):
         assert conflicts(lambda lane: (lane & 15) * 128 + ((((kk * 4) + (lane >> 4)) ^ (lane & 7)) << 4), B128_GROUPS, 16) == 0
+
+
+def test_generic_attention_tile_swizzle():
+    """attention.hip: row-major tiles of 128 / 256 / 512-byte rows, chunk ^ (row & (min(chunks, 16) - 1)) (swz_mask): the 16-row fragment
+    reads of every 64-byte K chunk group are conflict-free"""
+    for pitch in (128, 256, 512):
+        nch = pitch // 16
+        sw = min(nch, 16) - 1
+        for kk in range(nch // 4):
+            assert conflicts(lambda lane: (lane & 15) * pitch + ((((kk * 4) + (lane >> 4)) ^ ((lane & 15) & sw)) << 4), B128_GROUPS, 16) == 0
