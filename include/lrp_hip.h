@@ -42,7 +42,8 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 2 (lrp_attn_fwd takes v and v_t) */
+int lrp_version(void);                 /* ABI version, currently 2 (lrp_attn_fwd takes v and v_t); additions that do not break callers
+                                          -- lrp_linear_smallm_*, lrp_add_bcast, LRP_ACT_TANH -- keep the number */
 const char* lrp_build_arch(void);      /* "gfx950" */
 int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
 
