@@ -15,6 +15,10 @@
 //   * 64 KiB LDS/block -> 2 blocks per CU; XCD-aware block remap keeps a B panel in one L2.
 #include "common.hpp"
 
+// gemm_pp.hip: 8-wave ping-pong kernel for the big bf16 problems (>= 190 tiles of 256 x 256)
+int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                       int64_t ldc, int out_dtype, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, KB = 128;     // KB: bytes of K per stage and per row
@@ -499,7 +503,8 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // fp32 is the parity path, not the throughput path (1/16 of the bf16 MFMA rate): always the 128x128 kernel, whose fp32
     // instantiation accumulates in blocks
     if (sizeof(T) == 2 && tiles256 >= 190) {
-        if (batch == 1 && K / KE >= 2) return launch_swp<T, TO>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
+        if (batch == 1 && K / KE >= 2)
+            return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, st);
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }
     // small problems (BERT-sized M = 128: 6..24 tiles of 128x128 on 256 CUs, each walking the whole K alone): 64x64 or 32x32

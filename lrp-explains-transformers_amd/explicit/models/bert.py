@@ -37,8 +37,10 @@ def explicit_attention_forward(module, query, key, value, attention_mask=None, s
     scale = float(scaling) if scaling is not None else 1.0 / math.sqrt(d)
     s = lf.matmul(query, key.transpose(-1, -2))
     s = lf.mul2(s, scale)
-    if attention_mask is None:       # the reference's BertModel always builds the (zero) extended mask and add2's it
+    if attention_mask is None:       # no padding: the reference's BertModel builds the all-zero extended mask and add2's it
         attention_mask = torch.zeros(1, dtype=s.dtype, device=s.device)
+    elif attention_mask.dtype == torch.bool:   # a boolean "may attend" mask -> the additive form the reference adds (ref :346)
+        attention_mask = torch.zeros_like(attention_mask, dtype=s.dtype).masked_fill(~attention_mask, torch.finfo(s.dtype).min)
     s = lf.add2(s, attention_mask.to(s.dtype).expand_as(s))
     p = lf.softmax(s, dim=-1)
     c = lf.matmul(p, value)
@@ -72,6 +74,20 @@ def _layer_norm_forward(self, x):
     return lf.layer_norm(x, self.weight, self.bias, self.eps)
 
 
+def register_interfaces(attention_fn=None):
+    """Register the explicit attention function AND a mask builder under ATTN_NAME.  transformers >= 4.53 builds the attention
+    mask per `_attn_implementation` through AttentionMaskInterface; a name without a mask function gets attention_mask=None, i.e.
+    padded batches would silently attend to pad tokens.  The eager builder yields the additive [B,1,S,S] mask that the reference
+    feeds to lf.add2 (ref: lxt/explicit/models/bert.py:346)."""
+    from transformers import AttentionInterface
+    AttentionInterface.register(ATTN_NAME, attention_fn or explicit_attention_forward)
+    try:
+        from transformers.masking_utils import AttentionMaskInterface, eager_mask
+    except ImportError:          # older transformers: the model builds the extended additive mask itself
+        return
+    AttentionMaskInterface.register(ATTN_NAME, eager_mask)
+
+
 class BertAttnLRP:
     """`attnlrp` of the reference (a Composite) plus the function-level rules its vendored model file carries."""
 
@@ -81,10 +97,9 @@ class BertAttnLRP:
         self._config = None
 
     def register(self, model, verbose=False, no_grad=True):
-        from transformers import AttentionInterface
         from transformers.activations import GELUActivation
         from transformers.models.bert import modeling_bert as mb
-        AttentionInterface.register(ATTN_NAME, explicit_attention_forward)
+        register_interfaces()
         self._config = (model.config, model.config._attn_implementation)
         model.config._attn_implementation = ATTN_NAME
         for m in model.modules():

@@ -138,9 +138,55 @@ def bert_explicit():
     return 0 if ok else 1
 
 
+def bert_explicit_padded():
+    """a RIGHT-PADDED batch through attnlrp.register (without a mask function registered for the custom attention name HF
+    hands attention_mask=None to it and pad tokens are attended to): logits equal HF's eager logits under the same mask, pad
+    positions carry exactly zero relevance, and each row equals the fp64 oracle on the un-padded prompt within the instance's
+    fp32 conditioning (oracle/bert.py under fp32-sized noise -- explicit stabilisers have poles)."""
+    from lxt_amd.explicit.models import bert as xb
+    from oracle import bert as ob
+    from tests.golden import bert_explicit_compose as C
+    from tests.golden.hf_models import build_bert
+    from tests.util import fp32_conditioning_bert
+    model = build_bert(seed=0, attn="eager")
+    W64 = C.weights_from_hf(model, torch.float64)
+    model = model.cuda()
+    S, lens = 128, (128, 100)
+    ids = torch.randint(0, model.config.vocab_size, (2, S), generator=torch.Generator().manual_seed(11))
+    am = torch.zeros(2, S, dtype=torch.long)
+    for b, L in enumerate(lens):
+        am[b, :L] = 1
+    with torch.no_grad():
+        plain = model(input_ids=ids.cuda(), attention_mask=am.cuda()).logits
+        nomask = model(input_ids=ids.cuda()).logits
+    xb.attnlrp.register(model)
+    e = model.get_input_embeddings()(ids.cuda()).detach().requires_grad_()
+    logits = model(inputs_embeds=e, attention_mask=am.cuda()).logits
+    idx = logits.argmax(-1)
+    sel = logits.gather(1, idx[:, None])[:, 0]
+    sel.backward(sel.detach())
+    R = e.grad.sum(-1).double().cpu()
+    xb.attnlrp.remove()
+    ok = nmax(logits.detach(), plain) < 1e-5 and nmax(nomask[1], plain[1]) > 1e-4        # the mask matters for the padded row
+    ok = ok and float(R[1, lens[1]:].abs().max()) == 0.0
+    worst = 0.0
+    for b, L in enumerate(lens):
+        o64 = ob.explain(W64, ids[b, :L], target=int(idx[b]), dtype=torch.float64)
+        cond = fp32_conditioning_bert(W64, ids[b, :L], int(idx[b]), o64["R_tok"], draws=3, rel=1e-7)
+        err = nmax(R[b, :L], o64["R_tok"])
+        print(f"[bert-base explicit padded batch, row {b}, length {L}] token vs oracle fp64 {err:.2e} (instance fp32 conditioning {cond:.1e}) "
+              f"logit {float(sel[b]):+.6f} vs oracle {o64['logit']:+.6f}")
+        ok = ok and abs(float(sel[b]) - o64["logit"]) < 1e-4 and err < max(1e-4, 5 * cond)
+        worst = max(worst, err)
+    print(f"WORST {worst:.3e}")
+    return 0 if ok else 1
+
+
 def main(which):
     if which == "bert_explicit":
         return bert_explicit()
+    if which == "bert_explicit_padded":
+        return bert_explicit_padded()
     if which == "mini_vit":
         return mini_vit()
     if which == "gemma3_mm":

@@ -61,6 +61,51 @@ def test_bert_engine_explicit_fp32_vs_reference_and_oracle(bert):
     assert e1 < bar and e2 < bar and eL < bar
 
 
+def _prompt_set_errors(run, fx):
+    """normalised max error per prompt of `run(ids[B,S]) -> (R_tok [B,S], idx [B], logit [B])` against the reference's fp64 relevance"""
+    ids = t(fx["ids"])
+    R, idx, logit = run(ids)
+    errs = []
+    for p_ in range(ids.shape[0]):
+        assert int(idx[p_]) == int(fx["idx"][p_]) and abs(float(logit[p_]) - float(fx["logit"][p_])) < 1e-4
+        errs.append(nmax(R[p_], fx["R_tok_fp64"][p_]))
+    return errs
+
+
+def _gmean(v):
+    import math
+    return math.exp(sum(math.log(max(x, 1e-30)) for x in v) / len(v))
+
+
+def test_bert_engine_explicit_prompt_set(bert):
+    """BASELINE config 2, explicit semantics, SIXTEEN prompts (fixture bert_explicit_prompts.npz, made by the REAL reference in fp64
+    and fp32, tests/golden/make_golden_bert_prompts.py).  LayerNormEpsilon multiplies by y/(y + 1e-6): a pole one decade above the
+    absolute fp32 error of a LayerNorm output, so the reference's OWN fp32 arithmetic is off from its fp64 by 9e-6 ... 9e-2
+    depending on the prompt (median 1.6e-4): no fp32 evaluation resolves every instance to 1e-4, and one prompt says nothing about
+    an implementation.  The bar is therefore distributional and tied to the reference: the fused driver's geometric-mean and median
+    error over the prompt set must not exceed 3x / 3x the reference's fp32 figures, and the drop-in path is printed beside it."""
+    import statistics
+    from lxt_amd.engine_bert import BertLRP
+    fx = load("bert_explicit_prompts.npz")
+    assert abs(wsum(bert) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    eng = BertLRP.from_hf(bert, dtype=torch.float32, mode="explicit")
+
+    def run_engine(ids):
+        r = eng.explain(ids.cuda())
+        return r["R_tok"].double().cpu(), r["idx"].cpu(), r["logit"].cpu()
+    errs = _prompt_set_errors(run_engine, fx)
+    ref = [float(x) for x in fx["ref_fp32_gap"]]
+    noise = fx["noise_draws"]
+    print("[BertLRP explicit fp32, 16 prompts] prompt: engine | reference's own fp32 | fp64 oracle under fp32-sized noise (3 draws)")
+    for p_, (e, g) in enumerate(zip(errs, ref)):
+        print(f"   {p_:2d}: {e:.2e} | {g:.2e} | " + " ".join(f"{float(x):.1e}" for x in noise[p_]))
+    ge, gr = _gmean(errs), _gmean(ref)
+    me, mr = statistics.median(errs), statistics.median(ref)
+    print(f"   geometric mean {ge:.2e} (reference fp32 {gr:.2e}) | median {me:.2e} (reference fp32 {mr:.2e}) | "
+          f"prompts under 1e-4: {sum(e < 1e-4 for e in errs)} (reference fp32 {sum(g < 1e-4 for g in ref)})")
+    assert ge < 3 * gr and me < 3 * mr
+
+
 def test_bert_engine_batch_targets_and_graph(bert):
     """a batch is B independent explanations; a given target is honoured; the hipGraph replay reproduces the eager launches bit
     for bit, also after the static inputs are overwritten with another batch"""

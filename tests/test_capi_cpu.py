@@ -170,3 +170,34 @@ def test_bert_engine_refuses_to_run_without_a_device():
     from lxt_amd.engine_bert import BertLRP
     with pytest.raises(RuntimeError):
         BertLRP(dict(hidden=8, inter=16, n_layers=0, n_heads=2, ln_eps=1e-12, act="gelu", labels=2), {})
+
+
+def test_explicit_bert_registers_a_mask_function():
+    """transformers builds the attention mask per `_attn_implementation`; the explicit BERT wiring registers its own
+    attention function, so it must register a mask builder under the same name -- otherwise padded batches get attention_mask=None.
+    CPU plumbing check with a probe attention function (the real one needs the HIP library)."""
+    import lxt_amd.explicit.models.bert as xb
+    from transformers.models.bert.modeling_bert import eager_attention_forward
+    from tests.golden.hf_models import build_bert
+    model = build_bert(seed=0, attn="eager").eval()
+    seen = {}
+
+    def probe(module, query, key, value, attention_mask=None, **kw):
+        seen["mask"] = attention_mask
+        return eager_attention_forward(module, query, key, value, attention_mask, **kw)
+
+    xb.register_interfaces(probe)
+    try:
+        ids = torch.randint(0, 1000, (2, 16), generator=torch.Generator().manual_seed(0))
+        am = torch.ones(2, 16, dtype=torch.long)
+        am[1, 10:] = 0
+        with torch.no_grad():
+            ref = model(input_ids=ids, attention_mask=am).logits
+            model.config._attn_implementation = xb.ATTN_NAME
+            got = model(input_ids=ids, attention_mask=am).logits
+        m = seen["mask"]
+        assert m is not None and tuple(m.shape) == (2, 1, 16, 16)
+        assert float(m[1, 0, 0, 10:].max()) < -1e30 and float(m[0].abs().max()) == 0.0 and float(m[1, 0, :, :10].abs().max()) == 0.0
+        assert torch.allclose(ref, got, atol=1e-6)
+    finally:
+        xb.register_interfaces()           # restore the real attention function under the name

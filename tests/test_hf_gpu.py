@@ -124,3 +124,15 @@ def test_bert_base_explicit_full_model_relevance():
                        timeout=600, cwd=root)
     print(r.stdout[-600:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bert_explicit_padded_batch():
+    """explicit wiring on a right-padded batch: the attention mask reaches the custom attention function"""
+    _need_gpu()
+    import os, subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "hf_family_worker.py"), "bert_explicit_padded"], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    print(r.stdout[-900:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
