@@ -8,8 +8,8 @@ torch.distributed.run with one rank per GPU.  A "step" = every rank explains `--
 
   value        whole-job explanations/s = N * batch * K / max-over-ranks(time of K steps); inputs
                (ids, weights) are resident in HBM before the timed region.
-  roofline     dominant kernel = the NT GEMM behind lrp_gemm_nt (gemm_nt_swp_kernel<bf16,bf16> for the 256x256-tile
-               shapes, gemm_nt_glds_kernel 128x128 for the small ones; 94 % of the algorithmic FLOPs): achieved
+  roofline     dominant kernel = the NT GEMM behind lrp_gemm_nt (gemm_nt_pp_kernel<bf16>, the 8-wave ping-pong kernel, for the
+               256x256-tile shapes, gemm_nt_glds_kernel 128x128 for the small ones; 94 % of the algorithmic FLOPs): achieved
                = sum over its launches of 2*M*N*K divided by the sum of their durations, both taken
                live with HIP events on the launching stream inside the timed region; peak = 2500
                TFLOP/s (dense bf16 MFMA, MI355X_MICROARCH.md).
@@ -290,7 +290,7 @@ def main():
                                    f"random init, lxt.{args.mode} rule placement, seq={S}, causal, last-position arg-max logit",
                        "seq_len": S, "prompts_per_gpu_per_step": B, "global_batch": n_total, "mode": args.mode,
                        "parallelism": f"dp{world} (prompt sharding, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "lrp_gemm_nt: gemm_nt_swp_kernel / gemm_nt_glds_kernel (Linear forward + eps-rule dgrad)",
+            "roofline": {"bound": "mfma", "kernel": "lrp_gemm_nt: gemm_nt_pp_kernel / gemm_nt_glds_kernel (Linear forward + eps-rule dgrad)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
                          "gemm_time_frac_of_step": secs / elapsed, "traffic": pmc_traffic()},

@@ -1,21 +1,18 @@
 // gemm.hip -- NT GEMM on MFMA for the Linear eps-rule (K1) and every other contraction that
 // is not attention.   C[M,N] = A[M,K] . B[N,K]^T (+bias), fp32 accumulate.
 //
-// Design (gfx950, wave64):
-//   * tile BM x BN = 128 x 128, K step = 128 BYTES per row (64 bf16 / 32 fp32), so the LDS
-//     image, the staging code and the bank-conflict analysis are dtype-independent;
-//   * 256 threads = 4 waves in a 2x2 grid, each wave a 64x64 sub-tile = 4x4 MFMA 16x16 tiles,
-//     operands swapped (mma(Bfrag, Afrag)) so a lane owns 4 CONSECUTIVE output columns of one
-//     row -> one 8/16-byte store per tile instead of four scalars;
-//   * LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row & 7): ds_write_b128 of
-//     8 consecutive lanes covers one full row, and every ds_read_b128 lane group touches 16
-//     distinct 16-B bank slots (conflict-free, checked per lane group of MI355X_MICROARCH LDS table);
-//   * global -> register -> LDS staging, double-buffered: the loads of tile t+1 are issued before
-//     the MFMAs of tile t and written to the other buffer after them; one barrier per K step;
-//   * 64 KiB LDS/block -> 2 blocks per CU; XCD-aware block remap keeps a B panel in one L2.
+// Kernels (gfx950, wave64), chosen by launch_fast():
+//   * gemm_pp.hip: 256 x 256 tile, 8 waves in two ping-pong groups, buffer_load .. lds staging -- the big bf16 problems (M = B*S rows);
+//   * gemm_nt_glds_kernel (below): TBM x TBN tile (128x128 / 64x64 / 32x32 / 256x256), direct-to-LDS staging (global_load_lds_dwordx4),
+//     K step = 128 BYTES per row for both dtypes (64 bf16 / 32 fp32), two LDS stages, one barrier per K step; fp32 operands accumulate
+//     in blocks (an fp32 MFMA chain is a sequential fmaf chain);
+//   * gemm_nt_kernel (below): 128 x 128, register-staged, for K that is not a whole number of 128-byte steps (ragged K).
+//   Common: operands swapped (mma(Bfrag, Afrag)) so a lane owns 4 CONSECUTIVE output columns of one row; LDS rows are 128 B with
+//   the 16-byte chunk index XOR-swizzled with (row & 7): every ds_read_b128 lane group touches 16 distinct 16-byte bank slots;
+//   XCD-aware block remap + grouped tile order keep an operand panel in one XCD's L2.
 #include "common.hpp"
 
-// gemm_pp.hip: 8-wave ping-pong kernel for the big bf16 problems (>= 190 tiles of 256 x 256)
+// gemm_pp.hip: 8-wave ping-pong kernel for the big bf16 problems (>= 190 tiles of 256 x 256; 32-bit buffer offsets)
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int out_dtype, hipStream_t st);
 
@@ -320,181 +317,9 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
 }
 
 
-// =================================================================================================
-// SOFTWARE-PIPELINED fragments for the 256x256 / 16-wave form (64x64 per wave, 128-byte K step, two LDS stages).
-// The plain form re-reads its fragments in batches behind s_waitcnt lgkmcnt(0) and, worse, starts every K step with all
-// four waves of a SIMD waiting on LDS right after the barrier (in-loop MFMA occupancy 2048/2400 = 85 %, tools/
-// gemm_timeline.py).  Here a wave keeps the four B fragments of the current 64-byte K chunk, streams the A fragments
-// through a 2-deep register buffer one MFMA group ahead, collects the B fragments of the NEXT chunk one per group, and the
-// step barrier sits before the last group: tile t+1 has landed by then (its loads were issued one step earlier), so the
-// first fragments of step t+1 are read under the last MFMAs of step t and the staging loads of t+2 go into the stage
-// just retired.  Register budget: 64 accumulators + 2 x 16 (B) + 2 x 4 (A) + addresses < 128.
-// =================================================================================================
-template <typename T, typename TO>
-__global__ __launch_bounds__(1024, 4) void gemm_nt_swp_kernel(
-    const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C, const T* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n) {
-    constexpr int TBM = 256, TBN = 256, WN = 4, NW = 16;
-    constexpr int EPC = 16 / sizeof(T), KE = KB / sizeof(T);
-    constexpr int SM = 64, SN = 64, FM = 4, FN = 4;
-    constexpr int GA = TBM / 8 / NW, GB = TBN / 8 / NW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = (TBM + TBN) * KB;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int ntile = tiles_m * tiles_n;
-    const int nkt = K / KE;                            // host guarantees nkt >= 2
-    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
-    const int frow = lane & 15, fq = lane >> 4;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    typedef typename Mma16<T>::frag frag_t;
-
-    int tm, tn;
-    grouped_tile(xcd_remap(blockIdx.x, ntile), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * TBM, n0 = tn * TBN;
-    const T* pa[GA];
-    const T* pb[GB];
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        int r = m0 + (wave * GA + i) * 8 + lrow;
-        r = r < M ? r : M - 1;
-        pa[i] = A + (int64_t)r * lda + lchunk * EPC;
-    }
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
-        int r = n0 + (wave * GB + i) * 8 + lrow;
-        r = r < N ? r : N - 1;
-        pb[i] = B + (int64_t)r * ldb + lchunk * EPC;
-    }
-    auto stage = [&](int kt, int buf) {
-        char* sa = smem + buf * STAGE + (wave * GA) * 1024;
-        char* sb = smem + buf * STAGE + TBM * KB + (wave * GB) * 1024;
-#pragma unroll
-        for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[i] + (int64_t)kt * KE), (lds_ptr_t)(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb[i] + (int64_t)kt * KE), (lds_ptr_t)(sb + i * 1024), 16, 0, 0);
-    };
-    // fragment addresses: row (i*16 + frow) of the wave's A / B rows, 16-byte chunk (kk*4 + fq) ^ (frow & 7)
-    const int offA = (wm * SM + frow) * KB, offB = TBM * KB + (wn * SN + frow) * KB;
-    const int sw0 = ((0 * 4 + fq) ^ (frow & 7)) << 4, sw1 = ((1 * 4 + fq) ^ (frow & 7)) << 4;
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mma_row = [&](int i, const frag_t& a, const frag_t (&b)[FN]) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = Mma16<T>::mma(b[j], a, acc[i][j]);
-    };
-#define LRP_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-    frag_t bP[FN], bQ[FN], a0, a1;                    // B of the even / odd K chunk, A double buffer
-    stage(0, 0);
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");       // tile 0 landed (tile 1 may still fly)
-    __builtin_amdgcn_s_barrier();
-    {
-        // fragment reads are inline-asm ds_read_b128 with HAND-COUNTED s_waitcnt lgkmcnt(n): the LDS returns in order, so
-        // "the fragment I need" = "all but the n younger reads"; the compiler's own bookkeeping falls back to lgkmcnt(0)
-        // right after fresh reads (exposing their latency) at the loop head and after each fence (+4.5 % in situ over
-        // plain C++ loads, profiles/r01_gemm_experiments.txt cfg 27 vs 28).  Issue order inside a group: B fragment first,
-        // A fragment last.
-#define LRP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
-#define LRP_WAIT(n, ...) asm volatile("s_waitcnt lgkmcnt(" #n ")" : __VA_ARGS__)
-        constexpr int RS = 16 * KB;                    // bytes between the fragment rows i and i+1 (2048)
-        const unsigned cA0 = offA + sw0, cA1 = offA + sw1, cB0 = offB + sw0, cB1 = offB + sw1;
-        unsigned A0c = cA0, A1c = cA1, B0n, B1c = cB1, A0n;    // current-stage addresses; B0n / A0n: next stage, chunk 0
-        LRP_DSRD(bP[0], cB0, 0); LRP_DSRD(bP[1], cB0, RS); LRP_DSRD(bP[2], cB0, 2 * RS); LRP_DSRD(bP[3], cB0, 3 * RS);
-        LRP_DSRD(a0, cA0, 0);
-        int cur = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            // ---- chunk 0 (B = bP); group (0,i): read bQ[i] then A(next), need A(cur): 2 younger reads
-            LRP_DSRD(bQ[0], B1c, 0);      LRP_DSRD(a1, A0c, RS);     LRP_WAIT(2, "+v"(a0), "+v"(bP[0]), "+v"(bP[1]), "+v"(bP[2]), "+v"(bP[3])); mma_row(0, a0, bP); LRP_FENCE();
-            LRP_DSRD(bQ[1], B1c, RS);     LRP_DSRD(a0, A0c, 2 * RS); LRP_WAIT(2, "+v"(a1)); mma_row(1, a1, bP); LRP_FENCE();
-            LRP_DSRD(bQ[2], B1c, 2 * RS); LRP_DSRD(a1, A0c, 3 * RS); LRP_WAIT(2, "+v"(a0)); mma_row(2, a0, bP); LRP_FENCE();
-            LRP_DSRD(bQ[3], B1c, 3 * RS); LRP_DSRD(a0, A1c, 0);      LRP_WAIT(2, "+v"(a1)); mma_row(3, a1, bP); LRP_FENCE();
-            // ---- chunk 1 (B = bQ); one read per group: 1 younger read
-            LRP_DSRD(a1, A1c, RS);     LRP_WAIT(1, "+v"(a0), "+v"(bQ[0]), "+v"(bQ[1]), "+v"(bQ[2]), "+v"(bQ[3])); mma_row(0, a0, bQ); LRP_FENCE();
-            LRP_DSRD(a0, A1c, 2 * RS); LRP_WAIT(1, "+v"(a1)); mma_row(1, a1, bQ); LRP_FENCE();
-            LRP_DSRD(a1, A1c, 3 * RS); LRP_WAIT(1, "+v"(a0)); mma_row(2, a0, bQ); LRP_FENCE();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a1) : : "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nkt) stage(kt + 2, cur);
-            cur ^= 1;
-            const unsigned base = (unsigned)cur * STAGE;
-            B0n = cB0 + base; A0n = cA0 + base;
-            // first fragments of the next tile (garbage-but-harmless re-read of a valid stage after the last tile)
-            LRP_DSRD(bP[0], B0n, 0); LRP_DSRD(bP[1], B0n, RS); LRP_DSRD(bP[2], B0n, 2 * RS); LRP_DSRD(bP[3], B0n, 3 * RS);
-            LRP_DSRD(a0, A0n, 0);
-            mma_row(3, a1, bQ); LRP_FENCE();
-            A0c = A0n; A1c = cA1 + base; B1c = cB1 + base;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef LRP_DSRD
-#undef LRP_WAIT
-    }
-#undef LRP_FENCE
-
-    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int gm = m0 + wm * SM + i * 16 + frow;
-        if (gm >= M) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int gn = n0 + wn * SN + j * 16 + fq * 4;
-            if (gn >= N) continue;
-            f32x4 v = acc[i][j];
-            if (bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (gn + r < N) v[r] += to_f32(bias[gn + r]);
-            }
-            TO* dst = C + (int64_t)gm * ldc + gn;
-            if (vec_ok && gn + 3 < N) {
-                if constexpr (sizeof(TO) == 4) {
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4*>(dst) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (gn + r < N) dst[r] = from_f32<TO>(v[r]);
-            }
-        }
-    }
-}
-
-template <typename T, typename TO>
-int launch_swp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-               int64_t ldc, hipStream_t st) {
-    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-    dim3 grid(tiles_m * tiles_n), block(1024);
-    const size_t lds = 2 * (size_t)512 * KB;
-    auto kern = gemm_nt_swp_kernel<T, TO>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
-                       tiles_m, tiles_n);
-    return lrp_check_launch();
-}
-
-// Tile selection (measured on MI355X, profiles/r01_gemm_tiles.txt, r01/r02_gemm_experiments.txt): the 256x256 16-wave kernel
-// with software-pipelined fragments once it yields >= ~190 tiles (every CU busy), the 128x128 4-wave kernel (2 workgroups
-// per CU) below that.  Everything else that was tried -- 26 structural variants, a 32x32x16-MFMA form -- lives in
-// csrc/dev/ and is not part of the library.
+// Tile selection (measured on MI355X, profiles/r01_gemm_tiles.txt, r01..r03_gemm_experiments.txt): the 256x256 8-wave ping-pong
+// kernel of gemm_pp.hip once the problem yields >= ~190 tiles (every CU busy), the 128x128 4-wave kernel (2 workgroups per
+// CU) below that.  Everything else that was tried is logged in profiles/ (the code of the losing variants is not kept).
 template <typename T, typename TO>
 int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
@@ -503,7 +328,7 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // fp32 is the parity path, not the throughput path (1/16 of the bf16 MFMA rate): always the 128x128 kernel, whose fp32
     // instantiation accumulates in blocks
     if (sizeof(T) == 2 && tiles256 >= 190) {
-        if (batch == 1 && K / KE >= 2)
+        if (batch == 1 && K / KE >= 2 && (int64_t)M * lda < (1ll << 30) && (int64_t)N * ldb < (1ll << 30))
             return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, st);
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }

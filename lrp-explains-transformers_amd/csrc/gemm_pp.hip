@@ -1,24 +1,30 @@
 // gemm_pp.hip -- the big bf16 NT GEMMs of the Linear eps-rule (K1 at M = B*S rows): C[M,N] = A[M,K] . B[N,K]^T (+bias),
-// fp32 accumulate, as an 8-wave PING-PONG kernel on v_mfma_f32_32x32x16_bf16.
+// fp32 accumulate, as an 8-wave PING-PONG kernel on v_mfma_f32_16x16x32_bf16.
 //
-// Why this structure (profiles/r01_gemm_experiments.txt, r02_gemm_experiments.txt): every lock-step form (4, 8 or 16 waves that
-// all read LDS, then all issue MFMAs) lands at 1.2-1.3 PFLOP/s because its MFMA-slot occupancy stops at ~63 %; the package runs at
-// its power cap, so only occupancy -- not latency hiding -- moves the number.  Here the 8 waves of a workgroup form two groups
-// of four (one wave of each group per SIMD) that run HALF A PHASE APART: while group X issues 16 back-to-back MFMAs (32x32x16:
-// a single wave issues them at the pipe rate, 32 cycles each; 16x16x32 would be issue-limited at 18.25/16), group Y reads its
-// next fragments out of LDS and issues the direct-to-LDS loads of a later K tile; then they swap.  A SIMD's matrix pipe always
-// has one wave feeding it; LDS reads, address arithmetic, waits and LDS-DMA issue all sit in the other wave's shadow.
+// What the measurements of rounds 1-3 say (profiles/r03_gemm_experiments.txt):
+//   * Every one of these GEMMs runs at the 1400 W package power cap; the clock the chip settles at is the free variable.  What counts is
+//     (matrix-pipe occupancy) x (clock), i.e. ENERGY per FLOP, not latency hiding alone.
+//   * A pure v_mfma_f32_16x16x32_bf16 stream on random operands settles at 2.13 GHz / 2.06 PFLOP/s, a v_mfma_f32_32x32x16_bf16 stream at
+//     1.84 GHz / 1.82 PFLOP/s (tools/micro/mfma_power.hip): the 16x16 form is 13 % cheaper per FLOP.  LDS fragment reads cost ~8 % per
+//     0.75 KiB read per 32 KFLOP (tools/micro/lds_power.hip); the staging traffic (L2 -> LDS, fabric, HBM) another 12-25 %.
+//   * Lock-step forms (4, 8 or 16 waves that all read LDS, then all issue MFMAs) stop at ~63 % occupancy.  Here the 8 waves of a
+//     workgroup form two groups of four (one wave of each group per SIMD) that run HALF A PHASE APART: while group X issues 32
+//     back-to-back MFMAs (a bare stream: one extra VALU / branch state between MFMAs costs 40-90 cycles), group Y reads its next
+//     fragments out of LDS and issues the direct-to-LDS loads of a later K tile; then they swap.  The skeleton {barrier, MFMA burst,
+//     barrier} alone runs at 100 % of the pipe (tools/micro/mfma32_pp.hip); this kernel reaches 94-96 % inside the K loop (the
+//     single-wave issue limit of the 16x16 form) and 88-91 % over a whole tile.
 //
-// Geometry: 256 x 256 tile, K tile = 64 elements (128 B per row), 512 threads.  Wave w: group g = w >> 2 (rows g*128 .. +127
-// of the tile), column block wc = w & 3 (columns wc*64 .. +63): 128 x 64 per wave = 2 row halves (a) x {2 x 2 MFMA tiles of
-// 32 x 32} = 128 accumulator registers.  One phase = one row half a of one K tile: L = 8 A-fragment reads (+ 8 B-fragment
-// reads when a = 0; the B fragments are kept for a = 1), M = 16 MFMAs (4 k-steps x 2 x 2 tiles).  Registers: 128 acc +
-// 32 (A) + 32 (B) fragments + 8 LDS addresses + 16 (source pointers).
+// Geometry: 256 x 256 tile, K tile = 64 elements (128 B per row: full cache lines per row visit), 512 threads.  Wave w: group g = w >> 2
+// (rows g*128 .. +127 of the tile), column block wc = w & 3 (columns wc*64 .. +63): 128 x 64 per wave = 2 row halves (a) x {4 x 4 MFMA
+// tiles of 16 x 16} = 128 accumulator registers.  One phase = one row half a of one K tile: L = 8 A-fragment reads (+ 8 B-fragment
+// reads when a = 0; the B fragments are kept for a = 1), M = 32 MFMAs (2 k-steps x 4 x 4 tiles).
 //
-// LDS (128 KiB): [A buf0][A buf1][B buf0][B buf1], 32 KiB each = 256 rows x 128 B.  Row r holds its eight 16-byte chunks at
-// slot = chunk ^ ((r >> 1) & 7): a 32-row fragment read (lane l: row l & 31, chunk 2 ks + (l >> 5)) is conflict-free under the
-// ds_read_b128 lane groups of the hardware (tests/test_layout_maps_cpu.py).  Direct-to-LDS loads write lane-linear 1-KiB pieces
-// (8 rows), so the swizzle is applied to the per-lane SOURCE chunk.  Every fragment address is a per-lane register + immediate.
+// LDS (128 KiB): [A buf0][A buf1][B buf0][B buf1], 32 KiB each = 256 rows x 128 B.  Row r holds its eight 16-byte chunks at position
+// chunk ^ (r & 7): a 16-row fragment read (lane l: row l & 15, chunk 4 ks + (l >> 4)) is conflict-free under the ds_read_b128 lane
+// groups of the hardware (tests/test_layout_maps_cpu.py).  Staging pieces are buffer_load_dwordx4 .. lds: one wave instruction writes a
+// lane-linear 1-KiB piece (8 rows), so the swizzle is applied to the per-lane SOURCE chunk; the row and K position sit in the scalar
+// offset (one per-lane offset register per operand, no 64-bit address arithmetic: a global_load_lds piece costs ~80 cycles of the L
+// phase, a buffer piece ~35); rows past M / N read as zero through num_records.
 //
 // Staging units per K tile t (unit order = issue order = consumption order):
 //     V0(t) = A rows of row half 0 of both groups (128 rows, 2 pieces per wave)
@@ -48,6 +54,20 @@ typedef const __attribute__((address_space(1))) void* pp_glb_ptr_t;
 // PP_TIMELINE (dev builds only, tools/gemm_ab.py): waves 0 and 4 of a few workgroups stamp s_memtime at the start of every
 // interval into the spare LDS above the 128 KiB of tiles and dump it through the `bias` pointer (which is then NOT a bias).
 #ifdef PP_TIMELINE
+#define PP_STAMP_ALWAYS()                                                                         \
+    if (tl_on) {                                                                                  \
+        const uint64_t tt_ = __builtin_amdgcn_s_memtime();                                        \
+        if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
+        ++tl_idx;                                                                                 \
+    }
+#define PP_STAMP_RT()                                                                             \
+    if (tl_on) {                                                                                  \
+        const uint64_t tt_ = __builtin_amdgcn_s_memrealtime();                                    \
+        if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
+        ++tl_idx;                                                                                 \
+    }
+#endif
+#if defined(PP_TIMELINE) && PP_TIMELINE == 1
 #define PP_STAMP()                                                                                \
     if (tl_on) {                                                                                  \
         const uint64_t tt_ = __builtin_amdgcn_s_memtime();                                        \
@@ -58,7 +78,11 @@ typedef const __attribute__((address_space(1))) void* pp_glb_ptr_t;
 #define PP_STAMP()
 #endif
 
+#ifdef PP_ABL_NOREAD
+#define PP_DSRD(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr), "n"(off))
+#else
 #define PP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 
 template <typename TO>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
@@ -73,70 +97,69 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
     grouped_tile(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
 
-    // ---- staging sources: piece = 8 rows x 128 B; lane l -> row (l >> 3), LDS slot (l & 7), source chunk slot ^ ((row >> 1) & 7)
-    // A pieces of this wave: rows g*128 + a*64 + (wc*16 + 8 p) .. + 7 (a = unit half, p = 0, 1); B pieces: rows wave*32 + 8 p (p = 0..3)
+    // ---- staging: piece = 8 rows x 128 B (one buffer_load_dwordx4 .. lds); lane l -> row (l >> 3), LDS position (l & 7), source chunk
+    // position ^ ((row >> 1) & 7).  A pieces of this wave: rows g*128 + a*64 + wc*16 + 8 p (a = unit half, p = 0, 1); B pieces: rows
+    // wave*32 + 8 p (p = 0..3).  Piece bases are multiples of 8 rows, so (row >> 1) & 7 = 4*(p & 1) + (l >> 4): two per-lane offsets per
+    // operand (even / odd piece); the row and K position go into the scalar offset; rows past M / N read as zero (num_records).
     const int prow = lane >> 3, pslot = lane & 7;
-    const bf16_t* srcA[2][2];
-    const bf16_t* srcB[4];
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)M * lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)N * ldb * 2), 0x00020000);
+    // 16-row fragments: position = chunk ^ (row & 7) (= prow for every piece: one offset per operand)
+    const int voA[2] = {(int)(prow * lda * 2) + ((pslot ^ prow) << 4), (int)(prow * lda * 2) + ((pslot ^ prow) << 4)};
+    const int voB[2] = {(int)(prow * ldb * 2) + ((pslot ^ prow) << 4), (int)(prow * ldb * 2) + ((pslot ^ prow) << 4)};
+    int soA[2][2], soB[4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = g * 128 + a * 64 + wc * 16 + 8 * p + prow;
-            int gr = m0 + r;
-            gr = gr < M ? gr : M - 1;
-            srcA[a][p] = A + (int64_t)gr * lda + ((pslot ^ ((r >> 1) & 7)) << 3);
-        }
+        for (int p = 0; p < 2; ++p) soA[a][p] = (int)((int64_t)(m0 + g * 128 + a * 64 + wc * 16 + 8 * p) * lda * 2);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = wave * 32 + 8 * p + prow;
-        int gr = n0 + r;
-        gr = gr < N ? gr : N - 1;
-        srcB[p] = B + (int64_t)gr * ldb + ((pslot ^ ((r >> 1) & 7)) << 3);
-    }
+    for (int p = 0; p < 4; ++p) soB[p] = (int)((int64_t)(n0 + wave * 32 + 8 * p) * ldb * 2);
     char* const ldsA = smem + (g * 128 + wc * 16) * 128;               // + buf*PP_OPND + a*8192 + p*1024
     char* const ldsB = smem + 2 * PP_OPND + (wave * 32) * 128;         // + buf*PP_OPND + p*1024
     auto stage_A = [&](int a, int kt, int buf) {
+#ifdef PP_ABL_NOGLDS
+        if (kt >= 2) return;
+#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_global_load_lds((pp_glb_ptr_t)(srcA[a][p] + (int64_t)kt * PP_KT),
-                                             (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, voA[p],
+                                                     soA[a][p] + kt * 128, 0, 0);
     };
     auto stage_B = [&](int kt, int buf) {
+#ifdef PP_ABL_NOGLDS
+        if (kt >= 2) return;
+#endif
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((pp_glb_ptr_t)(srcB[p] + (int64_t)kt * PP_KT),
-                                             (pp_lds_ptr_t)(ldsB + buf * PP_OPND + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (pp_lds_ptr_t)(ldsB + buf * PP_OPND + p * 1024), 16, voB[p & 1],
+                                                     soB[p] + kt * 128, 0, 0);
     };
 
-    // ---- fragment addresses: row (l & 31) of a 32-row block, chunk (2 ks + (l >> 5)) ^ ((l >> 1) & 7)
-    const int hi = lane >> 5, sw = (lane >> 1) & 7;
-    const unsigned rowA = (unsigned)((g * 128 + (lane & 31)) * 128), rowB = (unsigned)(2 * PP_OPND + (wc * 64 + (lane & 31)) * 128);
-    unsigned cA[4], cB[4];
+    // ---- fragment addresses: row (l & 15) of a 16-row block, chunk (4 ks + (l >> 4)) ^ (l & 7)
+    const int hi = lane >> 4;
+    const unsigned rowA = (unsigned)((g * 128 + (lane & 15)) * 128), rowB = (unsigned)(2 * PP_OPND + (wc * 64 + (lane & 15)) * 128);
+    unsigned cA[2], cB[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned c = (unsigned)(((2 * ks + hi) ^ sw) << 4);
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned c = (unsigned)(((4 * ks + hi) ^ (lane & 7)) << 4);
         cA[ks] = rowA + c;
         cB[ks] = rowB + c;
     }
-
-    f32x16 acc[2][2][2];
+    f32x4 acc[2][4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
-    bf16x8 fa[2][4], fb[2][4];                                          // [32-row block][k-step]
+            for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fb[4][2];                                          // [16-row block][k-step]
 
 #ifdef PP_TIMELINE
     const int tl_slot = (blockIdx.x == 0) ? 0 : (blockIdx.x == 101) ? 1 : (blockIdx.x == 257) ? 2 : -1;
     const bool tl_on = tl_slot >= 0 && (wave & 3) == 0;
     const unsigned tl_base = 4u * PP_OPND + (unsigned)g * 2048u;
     unsigned tl_idx = 0;
-    PP_STAMP()
+    PP_STAMP_ALWAYS()
 #endif
     // ---- prologue: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
     stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1);
@@ -145,24 +168,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
     if (g == 1) __builtin_amdgcn_s_barrier();                          // the half-phase offset between the two groups
 
 #define PP_READ_A(BUF, AH)                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
         PP_DSRD(fa[0][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192);                                \
-        PP_DSRD(fa[1][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192 + 4096);                         \
+        PP_DSRD(fa[1][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192 + 2048);                         \
+        PP_DSRD(fa[2][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192 + 4096);                         \
+        PP_DSRD(fa[3][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192 + 6144);                         \
     }
 #define PP_READ_B(BUF)                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
         PP_DSRD(fb[0][ks], cB[ks], (BUF) * PP_OPND);                                              \
-        PP_DSRD(fb[1][ks], cB[ks], (BUF) * PP_OPND + 4096);                                       \
+        PP_DSRD(fb[1][ks], cB[ks], (BUF) * PP_OPND + 2048);                                       \
+        PP_DSRD(fb[2][ks], cB[ks], (BUF) * PP_OPND + 4096);                                       \
+        PP_DSRD(fb[3][ks], cB[ks], (BUF) * PP_OPND + 6144);                                       \
     }
-#define PP_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),   \
-                                 "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]) :: "memory")
-#define PP_WAIT_B() asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]),                        \
-                                 "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]))
+#define PP_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),   \
+                                 "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]) :: "memory")
+#define PP_WAIT_B() asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),                        \
+                                 "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]))
 #define PP_MMA(AH)                                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                acc[AH][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[AH][i][j], 0, 0, 0);
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[AH][i][j], 0, 0, 0);
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #if PP_SETPRIO
 #define PP_PRIO(n) __builtin_amdgcn_s_setprio(n)
@@ -193,6 +220,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
         __builtin_amdgcn_s_barrier(); PP_FENCE(); PP_STAMP()                                      \
     }
 
+#if defined(PP_TIMELINE) && PP_TIMELINE == 2
+    PP_STAMP_RT()
+    PP_STAMP_ALWAYS()
+#endif
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
         PP_KTILE(0)
@@ -202,82 +233,79 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
     }
     if (t < nkt) PP_KTILE(0)
 
+#if defined(PP_TIMELINE) && PP_TIMELINE == 2
+    PP_STAMP_ALWAYS()
+#endif
 #ifdef PP_TIMELINE
     uint64_t* const tl_out = (uint64_t*)bias;
     bias = nullptr;
 #endif
-    // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + (l & 31)][n = .. + 8 q + 4 (l >> 5) + e], acc register 4 q + e
-    const int mrow = m0 + g * 128 + (lane & 31);
+    // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
+    const int mrow = m0 + g * 128 + (lane & 15);
     const int ncol = n0 + wc * 64;
     const bool full = (m0 + 256 <= M) && (n0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gm = mrow + a * 64 + i * 32;
+        for (int i = 0; i < 4; ++i) {
+            const int gm = mrow + a * 64 + i * 16;
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16 v = acc[a][i][j];
-                const int nb = ncol + j * 32;
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[a][i][j];
                 if (bias) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int gn = nb + 8 * q + 4 * hi + e;
-                            if (gn < N) v[4 * q + e] += to_f32(bias[gn]);
-                        }
-                }
-                if constexpr (sizeof(TO) == 4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int gn = nb + 8 * q + 4 * hi;
-                        TO* dst = C + (int64_t)gm * ldc + gn;
-                        if (full) {
-                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-                        } else if (gm < M) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (gn + e < N) dst[e] = v[4 * q + e];
-                        }
-                    }
-                } else {
-                    // pack to bf16, then pair the two lane halves (v_permlane32_swap) so that a lane stores 16 contiguous bytes:
-                    // lower half n = 16 qq .. + 7, upper half n = 16 qq + 8 .. + 15
-                    uint32_t w[4][2];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        bf16x2 p0 = {(bf16_t)v[4 * q], (bf16_t)v[4 * q + 1]}, p1 = {(bf16_t)v[4 * q + 2], (bf16_t)v[4 * q + 3]};
-                        w[q][0] = __builtin_bit_cast(uint32_t, p0);
-                        w[q][1] = __builtin_bit_cast(uint32_t, p1);
-                    }
-                    if (full) {
-#pragma unroll
-                        for (int qq = 0; qq < 2; ++qq) {
-                            uint32_t x0 = w[2 * qq][0], x1 = w[2 * qq][1], y0 = w[2 * qq + 1][0], y1 = w[2 * qq + 1][1];
-                            auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-                            auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-                            u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                            *reinterpret_cast<u32x4*>(C + (int64_t)gm * ldc + nb + 16 * qq + 8 * hi) = o;
-                        }
-                    } else if (gm < M) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int gn = nb + 8 * q + 4 * hi + e;
-                                if (gn < N) C[(int64_t)gm * ldc + gn] = (bf16_t)v[4 * q + e];
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const int gn = ncol + j * 16 + 4 * hi + e;
+                        if (gn < N) v[j][e] += to_f32(bias[gn]);
                     }
                 }
             }
+            if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gn = ncol + j * 16 + 4 * hi;
+                    TO* dst = C + (int64_t)gm * ldc + gn;
+                    if (full) {
+                        *reinterpret_cast<f32x4*>(dst) = v[j];
+                    } else if (gm < M) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gn + e < N) dst[e] = v[j][e];
+                    }
+                }
+            } else if (full) {
+                // pack to bf16 and pair the column tiles 2 jj, 2 jj + 1 with v_permlane16_swap (odd 16-lane rows of the first operand <->
+                // even rows of the second): lane row q then holds 8 consecutive columns, 16 (2 jj + (q & 1)) + 8 (q >> 1) .. + 7
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bf16x2 x0 = {(bf16_t)v[2 * jj][0], (bf16_t)v[2 * jj][1]}, x1 = {(bf16_t)v[2 * jj][2], (bf16_t)v[2 * jj][3]};
+                    bf16x2 y0 = {(bf16_t)v[2 * jj + 1][0], (bf16_t)v[2 * jj + 1][1]}, y1 = {(bf16_t)v[2 * jj + 1][2], (bf16_t)v[2 * jj + 1][3]};
+                    auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(C + (int64_t)gm * ldc + ncol + 32 * jj + 16 * (hi & 1) + 8 * (hi >> 1)) = o;
+                }
+            } else if (gm < M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gn = ncol + j * 16 + 4 * hi + e;
+                        if (gn < N) C[(int64_t)gm * ldc + gn] = (bf16_t)v[j][e];
+                    }
+            }
         }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA may outlive the workgroup's LDS allocation
 #ifdef PP_TIMELINE
     if (tl_on) {
-        PP_STAMP()                                                      // end of the C stores' issue
+        PP_STAMP_ALWAYS()                                               // end of the C stores' issue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PP_STAMP()                                                      // stores retired
+        PP_STAMP_ALWAYS()                                               // stores retired
+#if PP_TIMELINE == 2
+        PP_STAMP_RT()
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tl_out && lane < 3) {
             // lane 0..2 copy 64 stamps each

@@ -1,7 +1,8 @@
 """CPU: the LDS images the kernels rely on, restated as index arithmetic and checked against the bank model of
 MI355X_MICROARCH.md (64 banks x 4 B; ds_read_b128 is served in four fixed 16-lane groups, ds_read_b64_tr_b16 in two 32-lane groups;
 lanes of one group conflict when they touch the same bank at different addresses).  Pins the "conflict-free" claims of
-csrc/attention32.hip (rot4 chunk swizzle), csrc/gemm.hip (chunk ^ row&7) and csrc/dev/gemm_w4.hip (1056-byte blocks), and the row <-> fragment bijections."""
+csrc/attention32.hip (rot4 chunk swizzle), csrc/gemm.hip / csrc/gemm_pp.hip (chunk ^ row&7; staging units and epilogue lane pairing of the
+ping-pong GEMM), and the row <-> fragment bijections."""
 import itertools
 
 B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
@@ -60,23 +61,47 @@ def test_attention32_accumulator_rows_match_the_transpose_reads():
             assert rows == [base + 4 * hi + e for e in range(4)] + [base + 8 + 4 * hi + e for e in range(4)]
 
 
-def test_gemm_w4_block_image():
-    """LDS blocks of [8 rows][128 B] + 32 B pad: fragment (i, s) of lane l at block(l&15) + i*128 + s*64 + (l>>4)*16 is conflict-free,
-    the direct-to-LDS lane map fills a block with 8 consecutive rows, and fragment i <-> rows {8 q + i} is a bijection of 128 rows"""
-    BLK = 1056
-    for i, s_ in itertools.product(range(8), range(2)):
-        assert conflicts(lambda lane: (lane & 15) * BLK + i * 128 + s_ * 64 + (lane >> 4) * 16, B128_GROUPS, 16) == 0
-    # a 16-byte pad (1040: the lane groups mix k-chunks, so row 11 / chunk 1 meets row 12 / chunk 0) and no pad at all are conflicted
-    assert conflicts(lambda lane: (lane & 15) * 1040 + (lane >> 4) * 16, B128_GROUPS, 16) == 16
-    assert conflicts(lambda lane: (lane & 15) * 1024 + (lane >> 4) * 16, B128_GROUPS, 16) > 16
-    # DMA lane l -> (row 8 q + (l>>3), bytes 16 (l&7)) lands at l*16 inside block q = sub-row (l>>3), byte 16 (l&7)
-    for lane in range(64):
-        assert lane * 16 == (lane >> 3) * 128 + (lane & 7) * 16
-    rows = sorted(8 * q + i for q in range(16) for i in range(8))
-    assert rows == list(range(128))
-    # epilogue: lane (q, fq), register r of N-tile j holds column 8 (4 fq + r) + j: eight N-tiles = 8 consecutive columns
-    cols = sorted(8 * (4 * fq + r) + j for fq in range(4) for r in range(4) for j in range(8))
-    assert cols == list(range(128))
+def test_gemm_pp_lds_image_staging_map_and_epilogue():
+    """gemm_pp.hip (8-wave ping-pong GEMM): (1) LDS rows of 128 B with chunk ^ (row & 7): every fragment read of the wave's 8 A / 4 B blocks
+    is conflict-free; (2) the direct-to-LDS piece (lane l -> LDS byte 16 l = row l>>3, position l&7, SOURCE chunk (l&7) ^ (l>>3)) and the
+    fragment read apply the same involution: the reader of (row, chunk c) finds source chunk c; (3) the staging units V0, V1, V2 of the
+    eight waves tile the 256 A rows and 256 B rows exactly once; (4) the v_permlane16_swap pairing of the epilogue gives every lane
+    8 consecutive columns and the four lane rows tile the 32 columns of a tile pair"""
+    for ks, blk in itertools.product(range(2), range(8)):
+        assert conflicts(lambda lane: (blk * 16 + (lane & 15)) * 128 + ((((ks * 4) + (lane >> 4)) ^ (lane & 7)) << 4), B128_GROUPS, 16) == 0
+    # (2) piece base rows are multiples of 8, so (row & 7) == l >> 3 inside a piece
+    for base in range(0, 256, 8):
+        for lane in range(64):
+            row, pos = base + (lane >> 3), lane & 7
+            src_chunk = pos ^ (lane >> 3)
+            assert lane * 16 == (row - base) * 128 + pos * 16          # lane-linear LDS image of the piece
+            assert (src_chunk ^ (row & 7)) == pos                       # a reader of chunk c looks at position c ^ (row & 7)
+    # (3) units: wave w = (g, wc); A pieces rows g*128 + a*64 + wc*16 + 8 p (a, p in 0..1); B pieces rows w*32 + 8 p (p in 0..3)
+    a_rows, b_rows = [], []
+    for w in range(8):
+        g, wc = w >> 2, w & 3
+        for a_, p_ in itertools.product(range(2), range(2)):
+            a_rows += [g * 128 + a_ * 64 + wc * 16 + 8 * p_ + r for r in range(8)]
+        for p_ in range(4):
+            b_rows += [w * 32 + 8 * p_ + r for r in range(8)]
+    assert sorted(a_rows) == list(range(256)) and sorted(b_rows) == list(range(256))
+    # unit V0 (a = 0) holds exactly the rows the a = 0 phases of both groups read: g*128 + 0..63
+    v0 = sorted(g * 128 + wc * 16 + 8 * p_ + r for g in range(2) for wc in range(4) for p_ in range(2) for r in range(8))
+    assert v0 == sorted(g * 128 + r for g in range(2) for r in range(64))
+    # (4) lane row q (= lane >> 4) of column tiles (2 jj, 2 jj + 1): before the swap it holds columns 16 j + 4 q + e of tile j;
+    # v_permlane16_swap exchanges the ODD rows of x (tile 2 jj) with the EVEN rows of y (tile 2 jj + 1)
+    x = {q: [4 * q + e for e in range(4)] for q in range(4)}              # tile 2 jj
+    y = {q: [16 + 4 * q + e for e in range(4)] for q in range(4)}         # tile 2 jj + 1
+    x2, y2 = dict(x), dict(y)
+    x2[1], y2[0] = y[0], x[1]
+    x2[3], y2[2] = y[2], x[3]
+    cols = []
+    for q in range(4):
+        mine = x2[q] + y2[q]
+        start = 16 * (q & 1) + 8 * (q >> 1)                              # the store offset the kernel uses
+        assert mine == list(range(start, start + 8))
+        cols += mine
+    assert sorted(cols) == list(range(32))
 
 
 def test_gemm_product_chunk_swizzle():

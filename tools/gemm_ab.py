@@ -74,8 +74,33 @@ def check(fn, name):
     return worst
 
 
+def timeline_light(fn, name):
+    """PP2_TIMELINE == 2: stamps [start, realtime, loop start, loop end, stores issued, stores retired, realtime] (realtime: 100 MHz)"""
+    for (M, N, K) in [(8192, 28672, 4096), (8192, 4096, 14336), (8192, 4096, 4096), (8192, 14336, 4096)]:
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        b = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        tl = torch.zeros(3 * 2 * 192, device="cuda", dtype=torch.int64)
+        for _ in range(5):
+            call(fn, a, b, out, tl)
+        torch.cuda.synchronize()
+        t = tl.cpu().view(3, 2, 192)
+        nph = K // 32
+        for slot in range(3):
+            for g in range(2):
+                v = t[slot, g].tolist()
+                if v[0] == 0:
+                    continue
+                clk = (v[5] - v[0]) / max(1, (v[6] - v[1])) * 0.1          # GHz
+                loop = v[3] - v[2]
+                print(f"  light {name} N={N} K={K} wg {slot} g{g}: prologue {v[2] - v[0]}  loop {loop} = {loop / nph:.0f} per phase (ideal 1024: "
+                      f"{1024 * nph / loop * 100:.1f} % MFMA slots)  store issue {v[4] - v[3]}  drain {v[5] - v[4]}  total {v[5] - v[0]}"
+                      f"  ({1024 * nph / (v[5] - v[0]) * 100:.1f} %)  shader clock {clk:.2f} GHz", flush=True)
+
+
 def timeline(fn, name):
-    for (M, N, K) in [(8192, 28672, 4096), (8192, 4096, 14336), (8192, 28672, 2048)]:
+    """pp2 stamps: 0 = kernel start; then per phase: L end (before barrier), M start (after it), M end (before barrier), next L start"""
+    for (M, N, K) in [(8192, 28672, 4096), (8192, 4096, 14336), (8192, 28672, 1024)]:
         a = torch.randn(M, K, device="cuda").bfloat16()
         b = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -84,21 +109,28 @@ def timeline(fn, name):
             call(fn, a, b, out, tl)
         torch.cuda.synchronize()
         t = tl.cpu().view(3, 2, 192)
-        nkt = K // 64
-        nst = 1 + 4 * nkt
-        print(f"  timeline {name} N={N} K={K}: stamps per wave {nst} (prologue start, loop start, 4 per K tile ...)")
+        nph = K // 32
+        print(f"  timeline {name} N={N} K={K} ({nph} phases)")
         for slot in range(3):
             for g in range(2):
-                v = t[slot, g]
-                n = min(192, nst + 2)
-                d = (v[1:n] - v[:n - 1]).tolist()
+                v = t[slot, g].tolist()
                 if v[0] == 0:
                     continue
-                print(f"    wg-slot {slot} group {g}: prologue {d[0]}  first intervals {d[1:9]}  steady (median of stamps 20..180) "
-                      f"{sorted(d[20:180])[len(d[20:180]) // 2] if len(d) > 40 else -1}  max {max(d[20:180]) if len(d) > 40 else -1}"
-                      f"  mean {sum(d[20:180]) / max(1, len(d[20:180])):.0f}", flush=True)
-                if n >= nst + 2:
-                    print(f"      epilogue: store issue {d[nst - 1]}  store drain {d[nst]}  (total kernel span {int(v[n - 1] - v[0])})")
+                nfull = min(nph, (192 - 1) // 4)
+                Lb, w1, Mb, w2 = [], [], [], []
+                for ph in range(4, nfull - 1):            # steady state
+                    s0 = v[4 * ph]                        # start of this phase's L (== stamp after the previous barrier)
+                    a_, b_, c_, d_ = v[4 * ph + 1: 4 * ph + 5]
+                    Lb.append(a_ - s0); w1.append(b_ - a_); Mb.append(c_ - b_); w2.append(d_ - c_)
+                md = lambda x: sorted(x)[len(x) // 2] if x else -1      # noqa: E731
+                mean = lambda x: sum(x) / max(1, len(x))              # noqa: E731
+                per = mean(Lb) + mean(w1) + mean(Mb) + mean(w2)
+                msg = (f"    wg {slot} group {g}: first L {v[1] - v[0]}  | per phase (median / mean): L busy {md(Lb)}/{mean(Lb):.0f}  wait {md(w1)}/{mean(w1):.0f}"
+                       f"  M busy {md(Mb)}/{mean(Mb):.0f}  wait {md(w2)}/{mean(w2):.0f}  = {per:.0f} cycles per phase (2 intervals; ideal 1024)")
+                if 4 * nph + 2 < 192:
+                    e0 = v[4 * nph]
+                    msg += f" | epilogue: store issue {v[4 * nph + 1] - e0} drain {v[4 * nph + 2] - v[4 * nph + 1]} | kernel span {v[4 * nph + 2] - v[0]}"
+                print(msg, flush=True)
 
 
 if __name__ == "__main__":
@@ -114,9 +146,11 @@ if __name__ == "__main__":
         name, path = spec.split("=", 1)
         libs.append((name, load(path)))
     for name, fn in libs:
-        if name.startswith("tl"):
+        if name.startswith("tll"):
+            timeline_light(fn, name)
+        elif name.startswith("tl"):
             timeline(fn, name)
-        elif not a_.no_check:
+        elif not a_.no_check and not name.startswith("x_"):
             check(fn, name)
     libs = [(n, f) for (n, f) in libs if not n.startswith("tl")]
     res = {}
