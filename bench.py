@@ -141,6 +141,28 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
             "one_pass_fused": fused}
 
 
+def config5_probe(eng, ops, cfg, dev, peak, steps=3):
+    """BASELINE config 5's per-GPU workload (Llama-3-8B, seq = 4096; the 1024-prompt job is sharded 128 prompts per GPU, explained here
+    2 prompts per step) AFTER and OUTSIDE the headline timed region: explanations/s and the GEMM's roofline fraction at S = 4096."""
+    S5, B5 = 4096, 2
+    ids = torch.randint(0, cfg["vocab"], (B5 * (steps + 1), S5), generator=torch.Generator().manual_seed(4321)).to(dev)
+    R = eng.explain(ids[:B5])["R_tok"]
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(steps):
+        R = eng.explain(ids[(i + 1) * B5: (i + 2) * B5])["R_tok"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    n_launch, flops, secs = timer.summary()
+    assert torch.isfinite(R).all()
+    return {"workload": f"seq={S5}, {B5} prompts per step, {steps} steps after the headline region (same engine, same weights)",
+            "value": B5 * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3,
+            "gemm_TFLOPs": flops / secs / 1e12, "gemm_frac_of_peak": flops / secs / 1e12 / peak, "gemm_time_frac_of_step": secs / el}
+
+
 def dry_run(args):
     """the N-rank control flow of main() with the explanation replaced by a pure function of the ids (no engine, no device):
     what torch.distributed.run + this script must get right before any kernel matters"""
@@ -194,6 +216,7 @@ def main():
     ap.add_argument("--mode", default="efficient", choices=["efficient", "explicit"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing self-test WITHOUT kernels or a GPU (gloo): rank env, sharding, barrier, max-over-ranks, gather, "
@@ -215,7 +238,7 @@ def main():
     cfg = dict(LLAMA3_8B, n_layers=args.layers)
 
     W = synth_weights(cfg, dev, dtype, seed=0)
-    eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=args.seq, sparse_top=not args.dense_top)
+    eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=max(args.seq, 4096), sparse_top=not args.dense_top)
     del W
     torch.cuda.empty_cache()
     if world > 1:
@@ -289,6 +312,8 @@ def main():
             "config": {"workload": f"Llama-3-8B shape ({cfg['n_layers']} layers, H4096, I14336, 32/8 heads, V128256), "
                                    f"random init, lxt.{args.mode} rule placement, seq={S}, causal, last-position arg-max logit",
                        "seq_len": S, "prompts_per_gpu_per_step": B, "global_batch": n_total, "mode": args.mode,
+                       "activation_policy": "stash: every Linear output z, q/k before and after RoPE, o, lse and the residual sums are kept in HBM "
+                                            "by the forward (~0.3 GB per layer and prompt); the backward recomputes no GEMM (DESIGN.md section 3)",
                        "parallelism": f"dp{world} (prompt sharding, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": "lrp_gemm_nt: gemm_nt_pp_kernel / gemm_nt_glds_kernel (Linear forward + eps-rule dgrad)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -296,6 +321,8 @@ def main():
                          "gemm_time_frac_of_step": secs / elapsed, "traffic": pmc_traffic()},
         }
         line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
+        if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16:
+            line["config5_seq4096"] = config5_probe(eng, ops, cfg, dev, peak)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Fixture generator for the BASELINE-size GPU tests (tests/test_baseline_size_gpu.py): the fp64 oracle (oracle/llama.py, pinned
+against the imported reference by make_golden.py) is expensive at H 4096 / I 14336 / S 2048-4096 (~1-4 minutes per evaluation on the
+host), so its outputs are computed ONCE here and cached as small fixtures:
+
+  baseline_s2048_seed{W}_{I}.npz   three instances (weights seed, ids seed) = (20,21), (22,23), (24,25), S = 2048, 2 layers:
+        per mode (explicit / efficient): fp64 R_tok [S], layer_R [L+1], R_emb on 32 sampled token rows, the reference ARITHMETIC's own
+        fp32-vs-fp64 gap (token / sampled neuron / layer) and, for explicit, two draws of the fp64 oracle under fp32-sized activation
+        noise (tests/util.fp32_conditioning) -- the yard-sticks of the multi-seed explicit test.
+  baseline_s4096_seed30.npz        BASELINE config 5's sequence length: S = 4096, two prompts, efficient placement, fp64 R_tok / layer_R.
+The synthetic weights are regenerated from the seed on the GPU box and checked against `wsum`; if that check fails there (a different
+CPU RNG stream) the tests fall back to running the oracle themselves."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import llama as ol  # noqa: E402
+from tests.util import nmax  # noqa: E402
+
+CFG = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=2048, rope_theta=500000.0, rms_eps=1e-5)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def wsum(W):
+    tot = float(W["embed"].double().abs().sum() + W["lm_head"].double().abs().sum())
+    for L in W["layers"]:
+        tot += sum(float(v.double().abs().sum()) for v in L.values())
+    return tot
+
+
+def run(W, ids, dtype, modes, target=None, rnd=None):
+    Wd = ol.cast_weights(W, dtype)
+    emb = Wd["embed"][ids]
+    cache = ol.forward(CFG, Wd, emb, rnd=rnd)
+    idx = int(cache["logits_last"].argmax()) if target is None else target
+    out = {}
+    for mode in modes:
+        G, layer_R = ol.backward(CFG, Wd, cache, idx, mode, rnd=rnd)
+        R_emb = emb * G
+        out[mode] = dict(R_tok=R_emb.sum(-1).double(), R_emb=R_emb.double(), layer_R=torch.tensor(layer_R, dtype=torch.float64))
+    return out, idx, float(cache["logits_last"][idx])
+
+
+def s2048(wseed, idseed):
+    S = 2048
+    t0 = time.time()
+    W = ol.random_weights(CFG, seed=wseed)
+    ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(idseed))
+    rows = torch.randperm(S, generator=torch.Generator().manual_seed(7))[:32].sort().values
+    modes = ("explicit", "efficient")
+    r64, idx, logit = run(W, ids, torch.float64, modes)
+    r32, _, _ = run(W, ids, torch.float32, modes, target=idx)
+    d = dict(wseed=wseed, idseed=idseed, wsum=wsum(W), ids=ids.numpy(), idx=idx, logit=logit, rows=rows.numpy(),
+             cfg_keys=np.array(list(CFG.keys())), cfg_vals=np.array([float(v) for v in CFG.values()]))
+    for m in modes:
+        d[f"{m}_R_tok"] = r64[m]["R_tok"].numpy()
+        d[f"{m}_layer_R"] = r64[m]["layer_R"].numpy()
+        d[f"{m}_R_emb_rows"] = r64[m]["R_emb"][rows].numpy().astype(np.float32)
+        d[f"{m}_R_emb_absmax"] = float(r64[m]["R_emb"].abs().max())
+        d[f"{m}_gap"] = np.array([nmax(r32[m]["R_tok"], r64[m]["R_tok"]), nmax(r32[m]["R_emb"], r64[m]["R_emb"]),
+                                  nmax(r32[m]["layer_R"], r64[m]["layer_R"])])
+    draws = []
+    for k in range(2):
+        g = torch.Generator().manual_seed(1000 + k)
+        rn, _, _ = run(W, ids, torch.float64, ("explicit",), target=idx,
+                       rnd=lambda x: x * (1 + 3e-7 * torch.randn(x.shape, generator=g, dtype=x.dtype)))
+        draws.append(nmax(rn["explicit"]["R_tok"], r64["explicit"]["R_tok"]))
+    d["explicit_noise_draws"] = np.array(draws)
+    print(f"S=2048 seeds ({wseed},{idseed}): idx {idx} logit {logit:+.6f}; reference-arithmetic fp32 gap explicit {d['explicit_gap']} efficient "
+          f"{d['efficient_gap']}; noise draws {draws}; {time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"baseline_s2048_seed{wseed}_{idseed}.npz"), **d)
+
+
+def s4096(wseed=30):
+    S = 4096
+    t0 = time.time()
+    W = ol.random_weights(CFG, seed=wseed)
+    d = dict(wseed=wseed, wsum=wsum(W), cfg_keys=np.array(list(CFG.keys())), cfg_vals=np.array([float(v) for v in CFG.values()]))
+    ids_all, R, LR, idxs, logits = [], [], [], [], []
+    for p, idseed in enumerate((31, 32)):
+        ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(idseed))
+        r64, idx, logit = run(W, ids, torch.float64, ("efficient",))
+        ids_all.append(ids.numpy()); R.append(r64["efficient"]["R_tok"].numpy()); LR.append(r64["efficient"]["layer_R"].numpy())
+        idxs.append(idx); logits.append(logit)
+        print(f"S=4096 prompt {p}: idx {idx} logit {logit:+.6f} sum R {float(r64['efficient']['R_tok'].sum()):+.6f}; {time.time() - t0:.0f} s", flush=True)
+    d.update(ids=np.stack(ids_all), efficient_R_tok=np.stack(R), efficient_layer_R=np.stack(LR), idx=np.array(idxs), logit=np.array(logits))
+    np.savez_compressed(os.path.join(OUT, f"baseline_s4096_seed{wseed}.npz"), **d)
+
+
+def s2048_bf16(wseed=20, idseed=21):
+    """the bf16 test's references: fp64 oracle on the bf16-ROUNDED weights, and the same oracle in fp32 with every stored activation
+    rounded to bf16 (the floor any bf16 evaluation has)"""
+    S = 2048
+    W = ol.random_weights(CFG, seed=wseed)
+    ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(idseed))
+    Wb = ol.cast_weights(ol.cast_weights(W, torch.bfloat16), torch.float32)
+    ref, idx, logit = run(Wb, ids, torch.float64, ("efficient",))
+    stor, _, _ = run(Wb, ids, torch.float32, ("efficient",), target=idx, rnd=ol.round_through(torch.bfloat16))
+    floor = nmax(stor["efficient"]["R_tok"], ref["efficient"]["R_tok"])
+    print(f"S=2048 bf16 weights seeds ({wseed},{idseed}): idx {idx}, bf16-storage floor {floor:.2e}", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"baseline_s2048_seed{wseed}_{idseed}_bf16.npz"), wsum=wsum(W), ids=ids.numpy(), idx=idx, logit=logit,
+                        efficient_R_tok=ref["efficient"]["R_tok"].numpy(), floor=floor)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["20", "22", "24", "4096"]
+    for w in which:
+        if w == "4096":
+            s4096()
+        elif w == "bf16":
+            s2048_bf16()
+        else:
+            s2048(int(w), int(w) + 1)

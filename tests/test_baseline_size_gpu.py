@@ -44,16 +44,42 @@ def _oracle_both_modes(W, ids, dtype, target=None, rnd=None, modes=("explicit", 
     return out, idx, float(cache["logits_last"][idx])
 
 
-SEEDS = ((20, 21),)        # (weights, ids)
+SEEDS = ((20, 21), (22, 23), (24, 25))        # (weights, ids); the module fixture `case` is the first one
+
+
+def _wsum(W):
+    tot = float(W["embed"].double().abs().sum() + W["lm_head"].double().abs().sum())
+    for L in W["layers"]:
+        tot += sum(float(v.double().abs().sum()) for v in L.values())
+    return tot
+
+
+def _cached(wseed, idseed):
+    """the fp64 oracle outputs frozen by tests/golden/make_golden_baseline.py (4-5 minutes of host time per instance), valid when the
+    synthetic weights regenerate bit-identically here (checked through the recorded |W| sum); None -> run the oracle"""
+    from tests.util import GOLDEN
+    path = os.path.join(GOLDEN, f"baseline_s2048_seed{wseed}_{idseed}.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
 
 
 def _instance(wseed, idseed, modes):
     W = ol.random_weights(CFG, seed=wseed)
     ids = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(idseed))
+    fx = _cached(wseed, idseed)
+    if fx is not None and abs(_wsum(W) - float(fx["wsum"])) <= 1e-9 * float(fx["wsum"]) and np.array_equal(fx["ids"], ids.numpy()):
+        rows = torch.from_numpy(fx["rows"])
+        ref64 = {m: dict(R_tok=torch.from_numpy(fx[f"{m}_R_tok"]), layer_R=torch.from_numpy(fx[f"{m}_layer_R"]),
+                         R_emb_rows=torch.from_numpy(fx[f"{m}_R_emb_rows"]).double(), R_emb_absmax=float(fx[f"{m}_R_emb_absmax"])) for m in modes}
+        gap = {m: dict(R_tok=float(fx[f"{m}_gap"][0]), R_emb=float(fx[f"{m}_gap"][1]), layer_R=float(fx[f"{m}_gap"][2])) for m in modes}
+        return dict(W=W, ids=ids, idx=int(fx["idx"]), logit=float(fx["logit"]), ref64=ref64, gap=gap, rows=rows, cached=True,
+                    noise=[float(x) for x in fx["explicit_noise_draws"]])
     ref64, idx, logit = _oracle_both_modes(W, ids, torch.float64, modes=modes)
     ref32, _, _ = _oracle_both_modes(W, ids, torch.float32, target=idx, modes=modes)
     gap = {m: {k: nmax(ref32[m][k], ref64[m][k]) for k in ("R_tok", "R_emb", "layer_R")} for m in ref64}
-    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap)
+    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap, rows=None, cached=False, noise=None)
 
 
 @pytest.fixture(scope="module")
@@ -63,7 +89,7 @@ def case():
     t0 = time.time()
     c = _instance(*SEEDS[0], modes=("explicit", "efficient"))
     gap = c["gap"]
-    print(f"[baseline-size oracle] fp64 + fp32 runs in {time.time() - t0:.1f} s on {torch.get_num_threads()} host threads; "
+    print(f"[baseline-size oracle] {'cached fixture' if c['cached'] else 'fp64 + fp32 runs'} in {time.time() - t0:.1f} s on {torch.get_num_threads()} host threads; "
           f"oracle's own fp32-vs-fp64 gap (token / neuron / layer): explicit {gap['explicit']['R_tok']:.1e} / "
           f"{gap['explicit']['R_emb']:.1e} / {gap['explicit']['layer_R']:.1e}, efficient {gap['efficient']['R_tok']:.1e} / "
           f"{gap['efficient']['R_emb']:.1e} / {gap['efficient']['layer_R']:.1e}")
@@ -77,8 +103,12 @@ def _engine_errors(c, mode):
     ref = c["ref64"][mode]
     assert int(out["idx"][0]) == c["idx"]
     assert abs(float(out["logit"][0]) - c["logit"]) < 1e-4 * max(1.0, abs(c["logit"]))
-    err = dict(R_tok=nmax(out["R_tok"][0], ref["R_tok"]), R_emb=nmax(out["emb"][0].double() * out["G_emb"][0].double(), ref["R_emb"]),
-               layer_R=nmax(out["layer_R"][:, 0], ref["layer_R"]))
+    R_emb = out["emb"][0].double() * out["G_emb"][0].double()
+    if c["rows"] is not None:      # cached oracle: per-neuron relevance on the 32 sampled token rows, normalised by the full tensor's max
+        e_emb = float((R_emb.cpu()[c["rows"]] - ref["R_emb_rows"]).abs().max() / ref["R_emb_absmax"])
+    else:
+        e_emb = nmax(R_emb, ref["R_emb"])
+    err = dict(R_tok=nmax(out["R_tok"][0], ref["R_tok"]), R_emb=e_emb, layer_R=nmax(out["layer_R"][:, 0], ref["layer_R"]))
     del eng, out
     torch.cuda.empty_cache()
     return err
@@ -103,7 +133,10 @@ def test_engine_fp32_full_width_explicit_vs_oracle(case):
     conditioning allows it.  The reference's fp32-vs-fp64 gap on the same instance is printed next to it."""
     from tests.util import fp32_conditioning
     err, gap = _engine_errors(case, "explicit"), case["gap"]["explicit"]
-    cond = fp32_conditioning(CFG, case["W"], case["ids"], case["idx"], "explicit", ref64=case["ref64"]["explicit"]["R_tok"], draws=2)
+    if case["noise"] is not None:
+        cond = max(case["noise"])
+    else:
+        cond = fp32_conditioning(CFG, case["W"], case["ids"], case["idx"], "explicit", ref64=case["ref64"]["explicit"]["R_tok"], draws=2)
     print(f"[H4096/S2048 fp32 explicit seeds {SEEDS[0]}] token {err['R_tok']:.2e} | neuron {err['R_emb']:.2e} | layer {err['layer_R']:.2e} "
           f"(instance fp32 conditioning {cond:.1e}; the reference's own fp32-vs-fp64 gap: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
     assert err["R_tok"] < max(1e-4, 5 * cond) and err["layer_R"] < max(1e-4, 5 * cond)
@@ -115,10 +148,16 @@ def test_engine_bf16_full_width_vs_oracle(case):
     Bar: 5x the oracle's own error when its activations are stored in bf16 (fp32 arithmetic between the stores) -- the
     floor any bf16 evaluation of this instance has, including the reference's own bf16 run -- and never above 5e-2."""
     import lxt_amd.engine as E
-    Wb = ol.cast_weights(ol.cast_weights(case["W"], torch.bfloat16), torch.float32)
-    ref, idx, _ = _oracle_both_modes(Wb, case["ids"], torch.float64, modes=("efficient",))
-    stor, _, _ = _oracle_both_modes(Wb, case["ids"], torch.float32, target=idx, rnd=ol.round_through(torch.bfloat16), modes=("efficient",))
-    floor = nmax(stor["efficient"]["R_tok"], ref["efficient"]["R_tok"])
+    from tests.util import GOLDEN
+    path = os.path.join(GOLDEN, f"baseline_s2048_seed{SEEDS[0][0]}_{SEEDS[0][1]}_bf16.npz")
+    if case["cached"] and os.path.exists(path):
+        z = np.load(path)
+        ref, idx, floor = {"efficient": dict(R_tok=torch.from_numpy(z["efficient_R_tok"]))}, int(z["idx"]), float(z["floor"])
+    else:
+        Wb = ol.cast_weights(ol.cast_weights(case["W"], torch.bfloat16), torch.float32)
+        ref, idx, _ = _oracle_both_modes(Wb, case["ids"], torch.float64, modes=("efficient",))
+        stor, _, _ = _oracle_both_modes(Wb, case["ids"], torch.float32, target=idx, rnd=ol.round_through(torch.bfloat16), modes=("efficient",))
+        floor = nmax(stor["efficient"]["R_tok"], ref["efficient"]["R_tok"])
     eng = E.LlamaLRP(CFG, case["W"], dtype=torch.bfloat16, mode="efficient", max_seq=S)
     out = eng.explain(case["ids"][None], target=torch.tensor([idx]))
     e_tok = nmax(out["R_tok"][0], ref["efficient"]["R_tok"])
@@ -144,6 +183,69 @@ def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
                        text=True, timeout=1500, cwd=ROOT)
     print(r.stdout[-1200:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_engine_fp32_full_width_three_seeds(case):
+    """the committed evidence is all three instances, not the best one.  Efficient placement: 1e-4 on every seed.  Explicit
+    placement: the engine's error beside the reference ARITHMETIC's own fp32-vs-fp64 gap and two draws of the fp64 oracle under
+    fp32-sized activation noise, per seed; asserted: on every seed the engine is within 5x the largest of those three numbers (each of
+    them is one draw of the same heavy-tailed quantity -- z/(z + eps) poles), and over the three seeds its
+    geometric-mean error is within 3x the reference arithmetic's."""
+    import math
+    table = []
+    for (ws, ids_) in SEEDS:
+        c = case if (ws, ids_) == SEEDS[0] else _instance(ws, ids_, modes=("explicit", "efficient"))
+        eff, exp = _engine_errors(c, "efficient"), _engine_errors(c, "explicit")
+        noise = c["noise"] or []
+        table.append((ws, ids_, eff, exp, c["gap"], noise))
+        print(f"[H4096/S2048 fp32 seeds ({ws},{ids_})] efficient token {eff['R_tok']:.2e} neuron {eff['R_emb']:.2e} layer {eff['layer_R']:.2e} | "
+              f"explicit token {exp['R_tok']:.2e} neuron {exp['R_emb']:.2e} layer {exp['layer_R']:.2e} | reference arithmetic fp32 gap (explicit) "
+              f"{c['gap']['explicit']['R_tok']:.1e} / {c['gap']['explicit']['R_emb']:.1e} / {c['gap']['explicit']['layer_R']:.1e}; noise-model draws "
+              + " ".join(f"{x:.1e}" for x in noise))
+        del c
+    for ws, ids_, eff, exp, gap, noise in table:
+        assert max(eff.values()) < 1e-4, (ws, eff)
+        yard = max([gap["explicit"]["R_tok"]] + list(noise))
+        assert exp["R_tok"] < max(1e-4, 5 * yard), (ws, exp, yard)
+    gm = lambda v: math.exp(sum(math.log(max(x, 1e-30)) for x in v) / len(v))      # noqa: E731
+    ge, gr = gm([t[3]["R_tok"] for t in table]), gm([t[4]["explicit"]["R_tok"] for t in table])
+    print(f"[H4096/S2048 fp32 explicit, 3 seeds] geometric mean: engine {ge:.2e}, reference arithmetic in fp32 {gr:.2e}")
+    assert ge < max(1e-4, 3 * gr)
+
+
+def test_engine_s4096_config5_efficient_vs_oracle():
+    """BASELINE config 5's sequence length at ENGINE level: H 4096 / I 14336 / 32+8 heads / d 128, two layers, S = 4096, two prompts in
+    one call (ref protocol: docs/source/quickstart.rst:120-141): fp32 efficient placement against the fp64 oracle (cached fixture
+    baseline_s4096_seed30.npz) < 1e-4 per token and per layer; bf16: the batched call equals the single-prompt calls, token
+    relevance sums to the latent relevance at the embedding, and stays close to the fp32 result."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.engine as E
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "baseline_s4096_seed30.npz"))
+    W = ol.random_weights(CFG, seed=int(z["wseed"]))
+    if abs(_wsum(W) - float(z["wsum"])) > 1e-9 * float(z["wsum"]):
+        pytest.skip("synthetic weights did not regenerate bit-identically on this host (cached oracle unusable)")
+    ids = torch.from_numpy(z["ids"])
+    eng = E.LlamaLRP(CFG, W, dtype=torch.float32, mode="efficient", max_seq=4096)
+    out = eng.explain(ids, layer_relevance=True)
+    for b in range(2):
+        assert int(out["idx"][b]) == int(z["idx"][b]) and abs(float(out["logit"][b]) - float(z["logit"][b])) < 1e-4 * max(1.0, abs(float(z["logit"][b])))
+        e_tok, e_lay = nmax(out["R_tok"][b], z["efficient_R_tok"][b]), nmax(out["layer_R"][:, b], z["efficient_layer_R"][b])
+        print(f"[H4096/S4096 fp32 efficient, prompt {b}] token {e_tok:.2e} | layer {e_lay:.2e}")
+        assert e_tok < 1e-4 and e_lay < 1e-4
+    R32 = out["R_tok"].double().cpu()
+    del eng, out
+    torch.cuda.empty_cache()
+    eng = E.LlamaLRP(CFG, W, dtype=torch.bfloat16, mode="efficient", max_seq=4096)
+    both = eng.explain(ids, target=torch.from_numpy(z["idx"]), layer_relevance=True)
+    for b in range(2):
+        one = eng.explain(ids[b: b + 1], target=torch.from_numpy(z["idx"][b: b + 1]))
+        e_b = nmax(both["R_tok"][b], one["R_tok"][0])
+        cons = abs(float(both["R_tok"][b].double().sum()) - float(both["layer_R"][0, b])) / abs(float(both["layer_R"][0, b]))
+        e32 = nmax(both["R_tok"][b], R32[b])
+        print(f"[H4096/S4096 bf16 efficient, prompt {b}] batched vs single {e_b:.2e} | sum_t R_t vs latent relevance at the embedding {cons:.2e} | vs fp32 {e32:.2e}")
+        assert e_b < 2e-2 and cons < 2e-2 and e32 < 5e-2 and torch.isfinite(both["R_tok"]).all()
 
 
 # ------------------------------------------------------------------------------ (d) attention kernels at S = 2048 / 4096
