@@ -62,6 +62,22 @@ int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
                 int batch, int64_t sA, int64_t sB, int64_t sC,
                 int dtype, int out_dtype, void* stream);
 
+/* lrp_gemm_nn: C[M,N] = A[M,K] . Bt[K,N] (+ bias[N]) -- the eps-rule's redistribution  c = s W  with W in its STORED forward layout
+ * [out, in] as Bt (contraction over W's rows): no W^T copy of a weight exists anywhere.  bf16 operands, out bf16 / fp32, K a multiple
+ * of 64 (>= 128), operands below 2^30 elements; other shapes return LRP_ESHAPE (the caller then transposes once and uses lrp_gemm_nt).
+ * ref: lxt/explicit/functional.py:355-364 (backward of linear_epsilon_fn: `relevance_norm @ weight`). */
+int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int dtype, int out_dtype, void* stream);
+
+/* lrp_gemm_skinny: the same two products for 1 <= M <= 256 rows (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic
+ * intensity ~2 M FLOP/B in bf16): split-K over the K tiles so that every CU streams its share of the weight exactly once, fp32 partial
+ * slabs in `ws` (lrp_gemm_skinny_ws(M,N,K) BYTES, caller-allocated), reduced (+ bias, cast) by a second small kernel.
+ *   nn = 0: C = A[M,K] . B[N,K]^T (forward z = x W^T);   nn = 1: C = A[M,K] . B[K,N] (redistribution c = s W, W as stored).
+ * Same operand restrictions as lrp_gemm_nn.  ref: lxt/explicit/functional.py:351 (forward), :355-364 (backward). */
+int64_t lrp_gemm_skinny_ws(int M, int N, int K);
+int lrp_gemm_skinny(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                    int64_t ldc, int nn, int dtype, int out_dtype, void* ws, void* stream);
+
 /* out = g (*) z/(c z + eps)      (mode 0: gradient form; eps==0 -> g/c)
  * out = r / (c z + eps)          (mode 1: relevance form, the reference's R_out/(z+eps))
  * ref: lxt/explicit/functional.py:360 (linear), :403 (matmul, c=2), :445 (add2) */

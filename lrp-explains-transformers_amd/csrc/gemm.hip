@@ -14,7 +14,7 @@
 
 // gemm_pp.hip: 8-wave ping-pong kernel for the big bf16 problems (>= 190 tiles of 256 x 256; 32-bit buffer offsets)
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                       int64_t ldc, int out_dtype, hipStream_t st);
+                       int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st);
 
 namespace {
 
@@ -329,7 +329,7 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // instantiation accumulates in blocks
     if (sizeof(T) == 2 && tiles256 >= 190) {
         if (batch == 1 && K / KE >= 2 && (int64_t)M * lda < (1ll << 30) && (int64_t)N * ldb < (1ll << 30))
-            return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, st);
+            return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, 0, 1, K / KE, 0, st);
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }
     // small problems (BERT-sized M = 128: 6..24 tiles of 128x128 on 256 CUs, each walking the whole K alone): 64x64 or 32x32
@@ -395,3 +395,82 @@ extern "C" int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bi
         return launch_gemm<bf16_t, bf16_t>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     return LRP_EINVAL;
 }
+
+// =================================================================================================
+// NN form and the skinny (split-K) dispatch of the ping-pong kernel (gemm_pp.hip)
+// =================================================================================================
+namespace {
+
+// out[m][n] = sum_s slab[s][m][n] (+ bias[n]), cast to TO; slabs are [M][ldw] fp32, ldw % 4 == 0
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ bias, TO* __restrict__ out, int M, int N,
+                                     int64_t ldw, int64_t ldo, int splits, int64_t slab) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one float4 of one row
+    const int nq = (N + 3) / 4;
+    if (q >= (int64_t)M * nq) return;
+    const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+    const float* p = ws + (int64_t)m * ldw + n;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+    for (int s_ = 1; s_ < splits; ++s_) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s_ * slab);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (n + e < N) out[(int64_t)m * ldo + n + e] = from_f32<TO>(acc[e] + (bias ? to_f32(bias[n + e]) : 0.f));
+}
+
+bool pp_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn) {
+    const int64_t brows = nn ? K : N;
+    return (K % 64) == 0 && K >= 128 && (int64_t)M * lda < (1ll << 30) && brows * ldb < (1ll << 30);
+}
+
+// split policy of the skinny path: ONE round of workgroups (one workgroup per CU: 128 KiB of LDS each) that covers as many of the 256 CUs
+// as the tile count allows -- a second, partial round would double the time of a kernel that only streams the weight --, at least 2 K
+// tiles per split
+int skinny_splits(int N, int K) {
+    const int tiles_n = (N + 255) / 256, nkt = K / 64;
+    int s_ = 256 / tiles_n;
+    if (s_ > nkt / 2) s_ = nkt / 2;
+    return s_ < 1 ? 1 : s_;
+}
+
+}  // namespace
+
+extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int dtype, int out_dtype, void* stream) {
+    if (!A || !Bt || !C || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
+    if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Bt) & 15)) return LRP_EALIGN;
+    if (!pp_ok(M, N, K, lda, ldb, 1)) return LRP_ESHAPE;
+    return lrp_launch_gemm_pp(A, Bt, C, bias, M, N, K, lda, ldb, ldc, out_dtype, 1, 1, K / 64, 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t lrp_gemm_skinny_ws(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 128) return 0;
+    const int64_t ldw = (N + 3) / 4 * 4;
+    return (int64_t)skinny_splits(N, K) * M * ldw * 4;
+}
+
+extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
+                               int64_t ldc, int nn, int dtype, int out_dtype, void* ws, void* stream) {
+    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return LRP_EINVAL;
+    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32) || M > 256) return LRP_ESHAPE;
+    if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+        (reinterpret_cast<uintptr_t>(ws) & 15)) return LRP_EALIGN;
+    if (!pp_ok(M, N, K, lda, ldb, nn)) return LRP_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = skinny_splits(N, K), nkt = K / 64;
+    const int per = (nkt + splits - 1) / splits;
+    const int used = (nkt + per - 1) / per;                                  // every launched split owns >= 1 K tile ...
+    if (nkt - (used - 1) * per < 2 && used > 1) return LRP_ESHAPE;           // ... and the kernel needs >= 2 (never hit for K % 128 == 0)
+    const int64_t ldw = (N + 3) / 4 * 4, slab = (int64_t)M * ldw;
+    int rc = lrp_launch_gemm_pp(A, B, ws, nullptr, M, N, K, lda, ldb, ldw, LRP_F32, nn, used, per, slab, st);
+    if (rc != LRP_OK) return rc;
+    const int64_t nq = (int64_t)M * ((N + 3) / 4);
+    dim3 grid((unsigned)((nq + 255) / 256)), block(256);
+    if (out_dtype == LRP_F32)
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, block, 0, st, (const float*)ws, (const bf16_t*)bias, (float*)C, M, N, ldw, ldc, used, slab);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, block, 0, st, (const float*)ws, (const bf16_t*)bias, (bf16_t*)C, M, N, ldw, ldc, used, slab);
+    return lrp_check_launch();
+}
+

@@ -35,6 +35,12 @@
 //   reads, which are waited for -- lgkmcnt(0) -- BEFORE the barrier that ends the L interval).
 //   Loads are therefore 5-6 intervals (>= 2.5 K-tile times) ahead of their first read.  After its issue a wave waits
 //   vmcnt(8): everything but the newest 8 pieces has landed = the unit the NEXT phase reads; the barrier publishes it.
+// Operand forms.  NT: B is [N, K], K contiguous (a weight in its forward layout).  NN: B is [K, N], N contiguous -- the SAME stored weight
+// W [out, in] used as the dgrad operand (c = s W contracts over W's rows), so no W^T copy exists: a staging piece is 2 contraction rows x
+// 512 B of the tile's 256 output columns, the LDS image is [64 contraction rows][512 B] with 16-byte chunk ^ 2 ((row & 3) + 4 ((row >> 3) & 1)),
+// and the MFMA operand (8 consecutive contraction indices of one output column) is gathered by two ds_read_b64_tr_b16 (4 rows each).
+// Split-K: blockIdx.y owns a contiguous range of K tiles and writes an fp32 partial slab; used for skinny problems (M <= 256 rows), where
+// the weight is streamed exactly once and the tile count alone would leave most CUs idle (lrp_gemm_skinny, reduced by a second kernel).
 // Barriers: L | barrier | M | barrier per phase; group 1 executes ONE extra barrier up front, which puts it half a phase behind
 // for the whole kernel (and group 0 one at the very end to balance the count).
 #include "common.hpp"
@@ -45,106 +51,110 @@ constexpr int PP_KT = 64;                         // K elements per K tile
 constexpr int PP_OPND = 256 * 128;                // one operand of one buffer (bytes)
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* pp_glb_ptr_t;
 
-#ifndef PP_SETPRIO
-#define PP_SETPRIO 1
-#endif
-
-// PP_TIMELINE (dev builds only, tools/gemm_ab.py): waves 0 and 4 of a few workgroups stamp s_memtime at the start of every
-// interval into the spare LDS above the 128 KiB of tiles and dump it through the `bias` pointer (which is then NOT a bias).
+// PP_TIMELINE (dev builds only, tools/gemm_ab.py): waves 0 and 4 of three workgroups stamp s_memtime at kernel start, loop start, loop
+// end, stores issued, stores retired (plus the 100 MHz s_memrealtime at loop start and at the end: shader clock) into the spare LDS above
+// the 128 KiB of tiles and dump the stamps through the `bias` pointer (which is then NOT a bias).
 #ifdef PP_TIMELINE
-#define PP_STAMP_ALWAYS()                                                                         \
+#define PP_STAMP(fn)                                                                              \
     if (tl_on) {                                                                                  \
-        const uint64_t tt_ = __builtin_amdgcn_s_memtime();                                        \
-        if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
-        ++tl_idx;                                                                                 \
-    }
-#define PP_STAMP_RT()                                                                             \
-    if (tl_on) {                                                                                  \
-        const uint64_t tt_ = __builtin_amdgcn_s_memrealtime();                                    \
-        if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
-        ++tl_idx;                                                                                 \
-    }
-#endif
-#if defined(PP_TIMELINE) && PP_TIMELINE == 1
-#define PP_STAMP()                                                                                \
-    if (tl_on) {                                                                                  \
-        const uint64_t tt_ = __builtin_amdgcn_s_memtime();                                        \
+        const uint64_t tt_ = fn();                                                                \
         if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
         ++tl_idx;                                                                                 \
     }
 #else
-#define PP_STAMP()
+#define PP_STAMP(fn)
 #endif
 
-#ifdef PP_ABL_NOREAD
-#define PP_DSRD(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr), "n"(off))
-#else
 #define PP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#endif
+#define PP_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <typename TO>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
+template <typename TO, bool NN>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wc = wave & 3;
-    const int nkt = K / PP_KT;                                         // host guarantees nkt >= 2
+    // this workgroup's range of K tiles (split-K: blockIdx.y), host guarantees >= 2 tiles per split
+    const int nkt_all = K / PP_KT;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int nkt = min(kt_per_split, nkt_all - kt0);
+    C += (int64_t)blockIdx.y * slab_stride;
     int tm, tn;
     grouped_tile(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
 
-    // ---- staging: piece = 8 rows x 128 B (one buffer_load_dwordx4 .. lds); lane l -> row (l >> 3), LDS position (l & 7), source chunk
-    // position ^ ((row >> 1) & 7).  A pieces of this wave: rows g*128 + a*64 + wc*16 + 8 p (a = unit half, p = 0, 1); B pieces: rows
-    // wave*32 + 8 p (p = 0..3).  Piece bases are multiples of 8 rows, so (row >> 1) & 7 = 4*(p & 1) + (l >> 4): two per-lane offsets per
-    // operand (even / odd piece); the row and K position go into the scalar offset; rows past M / N read as zero (num_records).
+    // ---- staging (buffer_load_dwordx4 .. lds, 1 KiB per wave instruction; rows / columns past the operand read as zero)
+    // A (both forms): piece = 8 rows x 128 B; lane l -> row (l >> 3), LDS position (l & 7), source chunk position ^ (row & 7).  A pieces of
+    // this wave: rows g*128 + a*64 + wc*16 + 8 p (a = unit half, p = 0, 1).
     const int prow = lane >> 3, pslot = lane & 7;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)M * lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((int64_t)N * ldb * 2), 0x00020000);
-    // 16-row fragments: position = chunk ^ (row & 7) (= prow for every piece: one offset per operand)
-    const int voA[2] = {(int)(prow * lda * 2) + ((pslot ^ prow) << 4), (int)(prow * lda * 2) + ((pslot ^ prow) << 4)};
-    const int voB[2] = {(int)(prow * ldb * 2) + ((pslot ^ prow) << 4), (int)(prow * ldb * 2) + ((pslot ^ prow) << 4)};
-    int soA[2][2], soB[4];
+    const int voA = (int)(prow * lda * 2) + ((pslot ^ prow) << 4);
+    int soA[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) soA[a][p] = (int)((int64_t)(m0 + g * 128 + a * 64 + wc * 16 + 8 * p) * lda * 2);
+        for (int p = 0; p < 2; ++p) soA[a][p] = (int)((int64_t)(m0 + g * 128 + a * 64 + wc * 16 + 8 * p) * lda * 2) + kt0 * 128;
+    // B, NT form: piece = 8 rows of B x 128 B, rows wave*32 + 8 p (p = 0..3), same swizzle as A.
+    // B, NN form: piece = 2 contraction rows x 512 B (the tile's 256 output columns), contraction rows 8 wave + 2 p + (l >> 5),
+    //             LDS position (l & 31), source chunk position ^ f(row), f(row) = 2 ((row & 3) + 4 ((row >> 3) & 1)).
+    const int64_t brows = NN ? (int64_t)K : (int64_t)N;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(brows * ldb * 2), 0x00020000);
+    int voB[2], soB[4];
+    if constexpr (NN) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) soB[p] = (int)((int64_t)(n0 + wave * 32 + 8 * p) * ldb * 2);
+        for (int pp = 0; pp < 2; ++pp) {
+            const int r = 2 * pp + (lane >> 5);                          // row & 3 of the piece's row (pieces p and p + 2 agree)
+            const int f = 2 * ((r & 3) + 4 * (wave & 1));
+            voB[pp] = (int)((lane >> 5) * ldb * 2) + (((lane & 31) ^ f) << 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) soB[p] = (int)(((int64_t)(kt0 * PP_KT + 8 * wave + 2 * p) * ldb + n0) * 2);
+    } else {
+        voB[0] = voB[1] = (int)(prow * ldb * 2) + ((pslot ^ prow) << 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) soB[p] = (int)((int64_t)(n0 + wave * 32 + 8 * p) * ldb * 2) + kt0 * 128;
+    }
+    const int bstep = NN ? (int)(PP_KT * ldb * 2) : 128;                // bytes per K tile along B
     char* const ldsA = smem + (g * 128 + wc * 16) * 128;               // + buf*PP_OPND + a*8192 + p*1024
-    char* const ldsB = smem + 2 * PP_OPND + (wave * 32) * 128;         // + buf*PP_OPND + p*1024
+    char* const ldsB = smem + 2 * PP_OPND + (NN ? wave * 8 * 512 : wave * 32 * 128);      // + buf*PP_OPND + p*1024
     auto stage_A = [&](int a, int kt, int buf) {
-#ifdef PP_ABL_NOGLDS
-        if (kt >= 2) return;
-#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, voA[p],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, voA,
                                                      soA[a][p] + kt * 128, 0, 0);
     };
     auto stage_B = [&](int kt, int buf) {
-#ifdef PP_ABL_NOGLDS
-        if (kt >= 2) return;
-#endif
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (pp_lds_ptr_t)(ldsB + buf * PP_OPND + p * 1024), 16, voB[p & 1],
-                                                     soB[p] + kt * 128, 0, 0);
+                                                     soB[p] + kt * bstep, 0, 0);
     };
 
-    // ---- fragment addresses: row (l & 15) of a 16-row block, chunk (4 ks + (l >> 4)) ^ (l & 7)
+    // ---- fragment addresses.  A (and NT B): row (l & 15) of a 16-row block, chunk (4 ks + (l >> 4)) ^ (l & 7).
     const int hi = lane >> 4;
-    const unsigned rowA = (unsigned)((g * 128 + (lane & 15)) * 128), rowB = (unsigned)(2 * PP_OPND + (wc * 64 + (lane & 15)) * 128);
-    unsigned cA[2], cB[2];
+    const unsigned rowA = (unsigned)((g * 128 + (lane & 15)) * 128);
+    unsigned cA[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const unsigned c = (unsigned)(((4 * ks + hi) ^ (lane & 7)) << 4);
-        cA[ks] = rowA + c;
-        cB[ks] = rowB + c;
+    for (int ks = 0; ks < 2; ++ks) cA[ks] = rowA + (unsigned)(((4 * ks + hi) ^ (lane & 7)) << 4);
+    // NT: cB[ks] as cA over the B rows wc*64 + 16 j.  NN: cB[j] = address of this lane's 8-byte segment for the transpose read of column tile
+    // j: contraction row 8 hi + (i16 >> 2) (+ 32 ks + 4 h through immediates), 16-byte chunk (8 wc + 2 j + ((i16 & 3) >> 1)) ^ f, byte 8 (i16 & 1)
+    unsigned cB[4];
+    if constexpr (NN) {
+        const int i16 = lane & 15;
+        const int f = 2 * (((i16 >> 2) & 3) + 4 * (hi & 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cB[j] = (unsigned)(2 * PP_OPND + (8 * hi + (i16 >> 2)) * 512 + (((8 * wc + 2 * j + ((i16 & 3) >> 1)) ^ f) << 4) + 8 * (i16 & 1));
+    } else {
+        const unsigned rowB = (unsigned)(2 * PP_OPND + (wc * 64 + (lane & 15)) * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) cB[ks] = rowB + (unsigned)(((4 * ks + hi) ^ (lane & 7)) << 4);
+        cB[2] = cB[3] = 0;
     }
+
     f32x4 acc[2][4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -152,14 +162,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[4][2], fb[4][2];                                          // [16-row block][k-step]
+    bf16x8 fa[4][2];                                                    // [16-row block][k-step]
+    union BFrag { bf16x8 v; bf16x4 h[2]; } fb[4][2];                    // [16-column tile][k-step]; NN: two 4-row transpose reads each
 
 #ifdef PP_TIMELINE
     const int tl_slot = (blockIdx.x == 0) ? 0 : (blockIdx.x == 101) ? 1 : (blockIdx.x == 257) ? 2 : -1;
-    const bool tl_on = tl_slot >= 0 && (wave & 3) == 0;
+    const bool tl_on = tl_slot >= 0 && (wave & 3) == 0 && blockIdx.y == 0;
     const unsigned tl_base = 4u * PP_OPND + (unsigned)g * 2048u;
     unsigned tl_idx = 0;
-    PP_STAMP_ALWAYS()
+    PP_STAMP(__builtin_amdgcn_s_memtime)
 #endif
     // ---- prologue: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
     stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1);
@@ -175,29 +186,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
         PP_DSRD(fa[3][ks], cA[ks], (BUF) * PP_OPND + (AH) * 8192 + 6144);                         \
     }
 #define PP_READ_B(BUF)                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
-        PP_DSRD(fb[0][ks], cB[ks], (BUF) * PP_OPND);                                              \
-        PP_DSRD(fb[1][ks], cB[ks], (BUF) * PP_OPND + 2048);                                       \
-        PP_DSRD(fb[2][ks], cB[ks], (BUF) * PP_OPND + 4096);                                       \
-        PP_DSRD(fb[3][ks], cB[ks], (BUF) * PP_OPND + 6144);                                       \
+    if constexpr (NN) {                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            PP_DSTR(fb[j][0].h[0], cB[j], (BUF) * PP_OPND);                                       \
+            PP_DSTR(fb[j][0].h[1], cB[j], (BUF) * PP_OPND + 2048);                                \
+            PP_DSTR(fb[j][1].h[0], cB[j], (BUF) * PP_OPND + 16384);                               \
+            PP_DSTR(fb[j][1].h[1], cB[j], (BUF) * PP_OPND + 16384 + 2048);                        \
+        }                                                                                         \
+    } else {                                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
+            PP_DSRD(fb[0][ks].v, cB[ks], (BUF) * PP_OPND);                                        \
+            PP_DSRD(fb[1][ks].v, cB[ks], (BUF) * PP_OPND + 2048);                                 \
+            PP_DSRD(fb[2][ks].v, cB[ks], (BUF) * PP_OPND + 4096);                                 \
+            PP_DSRD(fb[3][ks].v, cB[ks], (BUF) * PP_OPND + 6144);                                 \
+        }                                                                                         \
     }
 #define PP_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),   \
                                  "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]) :: "memory")
-#define PP_WAIT_B() asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),                        \
-                                 "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]))
+#define PP_WAIT_B() asm volatile("" : "+v"(fb[0][0].v), "+v"(fb[0][1].v), "+v"(fb[1][0].v), "+v"(fb[1][1].v),                \
+                                 "+v"(fb[2][0].v), "+v"(fb[2][1].v), "+v"(fb[3][0].v), "+v"(fb[3][1].v))
 #define PP_MMA(AH)                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[AH][i][j], 0, 0, 0);
+                acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks].v, fa[i][ks], acc[AH][i][j], 0, 0, 0);
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
-#if PP_SETPRIO
-#define PP_PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define PP_PRIO(n)
-#endif
 
-    // one K tile out of buffer BUF (compile-time); t is the running K-tile index
+    // one K tile out of buffer BUF (compile-time); t is the running K-tile index.  The M phases are BARE MFMA streams.
 #define PP_KTILE(BUF)                                                                             \
     {                                                                                             \
         /* ---- phase (t, 0): L */                                                                \
@@ -205,25 +220,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
         if (t + 1 < nkt) { stage_A(1, t + 1, (BUF) ^ 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
         PP_WAIT_A(); PP_WAIT_B(); PP_FENCE();                                                     \
-        __builtin_amdgcn_s_barrier(); PP_FENCE(); PP_STAMP()                                      \
+        __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- M */                                                                              \
-        PP_PRIO(1); PP_MMA(0) PP_PRIO(0); PP_FENCE();                                             \
-        __builtin_amdgcn_s_barrier(); PP_FENCE(); PP_STAMP()                                      \
+        __builtin_amdgcn_s_setprio(1); PP_MMA(0) __builtin_amdgcn_s_setprio(0); PP_FENCE();       \
+        __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- phase (t, 1): L */                                                                \
         PP_READ_A(BUF, 1)                                                                         \
         if (t + 2 < nkt) { stage_A(0, t + 2, BUF); stage_B(t + 2, BUF); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   \
         else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
         PP_WAIT_A(); PP_FENCE();                                                                  \
-        __builtin_amdgcn_s_barrier(); PP_FENCE(); PP_STAMP()                                      \
+        __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- M */                                                                              \
-        PP_PRIO(1); PP_MMA(1) PP_PRIO(0); PP_FENCE();                                             \
-        __builtin_amdgcn_s_barrier(); PP_FENCE(); PP_STAMP()                                      \
+        __builtin_amdgcn_s_setprio(1); PP_MMA(1) __builtin_amdgcn_s_setprio(0); PP_FENCE();       \
+        __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
     }
 
-#if defined(PP_TIMELINE) && PP_TIMELINE == 2
-    PP_STAMP_RT()
-    PP_STAMP_ALWAYS()
-#endif
+    PP_STAMP(__builtin_amdgcn_s_memrealtime)
+    PP_STAMP(__builtin_amdgcn_s_memtime)
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
         PP_KTILE(0)
@@ -232,18 +245,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
         --t;
     }
     if (t < nkt) PP_KTILE(0)
-
-#if defined(PP_TIMELINE) && PP_TIMELINE == 2
-    PP_STAMP_ALWAYS()
-#endif
+    PP_STAMP(__builtin_amdgcn_s_memtime)
 #ifdef PP_TIMELINE
     uint64_t* const tl_out = (uint64_t*)bias;
     bias = nullptr;
 #endif
+
     // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
     const int mrow = m0 + g * 128 + (lane & 15);
     const int ncol = n0 + wc * 64;
     const bool full = (m0 + 256 <= M) && (n0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -266,12 +278,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
                 for (int j = 0; j < 4; ++j) {
                     const int gn = ncol + j * 16 + 4 * hi;
                     TO* dst = C + (int64_t)gm * ldc + gn;
-                    if (full) {
-                        *reinterpret_cast<f32x4*>(dst) = v[j];
-                    } else if (gm < M) {
+                    if (gm < M) {
+                        if (vec4 && gn + 3 < N) {
+                            *reinterpret_cast<f32x4*>(dst) = v[j];
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (gn + e < N) dst[e] = v[j][e];
+                            for (int e = 0; e < 4; ++e)
+                                if (gn + e < N) dst[e] = v[j][e];
+                        }
                     }
                 }
             } else if (full) {
@@ -300,15 +314,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA may outlive the workgroup's LDS allocation
 #ifdef PP_TIMELINE
     if (tl_on) {
-        PP_STAMP_ALWAYS()                                               // end of the C stores' issue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PP_STAMP_ALWAYS()                                               // stores retired
-#if PP_TIMELINE == 2
-        PP_STAMP_RT()
-#endif
+        PP_STAMP(__builtin_amdgcn_s_memtime)                            // C stores issued (and, after the wait above, retired)
+        PP_STAMP(__builtin_amdgcn_s_memtime)
+        PP_STAMP(__builtin_amdgcn_s_memrealtime)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tl_out && lane < 3) {
-            // lane 0..2 copy 64 stamps each
             for (int i2 = lane * 64; i2 < lane * 64 + 64; ++i2) {
                 uint64_t v2;
                 asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v2) : "v"(tl_base + 8u * (unsigned)i2) : "memory");
@@ -324,35 +334,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(
 #undef PP_WAIT_B
 #undef PP_MMA
 #undef PP_FENCE
-#undef PP_PRIO
 }
 
-}  // namespace
-
-// host entry used by lrp_gemm_nt's dispatcher (gemm.hip): bf16 operands, K a multiple of 64 with K >= 128, operands < 4 GiB apart
-template <typename TO>
-static int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                       int64_t ldc, hipStream_t st) {
+template <typename TO, bool NN>
+int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                int splits, int kt_per_split, int64_t slab_stride, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-    dim3 grid(tiles_m * tiles_n), block(512);
+    dim3 grid(tiles_m * tiles_n, splits), block(512);
 #ifdef PP_TIMELINE
     const size_t lds = 4 * (size_t)PP_OPND + 4096;
 #else
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
-    auto kern = gemm_nt_pp_kernel<TO>;
+    auto kern = gemm_pp_kernel<TO, NN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
-                       ldb, ldc, tiles_m, tiles_n);
+                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride);
     return lrp_check_launch();
 }
 
+}  // namespace
+
+// Host entry used by the dispatchers of gemm.hip.  bf16 operands; K a multiple of 64, >= 128 per split; every operand below 2^30 elements
+// (32-bit buffer offsets).  nn = 0: B is [N, K] (ldb = row pitch of B); nn = 1: B is [K, N].  splits > 1: C must be fp32 slabs
+// [splits][M][ldc] (slab_stride elements apart), each holding the partial sum of kt_per_split K tiles; no bias then.
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                       int64_t ldc, int out_dtype, hipStream_t st) {
-    if (out_dtype == LRP_F32) return launch_pp_t<float>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
-    return launch_pp_t<bf16_t>(A, B, C, bias, M, N, K, lda, ldb, ldc, st);
+                       int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st) {
+    if (out_dtype == LRP_F32) {
+        if (nn) return launch_pp_t<float, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
+        return launch_pp_t<float, false>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
+    }
+    if (nn) return launch_pp_t<bf16_t, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
+    return launch_pp_t<bf16_t, false>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
 }

@@ -69,20 +69,18 @@ class GatedActFn(Function):
 
 
 class LinearFn(Function):
-    """K1 (efficient form, eps = 0): z = x W^T + b on the MFMA GEMM, backward G_x = G_z W on the same
-    kernel with the cached W^T copy (weights are frozen in the LRP protocol, quickstart.rst:84-86)."""
+    """K1 (efficient form, eps = 0): z = x W^T + b, backward G_x = G_z W -- both from the STORED weight [out, in] (ops.linear_fwd /
+    ops.linear_dgrad pick the kernel by row count and dtype; bf16 never makes a W^T copy).  `weight_t` is accepted for callers of the
+    round-2 signature and ignored."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, weight_t):
+    def forward(ctx, x, weight, bias, weight_t=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        ctx.small = ops.smallm_ok(x2.shape[0], weight, x2 if x2.is_contiguous() else None) and x2.is_contiguous()
-        if ctx.small:       # <= 16 rows (e.g. a last-token head): W-streaming kernels, no W^T needed
-            z = ops.linear_smallm_fwd(x2, weight, bias)
-            ctx.save_for_backward(weight)
-        else:
-            z = ops.gemm_nt(x2, weight, bias)
-            ctx.save_for_backward(weight_t if weight_t is not None else ops.weight_t(weight))
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        z = ops.linear_fwd(x2, weight, bias)
+        ctx.save_for_backward(weight)
         return z.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
@@ -90,11 +88,10 @@ class LinearFn(Function):
         (w,) = ctx.saved_tensors
         shp = gz.shape
         g2 = gz.reshape(-1, shp[-1])
-        if ctx.small:
-            gx = ops.linear_smallm_dgrad(g2.contiguous(), w)
-            return gx.view(*shp[:-1], w.shape[1]), None, None, None
-        gx = ops.gemm_nt(g2, w)
-        return gx.view(*shp[:-1], w.shape[0]), None, None, None
+        if g2.stride(-1) != 1:
+            g2 = g2.contiguous()
+        gx = ops.linear_dgrad(g2, w)
+        return gx.view(*shp[:-1], w.shape[1]), None, None, None
 
 
 def _kernel_head_dim(d, dtype):

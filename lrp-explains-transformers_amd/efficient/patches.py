@@ -89,17 +89,6 @@ def patch_ownership(module):
     return True
 
 
-def _weight_t(mod, w2):
-    """cached W^T copy for the dgrad GEMM (frozen weights); the key covers re-assignment of the Parameter
-    (resize_token_embeddings / tie_weights / adapter loading keep _version 0 but change storage or shape)"""
-    key = (w2.data_ptr(), tuple(w2.shape), w2.device, w2.dtype, mod.weight._version)
-    if mod.__dict__.get("_lrp_weight_key") != key:
-        from .. import ops
-        mod.__dict__["_lrp_weight_t"] = ops.transpose(w2.contiguous())
-        mod.__dict__["_lrp_weight_key"] = key
-    return mod.__dict__["_lrp_weight_t"]
-
-
 # ----------------------------------------------------------------------------------- AttnLRP patches
 def rms_norm_forward(self, hidden_states):
     """identity rule on RMSNorm (ref: lxt/efficient/patches.py:111-123) -- fused HIP row kernel"""
@@ -127,7 +116,7 @@ def layer_norm_forward(self, x):
 
 
 def linear_forward(self, x):
-    """nn.Linear on the MFMA GEMM; the W^T copy for the dgrad is cached on the module (frozen weights).  Not patched by
+    """nn.Linear on the MFMA GEMM, forward and dgrad from the stored weight (bf16: no W^T copy; fp32: one cached on the weight).  Not patched by
     the reference (ATen mm there); part of the default maps here so the whole backward runs on liblrp_hip.so.  Only
     instances of an explained model with frozen weights take this path (see `adopt`); everything else -- foreign
     modules, CPU probes, trainable weights, dtypes the kernels do not serve -- runs torch's own forward unchanged."""
@@ -136,24 +125,21 @@ def linear_forward(self, x):
                                               or x.dtype not in (torch.float32, torch.bfloat16)):
         return self.original_forward(x)
     _need_cuda(x, "linear_forward")
-    wd = w.detach()
-    from .. import ops
-    rows = x.numel() // x.shape[-1] if x.numel() else 0
-    wt = None if ops.smallm_ok(rows, wd) else _weight_t(self, wd)         # <= 16 rows: W-streaming kernels, no W^T copy at all
-    return LinearFn.apply(x, wd, self.bias.detach() if self.bias is not None else None, wt)
+    return LinearFn.apply(x, w.detach(), self.bias.detach() if self.bias is not None else None)
 
 
 def conv1d_forward(self, x):
     """HF's Conv1D (GPT-2's c_attn / c_fc / c_proj: y = x W + b with W stored [in, out]) on the MFMA GEMM: the forward
-    uses a cached [out, in] copy, the dgrad the stored weight itself -- both NT contractions.  The reference leaves these
+    uses a cached [out, in] copy (ops.weight_t), the dgrad the NN form on that copy (bf16) or the stored weight (fp32).  The reference leaves these
     on ATen (lxt/efficient/models/gpt2.py:11-32 patches only the MLP forward around them)."""
     w = self.weight
     if hasattr(self, "original_forward") and (not _owned(self) or w.requires_grad or x.dtype != w.dtype
                                               or x.dtype not in (torch.float32, torch.bfloat16)):
         return self.original_forward(x)
     _need_cuda(x, "conv1d_forward")
+    from .. import ops
     wd = w.detach()
-    return LinearFn.apply(x, _weight_t(self, wd), self.bias.detach() if self.bias is not None else None, wd.contiguous())
+    return LinearFn.apply(x, ops.weight_t(wd), self.bias.detach() if self.bias is not None else None)     # cached [out, in] copy
 
 
 def conv2d_patch_forward(self, x):
@@ -169,7 +155,7 @@ def conv2d_patch_forward(self, x):
     gh, gw = Hh // kh, Ww // kw
     patches = x[:, :, : gh * kh, : gw * kw].reshape(B, C, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * kh * kw)
     w2 = self.weight.detach().reshape(self.out_channels, C * kh * kw)
-    y = LinearFn.apply(patches, w2, self.bias.detach() if self.bias is not None else None, _weight_t(self, w2))
+    y = LinearFn.apply(patches, w2, self.bias.detach() if self.bias is not None else None)
     return y.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -332,15 +318,12 @@ def cp_multi_head_attention_forward(self, query, key, value, key_padding_mask=No
         q = ops.gemm_nt(query.detach().reshape(B * Sq, E).contiguous(), w[:E], bq).view(B, Sq, H, d)
         k = ops.gemm_nt(key.detach().reshape(-1, E).contiguous(), w[E: 2 * E], bk).view(B, -1, H, d)
     wv = w[2 * E:]
-    key = (w.data_ptr(), tuple(w.shape), w.device, w.dtype, self.in_proj_weight._version)
-    if self.__dict__.get("_lrp_wv_key") != key:
-        self.__dict__["_lrp_wv_t"], self.__dict__["_lrp_wv_key"] = ops.transpose(wv.contiguous()), key
-    v = LinearFn.apply(value, wv, bv, self.__dict__["_lrp_wv_t"]).view(B, -1, H, d)
+    v = LinearFn.apply(value, wv, bv).view(B, -1, H, d)
     if k.shape[1] != Sq:
         raise NotImplementedError("lxt_amd MultiheadAttention fast path: cross attention with a different key length")
     o = AttentionFn.apply(q, k, v, d ** -0.5, False, 0, True, None)            # cp=True: dQ = dK = 0, all relevance on V
     op_, ow = self.out_proj, self.out_proj.weight.detach()
-    out = LinearFn.apply(o.reshape(B, Sq, E), ow, op_.bias.detach() if op_.bias is not None else None, _weight_t(op_, ow))
+    out = LinearFn.apply(o.reshape(B, Sq, E), ow, op_.bias.detach() if op_.bias is not None else None)
     if not self.batch_first:
         out = out.transpose(0, 1)
     return out, None

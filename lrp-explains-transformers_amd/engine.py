@@ -11,9 +11,11 @@ MI355X-first decisions:
   * everything an eps-rule needs (every Linear output z, pre/post-RoPE q/k, attention o + lse,
     residual sums) is STASHED in HBM during the forward (~0.3 GB/layer at S=2048 bf16; 288 GB
     available) -- the backward never recomputes a GEMM, it runs one dgrad GEMM per Linear;
-  * every weight is kept twice, W [out,in] for the forward and W^T [in,out] for the backward, and
-    QKV / gate+up are fused along N, so every contraction is an NT GEMM with K-contiguous operands;
-  * q/k/v/Gho are also kept head-transposed for the attention kernels (attention.hip);
+  * every weight is kept ONCE, in its forward layout W [out,in] (QKV and gate+up fused along the output dim): the forward is an NT
+    GEMM, the backward the NN form  c = s W  of the same kernel (the transposed MFMA operand is gathered in LDS by
+    ds_read_b64_tr_b16); only the fp32 parity engine falls back to a W^T copy (ops.linear_dgrad);
+  * bf16 / head_dim 128 attention reads its transposed operands out of row-major LDS tiles as well; fp32 and the other head dims keep
+    head-transposed copies of q/k/v/Gho (attention.hip, `attn_t`);
   * only the last token's logits are formed (the explained logit lives there), and the LM head
     + final norm backward is a single row per prompt.
 Python only sequences kernel launches on the current stream; it performs no arithmetic.
@@ -128,7 +130,6 @@ class LlamaLRP:
                                     wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
                                     wgu=put(take(2 * I, H), L["wg"], L["wu"]), wd=put(take(H, I), L["wd"])))
         self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
-        self.build_transposes()
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
         if inv is None:
@@ -142,23 +143,19 @@ class LlamaLRP:
         self.max_seq = max_seq
         torch.cuda.synchronize(dev)
 
-    # rows-per-call <= ops.SMALLM_MAX (the one-row-per-prompt top layer, the last-token head): W-streaming kernels, W read
-    # once from its stored layout in both directions; above that the MFMA GEMM (forward: W, backward: the W^T copy)
+    # ops.linear_fwd / ops.linear_dgrad pick the kernel by row count: W-streaming small-M kernels and the split-K skinny path for the
+    # one-row-per-prompt top layer and the LM head, the 256x256 ping-pong GEMM (NT forward, NN backward) for M = B*S rows
     def _lin_fwd(self, x, W, out):
-        if x.shape[0] <= ops.SMALLM_MAX:
-            return ops.linear_smallm_fwd(x, W, out=out)
-        return ops.gemm_nt_2d(x, W, out)
+        return ops.linear_fwd(x, W, out=out)
 
-    def _lin_bwd(self, A, W, W_t, out):
-        if A.shape[0] <= ops.SMALLM_MAX:
-            return ops.linear_smallm_dgrad(A, W, out=out)
-        return ops.gemm_nt_2d(A, W_t, out)
+    def _lin_bwd(self, A, W, out):
+        return ops.linear_dgrad(A, W, out=out)
 
     def build_transposes(self):
-        """W^T ([in, out]) copies for the dgrad GEMMs, made locally from the forward layouts (after a weight broadcast too)"""
+        """kept for callers of the round-2 API (bench.py, dist tests): the bf16 engine holds no W^T copies any more; the fp32 parity
+        engine makes them lazily (ops.weight_t, cached on the weight) -- dropping the cache here makes a weight broadcast visible"""
         for L in self.layers:
-            for k in ("wqkv", "wo", "wgu", "wd"):
-                L[k + "_t"] = ops.transpose(L[k])
+            ops.clear_weight_cache(L["wqkv"], L["wo"], L["wgu"], L["wd"])
         self.lm_head_t = None
 
     @classmethod
@@ -196,7 +193,7 @@ class LlamaLRP:
             else:
                 st["h"] = new(M, H)
                 x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"])
-            qkv = ops.gemm_nt_2d(x, Lw["wqkv"], new(M, nqkv))
+            qkv = self._lin_fwd(x, Lw["wqkv"], new(M, nqkv))
             qkr = ops.rope_fwd(qkv, new(M, nqk), self.cos, self.sin, S, nq + nk, d)
             v = qkv[:, nqk:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
@@ -216,12 +213,12 @@ class LlamaLRP:
                 h_prev, branch = h1_l, dn_l
                 break
             ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
-            a = ops.gemm_nt_2d(o, Lw["wo"], new(M, H))
+            a = self._lin_fwd(o, Lw["wo"], new(M, H))
             h1 = new(M, H)
             x2, st["rstd2"] = ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1)
-            gu = ops.gemm_nt_2d(x2, Lw["wgu"], new(M, 2 * I))
+            gu = self._lin_fwd(x2, Lw["wgu"], new(M, 2 * I))
             m = ops.gated_act_fwd(gu[:, :I], gu[:, I:], new(M, I), self.act)
-            dn = ops.gemm_nt_2d(m, Lw["wd"], new(M, H))
+            dn = self._lin_fwd(m, Lw["wd"], new(M, H))
             st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
             stash.append(st)
             h_prev, branch = h1, dn
@@ -249,17 +246,12 @@ class LlamaLRP:
             Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
         else:
             # dense seed over the last-position logits (contrastive explanations): gradient in efficient mode, relevance
-            # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm (W-streaming dgrad for B <= 16, else the GEMM on a
-            # W_lm^T copy made on first use), then the final norm's identity rule (row scale, rmsnorm_bwd_add2 without a residual)
+            # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm (ops.linear_dgrad: W streamed once from its stored layout),
+            # then the final norm's identity rule (row scale, rmsnorm_bwd_add2 without a residual)
             coef = seed.to(device=dev, dtype=torch.float32).reshape(B, -1).contiguous()
             if E["lin"] != 0.0:
                 coef = ops.eps_scale(coef, fw["logits"], 1.0, E["lin"], relevance=True)
-            if B <= ops.SMALLM_MAX:
-                g_xn = ops.linear_smallm_dgrad(coef.to(dt), self.lm_head, out_dtype=torch.float32)
-            else:
-                if self.lm_head_t is None:
-                    self.lm_head_t = ops.transpose(self.lm_head)
-                g_xn = ops.gemm_nt_2d(coef.to(dt), self.lm_head_t, torch.empty(B, H, device=dev, dtype=torch.float32))
+            g_xn = ops.linear_dgrad(coef.to(dt), self.lm_head, out_dtype=torch.float32)
             Gh_last = ops.head_norm_bwd(g_xn, self.norm, fw["rstd_f"], new(B, H))
         # add2 at h_L = h1 + dn and the eps scale of the last down_proj, still one row per prompt
         Gs_last, A_last = new(B, H), new(B, H)
@@ -280,14 +272,14 @@ class LlamaLRP:
             if st.get("top", False):
                 # ---- one row per prompt through MLP, norm/add2 and o-proj; scatter into the dense attention inputs
                 gu_l = st["gu_l"]
-                Gm = self._lin_bwd(A_last, Lw["wd"], Lw["wd_t"], new(B, I))
+                Gm = self._lin_bwd(A_last, Lw["wd"], new(B, I))
                 Agu = new(B, 2 * I)
                 ops.gated_act_bwd(Gm, gu_l[:, :I], gu_l[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-                Gx2 = self._lin_bwd(Agu, Lw["wgu"], Lw["wgu_t"], new(B, H))
+                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new(B, H))
                 Gs1_l, Aa_l = new(B, H), new(B, H)
                 ops.rmsnorm_bwd_add2(Gs_last, Gx2, Lw["ln2"], st["rstd2_l"], st["h1_l"], st["a_l"], Gs1_l, Aa_l, None, 0.0,
                                      E["add"], E["lin"])
-                Gof_l = self._lin_bwd(Aa_l, Lw["wo"], Lw["wo_t"], new(B, nq * d))
+                Gof_l = self._lin_bwd(Aa_l, Lw["wo"], new(B, nq * d))
                 Gho_l = new(B, nq * d)
                 D_l = torch.empty(B, nq, 1, device=dev, dtype=torch.float32)
                 ops.attn_bwd_prep(Gof_l, st["o_l"], Gho_l, D_l, B, 1, nq, d, E["pv"], 0.5)
@@ -299,14 +291,14 @@ class LlamaLRP:
             else:
                 gu = st["gu"]
                 # ---- MLP
-                Gm = ops.gemm_nt_2d(Adn, Lw["wd_t"], new(M, I))
+                Gm = self._lin_bwd(Adn, Lw["wd"], new(M, I))
                 Agu = new(M, 2 * I)
                 ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-                Gx2 = ops.gemm_nt_2d(Agu, Lw["wgu_t"], new(M, H))
+                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new(M, H))
                 Gs1, Aa = new(M, H), new(M, H)
                 ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
                 # ---- attention
-                Gof = ops.gemm_nt_2d(Aa, Lw["wo_t"], new(M, nq * d))
+                Gof = self._lin_bwd(Aa, Lw["wo"], new(M, nq * d))
                 Gho = new(M, nq * d)
                 D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
                 ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
@@ -331,7 +323,7 @@ class LlamaLRP:
                 dv = ops.gqa_reduce(dv_h, new(M, nk * d), M, nk, rep, d)
                 ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
                 ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
-            Gx = ops.gemm_nt_2d(Aqkv, Lw["wqkv_t"], new(M, H))
+            Gx = self._lin_bwd(Aqkv, Lw["wqkv"], new(M, H))
             # ---- input norm + the residual add below (or the embedding)
             rel = torch.empty(M, device=dev, dtype=torch.float32) if layer_relevance else None
             if li > 0:

@@ -55,7 +55,7 @@ def weights_from_hf(model):
 
 
 class BertLRP:
-    """Device-resident weights (forward layout + W^T for the dgrad GEMMs) + explain()."""
+    """Device-resident weights (forward layout only; ops.linear_dgrad derives the backward from it) + explain()."""
 
     def __init__(self, cfg, W, dtype=torch.float32, device="cuda", mode="efficient"):
         if not torch.cuda.is_available():
@@ -67,15 +67,12 @@ class BertLRP:
         self.tt0 = t(W["tt"][0:1])                                            # token type 0 (single-segment inputs)
         self.pos = t(W["pos"])
         self.pool_w, self.pool_b, self.cls_w, self.cls_b = t(W["pool_w"]), t(W["pool_b"]), t(W["cls_w"]), t(W["cls_b"])
-        self.pool_wt, self.cls_wt = ops.transpose(self.pool_w), ops.transpose(self.cls_w)
         self.layers = []
         for L in W["layers"]:
             wqkv = torch.cat([t(L["wq"]), t(L["wk"]), t(L["wv"])], 0)
             P = dict(wqkv=wqkv, bqkv=torch.cat([t(L["bq"]), t(L["bk"]), t(L["bv"])], 0), wo=t(L["wo"]), bo=t(L["bo"]),
                      wi=t(L["wi"]), bi=t(L["bi"]), wd=t(L["wd"]), bd=t(L["bd"]), ln1_w=t(L["ln1_w"]), ln1_b=t(L["ln1_b"]),
                      ln2_w=t(L["ln2_w"]), ln2_b=t(L["ln2_b"]))
-            for n in ("wqkv", "wo", "wi", "wd"):
-                P[n + "_t"] = ops.transpose(P[n])
             self.layers.append(P)
         self._graphs = {}
 
@@ -101,13 +98,10 @@ class BertLRP:
         out = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=x.dtype)
         return ops.gemm_nt_2d(x, w, out, b)
 
-    def _dgrad(self, G, z, w_t, eps):
-        """input gradient of z = x W^T + b under the eps rule: (G * z/(z+eps)) W"""
-        s = self._scale(G, z, eps)
-        if (s.shape[1] * s.element_size()) % 16:                              # the classifier: K = num_labels (zero-padded copy)
-            return ops.gemm_nt(s, w_t)
-        out = torch.empty(s.shape[0], w_t.shape[0], device=s.device, dtype=s.dtype)
-        return ops.gemm_nt_2d(s, w_t, out)
+    def _dgrad(self, G, z, w, eps):
+        """input gradient of z = x W^T + b under the eps rule: (G * z/(z+eps)) W, from the stored weight W [out, in] (bf16: NN form of
+        the GEMM, no W^T copy; fp32 and odd shapes such as the 2-label classifier: a W^T copy cached on the weight)"""
+        return ops.linear_dgrad(self._scale(G, z, eps), w)
 
     # ------------------------------------------------------------------------------------------------ one explanation
     def _run(self, ids, target, want_layers):
@@ -157,10 +151,10 @@ class BertLRP:
         onehot = torch.zeros(B, cfg["labels"], device=h.device, dtype=h.dtype).scatter_(1, idx.view(B, 1), 1.0)
         logit = logits.gather(1, idx.view(B, 1)).view(B)
         # ---------------------------------------------------------------- backward (gradient form)
-        Gpooled = self._dgrad(onehot, logits.to(h.dtype), self.cls_wt, E["lin"])
+        Gpooled = self._dgrad(onehot, logits.to(h.dtype), self.cls_w, E["lin"])
         Gzp = ops.act_bwd(Gpooled, zp, "tanh", E["act"])
         Gh = torch.zeros(M, H, device=h.device, dtype=h.dtype)
-        ops.gemm_nt_2d(self._scale(Gzp, zp, E["lin"]), self.pool_wt, Gh.view(B, S, H)[:, 0])
+        Gh.view(B, S, H)[:, 0].copy_(self._dgrad(Gzp, zp, self.pool_w, E["lin"]))
         layer_R = []
         if want_layers:
             layer_R.append(ops.readout(h, Gh).view(B, S).sum(1))
@@ -170,13 +164,13 @@ class BertLRP:
             # h2 = LN(add2(dn, h1))
             Gr2 = ops.layernorm_bwd(Gh, c["h2"], P["ln2_w"], c["rstd2"], E["ln"])
             Gs = self._scale(Gr2, c["r2"], E["add"])                         # add2: the same factor to both summands
-            Gm = self._dgrad(Gs, c["dn"], P["wd_t"], E["lin"])
+            Gm = self._dgrad(Gs, c["dn"], P["wd"], E["lin"])
             Gzi = ops.act_bwd(Gm, c["zi"], act, E["act"])
-            Gh1 = ops.add_bcast(self._dgrad(Gzi, c["zi"], P["wi_t"], E["lin"]), Gs)
+            Gh1 = ops.add_bcast(self._dgrad(Gzi, c["zi"], P["wi"], E["lin"]), Gs)
             # h1 = LN(add2(a, h))
             Gr1 = ops.layernorm_bwd(Gh1, c["h1"], P["ln1_w"], c["rstd1"], E["ln"])
             Gs1 = self._scale(Gr1, c["r1"], E["add"])
-            Go = self._dgrad(Gs1, c["a"], P["wo_t"], E["lin"])
+            Go = self._dgrad(Gs1, c["a"], P["wo"], E["lin"])
             # attention: lf.matmul on P.V == the uniform-rule kernel with eps/2 (o/(2o+eps) = 1/2 o/(o+eps/2))
             Gho = torch.empty_like(Go)
             D = torch.empty(B, nh, S, device=h.device, dtype=torch.float32)
@@ -189,8 +183,7 @@ class BertLRP:
             ops.attn_bwd_dq(q, k, v, k_t, Gho, c["lse"], D, dq, B, S, nh, nh, d, scale, E["mask"], E["qk"], False, 0)
             if E["lin"] != 0.0:
                 ops.eps_scale2d(A, qkv, A, 1.0, E["lin"])
-            Gx = torch.empty(M, H, device=h.device, dtype=h.dtype)
-            ops.gemm_nt_2d(A, P["wqkv_t"], Gx)
+            Gx = ops.linear_dgrad(A, P["wqkv"])
             Gh = ops.add_bcast(Gx, Gs1)
             if want_layers:
                 layer_R.append(ops.readout(c["h"], Gh).view(B, S).sum(1))

@@ -46,29 +46,24 @@ class linear_epsilon_fn(Function):
         shp = inputs.shape
         x2 = inputs.reshape(-1, shp[-1]).contiguous()
         w = weight.detach()
-        ctx.small = ops.smallm_ok(x2.shape[0], w, x2)
-        if ctx.small:
-            # <= 16 rows: W-streaming kernels, W read once per direction from its stored layout (HBM-bound regime of the rule)
-            z = ops.linear_smallm_fwd(x2, w, bias)
-            ctx.save_for_backward(x2, w, z)
-        else:
-            z = ops.gemm_nt(x2, weight, bias)
-            # the W^T copy of the dgrad GEMM is cached on the weight object (frozen weights): one transpose per weight,
-            # not one per call
-            ctx.save_for_backward(x2, ops.weight_t(weight), z)
+        # <= 4 rows: the W-streaming kernels form s = R/(z+eps) on the fly (one launch pair for the whole rule); above that
+        # ops.linear_fwd / ops.linear_dgrad (skinny split-K, NN GEMM from the stored weight, or the fp32 path with a cached W^T)
+        ctx.small = x2.shape[0] <= 4 and ops.smallm_ok(x2.shape[0], w, x2)
+        z = ops.linear_smallm_fwd(x2, w, bias) if ctx.small else ops.linear_fwd(x2, w, bias)
+        ctx.save_for_backward(x2, w, z)
         ctx.epsilon, ctx.shp = epsilon, shp
         return z.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
     @conservation_check_wrap
     def backward(ctx, R_out):
-        x2, w_or_wt, z = ctx.saved_tensors
+        x2, w, z = ctx.saved_tensors
         if ctx.small:       # s = R/(z+eps), (s W) (*) x in one launch pair
-            R_in = ops.linear_smallm_dgrad(R_out.reshape(z.shape).contiguous(), w_or_wt, z=z, x=x2, eps=ctx.epsilon, relevance_in=True,
+            R_in = ops.linear_smallm_dgrad(R_out.reshape(z.shape).contiguous(), w, z=z, x=x2, eps=ctx.epsilon, relevance_in=True,
                                            relevance_out=True)
             return R_in.view(ctx.shp), None, None, None
         s = ops.eps_scale(R_out.reshape(z.shape), z, 1.0, ctx.epsilon, relevance=True)
-        R_in = ops.mul(ops.gemm_nt(s, w_or_wt), x2)
+        R_in = ops.mul(ops.linear_dgrad(s, w), x2)
         return R_in.view(ctx.shp), None, None, None
 
 

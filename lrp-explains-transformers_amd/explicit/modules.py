@@ -51,9 +51,8 @@ class _LinearProjection(nn.Module):
 
     def forward(self, x):
         from ..efficient.functions import LinearFn
-        from .. import ops
         w = self.weight if self.weight.is_contiguous() else self.weight.contiguous()
-        return LinearFn.apply(x, w.detach(), self.bias.detach() if self.bias is not None else None, ops.weight_t(w))
+        return LinearFn.apply(x, w.detach(), self.bias.detach() if self.bias is not None else None)
 
 
 class LinearInProjection(_LinearProjection):

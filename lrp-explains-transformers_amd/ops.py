@@ -148,6 +148,62 @@ def gemm_nt_2d(a, b, out, bias=None):
     return out
 
 
+def gemm_nn_ok(a, w):
+    """can lrp_gemm_nn / lrp_gemm_skinny serve C = a[M,K] @ w[K,N] (w = a weight in its stored [out,in] layout)?  bf16, K % 64 == 0,
+    K >= 128, 16-byte aligned K-/N-contiguous operands below 2^30 elements"""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2:
+        return False
+    M, K = a.shape
+    return (K % 64 == 0 and K >= 128 and a.stride(1) == 1 and w.stride(1) == 1 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and M * a.stride(0) < 2 ** 30 and w.shape[0] * w.stride(0) < 2 ** 30)
+
+
+def gemm_nn_2d(a, w, out, bias=None):
+    """out[M,N] = a[M,K] @ w[K,N]: the eps-rule redistribution c = s W straight from the STORED weight W [out,in] (no W^T copy)"""
+    M, K = a.shape
+    N = w.shape[1]
+    same(a, w)
+    ev = GEMM_TIMER.span(2.0 * M * N * K) if GEMM_TIMER is not None else None
+    if ev:
+        ev[0].record()
+    rc = lib.lrp_gemm_nn(a.data_ptr(), w.data_ptr(), out.data_ptr(), p(aux(bias, a, N)), M, N, K, a.stride(0), w.stride(0),
+                         out.stride(0), dt(a), _DT[out.dtype], stream())
+    if ev:
+        ev[1].record()
+    check(rc, "lrp_gemm_nn")
+    return out
+
+
+SKINNY_MAX = 256         # rows the split-K skinny path serves (HBM-bound regime of the Linear eps-rule: M <~ 160 in bf16)
+_WS = {}
+
+
+def workspace(nbytes, ref):
+    """scratch for kernels that take a caller-allocated workspace.  One buffer per (device, stream), grown on demand: kernels on
+    one stream are ordered, two streams never share a buffer.  Under hipGraph capture a FRESH allocation is made per
+    call (it lives in the graph's private pool; a cached buffer could be re-grown -- freed -- after the capture)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 16), device=ref.device, dtype=torch.uint8)
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 4 << 20), device=ref.device, dtype=torch.uint8)
+        _WS[key] = ws
+    return ws
+
+
+def gemm_skinny(a, b, out, nn=False, bias=None):
+    """out[M,N] = a[M,K] @ b[N,K]^T (nn=False) or a[M,K] @ b[K,N] (nn=True) for M <= 256 rows: split-K over the CUs, the weight
+    streamed exactly once; fp32 partial slabs in a stream-local workspace"""
+    M, K = a.shape
+    N = b.shape[1] if nn else b.shape[0]
+    same(a, b)
+    ws = workspace(lib.lrp_gemm_skinny_ws(M, N, K), a)
+    check(lib.lrp_gemm_skinny(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(aux(bias, a, N)), M, N, K, a.stride(0), b.stride(0),
+                              out.stride(0), int(nn), dt(a), _DT[out.dtype], ws.data_ptr(), stream()), "lrp_gemm_skinny")
+    return out
+
+
 def transpose(x, out=None):
     """[..., R, C] -> [..., C, R] (contiguous)"""
     x = _c(x)
@@ -397,18 +453,12 @@ def linear_eps_smallm(x, W, bias, g, eps, relevance_in=False, relevance_out=True
     return (out, z) if want_z else out
 
 
-SMALLM_MAX = 16          # rows the W-streaming small-M kernels serve (above: the MFMA GEMM)
-_SMALLM_WS = {}
+SMALLM_MAX = 16          # rows the W-streaming small-M kernels serve (above: the skinny split-K path, then the MFMA GEMM)
 
 
 def _smallm_ws(M, N, K, ref):
-    """per-device fp32 scratch for the small-M kernels, grown on demand and reused (stream-ordered use only)"""
-    need = lib.lrp_linear_smallm_ws(M, N, K, dt(ref))
-    ws = _SMALLM_WS.get(ref.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 20), device=ref.device, dtype=torch.float32)
-        _SMALLM_WS[ref.device] = ws
-    return ws
+    """fp32 scratch of the small-M kernels: the per-(device, stream) workspace (capture-safe, see workspace())"""
+    return workspace(4 * lib.lrp_linear_smallm_ws(M, N, K, dt(ref)), ref)
 
 
 def smallm_ok(M, W, x=None):
@@ -450,6 +500,64 @@ def linear_smallm_dgrad(g, W, z=None, x=None, eps=0.0, relevance_in=False, relev
                                       z.stride(0) if z is not None else 0, eps, int(relevance_in), int(relevance_out), dt(W),
                                       _DT[out.dtype], stream()), "lrp_linear_smallm_dgrad")
     return out
+
+
+def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
+    """z[M,N] = x2[M,K] @ W[N,K]^T (+ bias) on the kernel that fits M (ref: lxt/explicit/functional.py:351):
+       M <= 256 rows, bf16, K % 64 == 0 : split-K skinny path of the ping-pong GEMM (W streamed once by all CUs)
+       M <= 16 otherwise                : W-streaming small-M kernels (fp32, odd K)
+       else                             : the MFMA GEMM (lrp_gemm_nt)"""
+    M, K = x2.shape
+    N = W.shape[0]
+    odt = out_dtype or (out.dtype if out is not None else x2.dtype)
+    if M <= SKINNY_MAX and gemm_nn_ok(x2, W) and W.is_contiguous():
+        if out is None:
+            out = torch.empty(M, N, device=x2.device, dtype=odt)
+        return gemm_skinny(x2, W, out, nn=False, bias=bias)
+    if smallm_ok(M, W, x2):
+        return linear_smallm_fwd(x2, W, bias, out=out, out_dtype=odt)
+    if out is not None and x2.stride(1) == 1 and W.stride(1) == 1 and x2.dtype == W.dtype and x2.stride(0) % epc(x2) == 0:
+        return gemm_nt_2d(x2, W, out, bias)
+    z = gemm_nt(x2, W, bias, out_dtype=odt)
+    if out is not None:
+        out.copy_(z)
+        return out
+    return z
+
+
+def linear_dgrad(s2, W, out=None, out_dtype=None):
+    """c[M,K] = s2[M,N] @ W[N,K]: the redistribution half of the Linear eps-rule (ref: lxt/explicit/functional.py:355-364) from the
+    STORED weight layout:
+       M <= 4, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
+       M <= 256, bf16, N % 64 == 0                           : split-K skinny path, NN form
+       larger bf16 problems                                  : lrp_gemm_nn (no W^T copy)
+       everything else (fp32 parity path, odd shapes)        : lrp_gemm_nt on a W^T copy cached on the weight (ops.weight_t)"""
+    M, N = s2.shape
+    K = W.shape[1]
+    odt = out_dtype or (out.dtype if out is not None else W.dtype)
+    nn = gemm_nn_ok(s2, W)
+    if (M <= 4 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
+        return linear_smallm_dgrad(s2, W, out=out, out_dtype=odt)
+    if nn:
+        if out is None:
+            out = torch.empty(M, K, device=s2.device, dtype=odt)
+        return gemm_skinny(s2, W, out, nn=True) if M <= SKINNY_MAX else gemm_nn_2d(s2, W, out)
+    wt = weight_t(W)
+    if out is not None and s2.stride(1) == 1 and s2.dtype == wt.dtype and s2.stride(0) % epc(s2) == 0:
+        return gemm_nt_2d(s2, wt, out)
+    c = gemm_nt(s2, wt, out_dtype=odt)
+    if out is not None:
+        out.copy_(c)
+        return out
+    return c
+
+
+def clear_weight_cache(*weights):
+    """drop the cached W^T copies (fp32 / odd-shape dgrad path) of the given weight tensors -- call after writing to a weight through
+    `.data` (optimizers, adapter / quantisation loaders), which does not bump `_version` and would leave a stale W^T behind"""
+    for w in weights:
+        if hasattr(w, "__dict__"):
+            w.__dict__.pop("_lrp_wt", None)
 
 
 # -------------------------------------------------------------------------------------- attention

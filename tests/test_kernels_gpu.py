@@ -54,8 +54,8 @@ def test_gemm_nt(ops, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(3301, 3700, 192), (4096, 3100, 128), (3600, 3584, 64), (3333, 3841, 320)])
 def test_gemm_nt_big_tile_path(ops, dtype, M, N, K):
-    """>= 190 tiles of 256x256: the software-pipelined 16-wave kernel (ragged M / N: clamped rows, odd and minimal numbers
-    of K steps; one K step falls back to the plain form), bias, row strides larger than K"""
+    """>= 190 tiles of 256x256: the 8-wave ping-pong kernel (ragged M / N: rows past the operand read as zero, odd and minimal
+    numbers of K tiles; one K tile falls back to the plain form), bias, row strides larger than K"""
     g = torch.Generator().manual_seed(5)
     a = torch.randn(M, K + 64, generator=g).to(dtype).cuda()[:, :K]
     b = (torch.randn(N, K + 64, generator=g) * K ** -0.5).to(dtype).cuda()[:, :K]
@@ -67,6 +67,49 @@ def test_gemm_nt_big_tile_path(ops, dtype, M, N, K):
     # every tile, not only the largest entries: block-wise normalised error
     blk = (out.double() - ref).abs().reshape(-1)[: (M * N // 4096) * 4096].reshape(-1, 4096).max(1).values
     assert float(blk.max()) < 4 * TOL[dtype] * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,odt", [(4096, 4096, 4096, torch.bfloat16), (3301, 3700, 192, torch.bfloat16), (4096, 3100, 128, torch.float32),
+                                       (3333, 3841, 320, torch.bfloat16), (2048, 6144, 1024, torch.float32), (300, 520, 256, torch.bfloat16)])
+def test_gemm_nn_from_stored_weight(ops, M, N, K, odt):
+    """lrp_gemm_nn: C = A[M,K] @ W[K,N] with W row-major -- the eps-rule redistribution c = s W from the STORED weight [out,in] (no W^T
+    copy; ref lxt/explicit/functional.py:355-364): the transposed MFMA operand is gathered from a row-major LDS tile by
+    ds_read_b64_tr_b16.  Ragged M / N / odd K-tile counts, row pitches larger than the logical width, bf16 and fp32 outputs; every tile
+    is checked (block-wise normalised error), against fp64 on the same bf16 operands."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(M, K + 64, generator=g).bfloat16().cuda()[:, :K]
+    w = (torch.randn(K, (N + 71) // 8 * 8, generator=g) * K ** -0.5).bfloat16().cuda()[:, :N]
+    out = torch.full((M, N + 8), float("nan"), dtype=odt, device="cuda")[:, :N]
+    assert ops.gemm_nn_ok(a, w)
+    ops.gemm_nn_2d(a, w, out)
+    ref = f64(a) @ f64(w)
+    tol = TOL[torch.bfloat16] if odt == torch.bfloat16 else 2e-5
+    assert not torch.isnan(out).any() and nmax(out, ref) < tol
+    blk = (out.double() - ref).abs().reshape(-1)[: (M * N // 4096) * 4096].reshape(-1, 4096).max(1).values
+    assert float(blk.max()) < 4 * tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nn", [False, True])
+@pytest.mark.parametrize("M", [1, 4, 16, 17, 33, 100, 160, 256])
+def test_gemm_skinny_split_k(ops, M, nn):
+    """lrp_gemm_skinny: 1 <= M <= 256 rows, split-K over the CUs + fp32 slab reduction (+ bias, cast); forward z = x W^T (nn = 0) and
+    redistribution c = s W from the stored weight (nn = 1); vs fp64 on the same bf16 operands"""
+    g = torch.Generator().manual_seed(M + 7 * nn)
+    N, K = (1536, 1024) if M % 2 else (1000, 2048 + 128)
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    if nn:
+        b = (torch.randn(K, (N + 15) // 8 * 8, generator=g) * K ** -0.5).bfloat16().cuda()[:, :N]
+        ref = f64(a) @ f64(b)
+    else:
+        b = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        ref = f64(a) @ f64(b).T
+    bias = torch.randn(N, generator=g).bfloat16().cuda() if M % 3 == 0 else None
+    if bias is not None:
+        ref = ref + f64(bias)
+    for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL[torch.bfloat16])):
+        out = torch.full((M, N), float("nan"), dtype=odt, device="cuda")
+        ops.gemm_skinny(a, b, out, nn=nn, bias=bias)
+        assert not torch.isnan(out).any() and nmax(out, ref) < tol, (M, nn, odt)
 
 
 def test_gemm_batched_and_f32_out(ops):
