@@ -86,12 +86,13 @@ def pmc_traffic():
 
 def smallm_roofline(ops, dtype, device, cfg, batch):
     """secondary roofline: the Linear eps-rule in its HBM-bound regime (north star: ">= 60 % HBM roofline on the Linear eps-rule
-    kernel").  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
-    [vocab, hidden] at M = prompts per step -- forward z = x W^T (lrp_linear_smallm_fwd) and eps-rule redistribution
-    c = (g z/(z+eps)) W (lrp_linear_smallm_dgrad), each streaming W ONCE from its stored layout (no W^T copy).  Algorithmic bytes
-    = sizeof * (N K + M K + M N) forward, sizeof * (N K + M K + 2 M N) backward; durations from HIP events on the launching stream,
-    20 launches each.  `table` adds M = 1, 2, 4, 8, 16 on the gate/up-sized weight [14336, 4096] and the one-pass fused kernel
-    (z recompute + redistribution in ONE pass over W, lrp_linear_eps_smallm, M <= 4)."""
+    kernel"; SURVEY.md 8d: bf16 arithmetic intensity ~2 M FLOP/B, HBM-bound for M <~ 160 rows).  Everything is timed THROUGH THE PRODUCT
+    DISPATCH (ops.linear_fwd / ops.linear_dgrad: W-streaming small-M kernels, the split-K skinny path of the ping-pong GEMM in its NT
+    and NN forms -- W is read ONCE per direction from its stored layout, no W^T copy), plus lrp_eps_scale where the dispatch does not
+    fuse the stabiliser.  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
+    [vocab, hidden] at M = prompts per step.  `table` = M = 1 ... 160 on the gate/up-sized weight [14336, 4096] and on the LM head.
+    Algorithmic bytes = sizeof * (N K + M K + M N) forward, sizeof * (N K + M K + 2 M N) backward; HIP events on the launching
+    stream, 20 launches each."""
     g = torch.Generator(device=device).manual_seed(3)
     es = torch.empty(0, dtype=dtype).element_size()
 
@@ -107,38 +108,37 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / 20
 
-    def pair(M, N, K):
+    def pair(M, N, K, W=None):
         x = torch.randn(M, K, generator=g, device=device).to(dtype)
-        W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
+        if W is None:
+            W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
         gg = torch.randn(M, N, generator=g, device=device).to(dtype)
-        z = ops.linear_smallm_fwd(x, W)
-        out = ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6)
-        tf = timed(lambda: ops.linear_smallm_fwd(x, W, out=z))
-        tb = timed(lambda: ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out))
+        z = ops.linear_fwd(x, W)
+        out = torch.empty(M, K, device=device, dtype=dtype)
+
+        def bwd():      # eps-rule redistribution c = (g z/(z+eps)) W
+            if M <= 4:
+                return ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the W stream
+            return ops.linear_dgrad(ops.eps_scale(gg, z, 1.0, 1e-6), W, out=out)
+        bwd()
+        tf = timed(lambda: ops.linear_fwd(x, W, out=z))
+        tb = timed(bwd)
         bf, bb = es * (N * K + M * K + M * N), es * (N * K + M * K + 2 * M * N)
         return dict(M=M, N=N, K=K, fwd_us=tf * 1e6, fwd_GBs=bf / tf / 1e9, dgrad_us=tb * 1e6, dgrad_GBs=bb / tb / 1e9,
                     pair_GBs=(bf + bb) / (tf + tb) / 1e9, pair_frac=(bf + bb) / (tf + tb) / 1e9 / 8000.0)
 
-    M = min(batch, ops.SMALLM_MAX)
-    head = pair(M, cfg["vocab"], cfg["hidden"])
-    table = [pair(m, 2 * cfg["inter"] // 2, cfg["hidden"]) for m in (1, 2, 4, 8, 16)]
-    fused = None
-    try:
-        Mf, N, K = 1, cfg["inter"], cfg["hidden"]
-        x = torch.randn(Mf, K, generator=g, device=device).to(dtype)
-        W = (torch.randn(N, K, generator=g, device=device) * K ** -0.5).to(dtype)
-        gg = torch.randn(Mf, N, generator=g, device=device).to(dtype)
-        ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(Mf, N, K), device=device)
-        t = timed(lambda: ops.linear_eps_smallm(x, W, None, gg, 1e-6, workspace=ws))
-        nb = es * (N * K + 2 * Mf * K + Mf * N)
-        fused = dict(M=Mf, N=N, K=K, us=t * 1e6, GBs=nb / t / 1e9, frac=nb / t / 1e9 / 8000.0)
-    except RuntimeError:
-        pass
-    return {"bound": "hbm", "kernel": f"lrp_linear_smallm_fwd + lrp_linear_smallm_dgrad (Linear eps-rule, M={M} rows, W [{cfg['vocab']},{cfg['hidden']}] "
+    M = min(batch, 256)
+    Wh = (torch.randn(cfg["vocab"], cfg["hidden"], generator=g, device=device) * cfg["hidden"] ** -0.5).to(dtype)
+    head = pair(M, cfg["vocab"], cfg["hidden"], Wh)
+    rows = (1, 2, 4, 8, 16, 32, 64, 128, 160)
+    table = [pair(m, cfg["inter"], cfg["hidden"]) for m in rows]
+    table_head = [pair(m, cfg["vocab"], cfg["hidden"], Wh) for m in rows]
+    del Wh
+    return {"bound": "hbm", "kernel": f"ops.linear_fwd + ops.linear_dgrad (Linear eps-rule, M={M} rows, W [{cfg['vocab']},{cfg['hidden']}] "
                                       "= the LM head, the largest one-row-per-prompt Linear explain() runs)",
             "achieved": head["pair_GBs"], "peak": 8000.0, "unit": "GB/s", "frac": head["pair_frac"],
             "avg_launch_us": (head["fwd_us"] + head["dgrad_us"]) / 2, "traffic": None, "head": head, "table_gate_up_sized": table,
-            "one_pass_fused": fused}
+            "table_lm_head": table_head}
 
 
 def config5_probe(eng, ops, cfg, dev, peak, steps=3):
@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
+    ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (LlamaLRP.explain(graph=True)); pays at small batch")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing self-test WITHOUT kernels or a GPU (gloo): rank env, sharding, barrier, max-over-ranks, gather, "
                          "one JSON line from rank 0 -- value is null; used by tests/test_dist_cpu.py for the N>1 launch contract")
@@ -256,7 +257,8 @@ def main():
     def step(i):
         chunk = ids_all[i * n_total: (i + 1) * n_total]
         lo, hi = D.shard_range(n_total, rank, world)
-        return eng.explain(chunk[lo:hi])["R_tok"]               # this rank's shard; the all-gather (C2) is per JOB, below
+        r = eng.explain(chunk[lo:hi], graph=args.graph)["R_tok"]    # this rank's shard; the all-gather (C2) is per JOB, below
+        return r.clone() if args.graph else r
 
     for i in range(args.warmup):
         R = step(i)

@@ -91,16 +91,6 @@ int lrp_eps_scale2d(const void* g, const void* z, void* out, int rows, int cols,
 /* out = a (*) b  (R = x (*) G read-out of a rule, ref: functional.py:362 ".mul_(inputs)") */
 int lrp_mul(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 
-/* Small-M Linear eps-rule in ONE pass over W (HBM-bound regime, M <= 4):
- *   z = x W^T + b ; s = g (*) z/(z+eps)  [or r/(z+eps) if relevance_in] ;
- *   out = s W  [ (*) x if relevance_out ]      out fp32 [M,K]; z_out optional fp32 [M,N].
- *   workspace: fp32 scratch of lrp_linear_eps_smallm_ws(M,N,K) floats (split-N slabs, no atomics).
- * ref: lxt/explicit/functional.py:345-364 ; BASELINE config 1 (768->768, M=1). */
-int64_t lrp_linear_eps_smallm_ws(int M, int N, int K);
-int lrp_linear_eps_smallm(const void* x, const void* W, const void* bias, const void* g,
-                          float* out, float* z_out, float* workspace, int M, int N, int K,
-                          float eps, int relevance_in, int relevance_out, int dtype, void* stream);
-
 /* Small-M Linear (M <= 16) as W-streaming kernels -- what the engine runs for its one-row-per-prompt top layer, the
  * last-token LM head and dense logit seeds, and lxt_amd.explicit.functional.linear_epsilon for M <= 16.  W [N,K] row-major is
  * read ONCE per call and no W^T copy is needed in either direction (HBM-bound: roofline 8 TB/s).

@@ -1,198 +1,12 @@
-// linear_smallm.hip -- K1 in its HBM-bound regime: the Linear eps-rule for M <= 8 rows in ONE
-// pass over W.  ref: lxt/explicit/functional.py:345-364 (z = xW^T+b ; s = R/(z+eps) ; R_in = x*(sW)).
-//
-// z_n needs a full K reduction before s_n exists while c_k = sum_n s_n W[n,k] reduces over N, so a
-// single pass over W must be N-blocked: a WAVE owns one row of W at a time, keeps it in registers
-// (K*sizeof/1 KiB x 16-byte chunks per lane), computes z_n for every m with a wave reduction,
-// forms s_n, and immediately re-uses the registers for the axpy into per-lane partial c.  Rows are
-// streamed straight to VGPRs (no LDS round trip: nothing is shared between waves), x sits in LDS.
-// Split-N reduction WITHOUT atomics (fp32 atomics cap at ~15 G/s: 16 M of them cost 1 ms where the
-// W stream costs 6 us): the 4 waves of a workgroup fold their partial c through LDS, the workgroup
-// writes one fp32 slab [M,K] to a caller-provided workspace, and a second tiny kernel sums the
-// <= 256 slabs (L2-resident, just written) and applies the optional (*) x.
-// Algorithmic HBM bytes = sizeof(T)*(N*K + 2*M*K + M*N): W is read exactly once.
+// linear_smallm.hip -- K1 in its HBM-bound regime for M <= 16 rows: W-streaming forward and eps-rule dgrad kernels that read W [N,K]
+// exactly once from its stored layout (fp32 and bf16, any N, K a multiple of 16 bytes).  ref: lxt/explicit/functional.py:345-364
+// (z = xW^T+b ; s = R/(z+eps) ; R_in = x*(sW)).  bf16 problems with K % 64 == 0 are also served -- up to M = 256 rows -- by the split-K
+// skinny path of the ping-pong GEMM (gemm.hip: lrp_gemm_skinny); ops.linear_fwd / ops.linear_dgrad choose.
+// (The round-1 one-pass kernel -- z recompute + redistribution in one sweep over W, M <= 4 -- was removed in round 3: with forward and
+// backward separated in time by the protocol, W is read once per direction either way, and the pair below is faster per direction.)
 #include "common.hpp"
 
 namespace {
-
-template <typename T, int KCH, int MM, int NWV>
-__global__ __launch_bounds__(64 * NWV) void linear_eps_smallm_kernel(
-    const T* __restrict__ x, const T* __restrict__ W, const T* __restrict__ bias, const T* __restrict__ g,
-    float* __restrict__ out, float* __restrict__ z_out, int M, int N, int K, float eps, int rel_in, int rel_out) {
-    constexpr int EPC = 16 / (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sx = reinterpret_cast<T*>(smem);                       // [MM][KCH*64*EPC], zero padded
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int KP = KCH * 64 * EPC;
-    for (int i = threadIdx.x; i < MM * KP; i += blockDim.x) {
-        const int m = i / KP, k = i % KP;
-        sx[i] = (m < M && k < K) ? x[(int64_t)m * K + k] : from_f32<T>(0.f);
-    }
-    __syncthreads();
-
-    float acc[MM][KCH][EPC];
-#pragma unroll
-    for (int m = 0; m < MM; ++m)
-#pragma unroll
-        for (int j = 0; j < KCH; ++j)
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[m][j][e] = 0.f;
-
-    const int nwave = gridDim.x * NWV;
-    auto load_row = [&](Vec16<T>(&w)[KCH], int n) {
-#pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            const int k = (j * 64 + lane) * EPC;
-            if (k < K) w[j] = ld16(W + (int64_t)n * K + k);
-            else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) w[j].set(e, 0.f);
-            }
-        }
-    };
-    auto process = [&](const Vec16<T>(&w)[KCH], int n) {
-        float s[MM];
-#pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < KCH; ++j) {
-                const Vec16<T> xv = ld16(sx + m * KP + (j * 64 + lane) * EPC);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) d += w[j].get(e) * xv.get(e);
-            }
-            d = wave_sum(d);
-            float z = d + (bias ? to_f32(bias[n]) : 0.f);
-            z = to_f32(from_f32<T>(z));                              // the forward's stored z (storage dtype)
-            if (m < M) {
-                if (z_out && lane == 0) z_out[(int64_t)m * N + n] = z;
-                const float gv = to_f32(g[(int64_t)m * N + n]);
-                s[m] = rel_in ? gv / (z + eps) : gv * eps_ratio(z, 1.f, eps);
-            } else s[m] = 0.f;
-        }
-#pragma unroll
-        for (int m = 0; m < MM; ++m)
-#pragma unroll
-            for (int j = 0; j < KCH; ++j)
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[m][j][e] += s[m] * w[j].get(e);
-    };
-    // two register sets: the row after next streams in while the current one is reduced / axpy'd
-    // (only when the workgroup is small; 16-wave workgroups hide the latency by occupancy instead)
-    constexpr bool DBUF = (NWV <= 8) && (MM * KCH * EPC <= 64);
-    int n = blockIdx.x * NWV + wave;
-    if constexpr (DBUF) {
-        Vec16<T> w0[KCH], w1[KCH];
-        if (n < N) load_row(w0, n);
-        while (n < N) {
-            const int n1 = n + nwave, n2 = n1 + nwave;
-            if (n1 < N) load_row(w1, n1);
-            process(w0, n);
-            if (n1 >= N) break;
-            if (n2 < N) load_row(w0, n2);
-            process(w1, n1);
-            n = n2;
-        }
-    } else {
-        Vec16<T> w0[KCH];
-        for (; n < N; n += nwave) { load_row(w0, n); process(w0, n); }
-    }
-    // fold the waves' partial sums through LDS in ONE step: every wave parks its partial c in its own
-    // [MM][KP] fp32 region (16-byte stores, lane-linear), one barrier, then each thread sums the NWV copies
-    // of its float4 columns and writes the workgroup's slab row directly (x is no longer needed in LDS).
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                      // [NWV][MM][KP] fp32 (host sizes LDS for it)
-#pragma unroll
-    for (int m = 0; m < MM; ++m)
-#pragma unroll
-        for (int j = 0; j < KCH; ++j) {
-            float* dst = red + ((size_t)(wave * MM + m) * KP) + (j * 64 + lane) * EPC;
-#pragma unroll
-            for (int e4 = 0; e4 < EPC / 4; ++e4)
-                *reinterpret_cast<f32x4*>(dst + e4 * 4) = f32x4{acc[m][j][e4 * 4], acc[m][j][e4 * 4 + 1], acc[m][j][e4 * 4 + 2], acc[m][j][e4 * 4 + 3]};
-        }
-    __syncthreads();
-    float* slab = out + (int64_t)blockIdx.x * M * K;                  // `out` is the workspace here
-    for (int i = threadIdx.x; i < MM * KP / 4; i += blockDim.x) {
-        const int m = (i * 4) / KP, k = (i * 4) - m * KP;
-        if (m >= M || k >= K) continue;
-        f32x4 sum = *reinterpret_cast<const f32x4*>(red + (size_t)m * KP + k);
-#pragma unroll
-        for (int w = 1; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(red + ((size_t)(w * MM + m) * KP) + k);
-        *reinterpret_cast<f32x4*>(slab + (size_t)m * K + k) = sum;
-    }
-}
-
-// out[i] = sum_b ws[b][i] (*x[i]) : 256 threads = 16 slab groups x 16 float4 columns; every thread sums
-// nslab/16 independent float4 loads, the 16 groups fold through LDS (MK % 4 == 0 is guaranteed by K % EPC)
-template <typename T>
-__global__ void smallm_reduce_kernel(const float* __restrict__ ws, const T* __restrict__ x, float* __restrict__ out,
-                                     int nslab, int MK, int rel_out) {
-    __shared__ f32x4 part[16][16];
-    const int ql = threadIdx.x & 15, sg = threadIdx.x >> 4;
-    const int i = (blockIdx.x * 16 + ql) * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (i < MK) {
-#pragma unroll 4
-        for (int b = sg; b < nslab; b += 16) s += *reinterpret_cast<const f32x4*>(ws + (int64_t)b * MK + i);
-    }
-    part[sg][ql] = s;
-    __syncthreads();
-    if (sg == 0 && i < MK) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) s += part[k][ql];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[i + e] = rel_out ? s[e] * to_f32(x[i + e]) : s[e];
-    }
-}
-
-inline int smallm_blocks(int N) {
-    constexpr int cap = 256;     // one workgroup per CU (measured: 512 / 1024 are 30 % / 90 % slower -- per-workgroup fold + slab cost)
-    int nb = (N + 15) / 16;
-    return nb > cap ? cap : (nb < 1 ? 1 : nb);
-}
-
-template <typename T, int KCH, int MM>
-int launch(const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, float* ws, int M, int N,
-           int K, float eps, int rel_in, int rel_out, hipStream_t st) {
-    constexpr int EPC = 16 / (int)sizeof(T);
-    // bytes of W in flight per CU must cover HBM latency x 6 TB/s / 256 CUs (~50 KiB): 16 waves per
-    // workgroup when the per-lane state fits 128 VGPRs, 8 waves + a second register set (row n+2 streams
-    // in under row n's reduction) at 256 VGPRs, 4 waves for the largest K
-    constexpr int STATE = MM * KCH * EPC;
-    constexpr int NWV = (STATE <= 32) ? 16 : ((STATE <= 64) ? 8 : 4);
-    const size_t kp = (size_t)KCH * 64 * EPC;
-    const size_t lds = (size_t)NWV * MM * kp * 4;                      // x (T) first, then NWV fp32 fold regions
-    auto kern = linear_eps_smallm_kernel<T, KCH, MM, NWV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const int nb = smallm_blocks(N);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NWV), lds, st, (const T*)x, (const T*)W, (const T*)bias, (const T*)g, ws, z_out,
-                       M, N, K, eps, rel_in, rel_out);
-    const int MK = M * K;
-    hipLaunchKernelGGL((smallm_reduce_kernel<T>), dim3((MK + 63) / 64), dim3(256), 0, st, ws, (const T*)x, out, nb, MK, rel_out);
-    return lrp_check_launch();
-}
-
-template <typename T, int MM>
-int launch_k(int kch, const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out, float* ws, int M,
-             int N, int K, float eps, int rel_in, int rel_out, hipStream_t st) {
-    constexpr int EPC = 16 / (int)sizeof(T);
-    if (kch <= 1) return launch<T, 1, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
-    if (kch <= 2) return launch<T, 2, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
-    if (kch <= 4) return launch<T, 4, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
-    if constexpr (MM * 8 * EPC <= 128) {
-        if (kch <= 8) return launch<T, 8, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
-    }
-    if constexpr (MM * 16 * EPC <= 128) {
-        if (kch <= 16) return launch<T, 16, MM>(x, W, bias, g, out, z_out, ws, M, N, K, eps, rel_in, rel_out, st);
-    }
-    return LRP_ESHAPE;
-}
-
 
 // =====================================================================================================================
 // Small-M forward and dgrad as pure W-streaming kernels (M <= 16).  One WAVE per workgroup owns a [rows x 512 columns]
@@ -579,29 +393,4 @@ extern "C" int lrp_linear_smallm_dgrad(const void* g, const void* z, const void*
     if (dtype == LRP_F32) { SMALLM_MM(M, return (launch_dgrad<float, float, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));) }
     if (out_dtype == LRP_F32) { SMALLM_MM(M, return (launch_dgrad<bf16_t, float, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));) }
     SMALLM_MM(M, return (launch_dgrad<bf16_t, bf16_t, MM>(W, g, z, x, out, workspace, M, N, K, ldg, ldz, eps, relevance_in, relevance_out, st));)
-}
-
-extern "C" int64_t lrp_linear_eps_smallm_ws(int M, int N, int K) { return (int64_t)smallm_blocks(N) * M * K; }
-
-extern "C" int lrp_linear_eps_smallm(const void* x, const void* W, const void* bias, const void* g, float* out, float* z_out,
-                                     float* workspace, int M, int N, int K, float eps, int relevance_in, int relevance_out,
-                                     int dtype, void* stream) {
-    if (!x || !W || !g || !out || !workspace || M < 1 || N < 1 || K < 1) return LRP_EINVAL;
-    if (dtype != LRP_F32 && dtype != LRP_BF16) return LRP_EINVAL;
-    const int epc = dtype == LRP_F32 ? 4 : 8;
-    if ((K % epc) || (reinterpret_cast<uintptr_t>(W) & 15)) return LRP_EALIGN;
-    if (M > 4) return LRP_ESHAPE;
-    const int kch = (K + 64 * epc - 1) / (64 * epc);
-    hipStream_t st = (hipStream_t)stream;
-#define GO(T, MM) return launch_k<T, MM>(kch, x, W, bias, g, out, z_out, workspace, M, N, K, eps, relevance_in, relevance_out, st)
-    if (dtype == LRP_F32) {
-        if (M == 1) GO(float, 1);
-        if (M == 2) GO(float, 2);
-        GO(float, 4);
-    } else {
-        if (M == 1) GO(bf16_t, 1);
-        if (M == 2) GO(bf16_t, 2);
-        GO(bf16_t, 4);
-    }
-#undef GO
 }

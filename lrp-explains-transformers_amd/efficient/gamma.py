@@ -27,7 +27,7 @@ class GammaLinearFn(Function):
     def forward(ctx, x, weight, bias, gamma, eps, cache):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous()
-        z = ops.gemm_nt(x2, weight, bias)
+        z = ops.linear_fwd(x2, weight, bias)            # the same dispatch as the un-ruled LinearFn: identical forward values
         ctx.save_for_backward(x2, z)
         ctx.meta = (weight, bias, gamma, eps, cache, shp)
         return z.view(*shp[:-1], weight.shape[0])

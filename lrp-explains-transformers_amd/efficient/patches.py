@@ -66,6 +66,9 @@ def adopt(model):
     return model
 
 
+_WARNED = {}
+
+
 def _owned(m):
     return m.__dict__.get("_lrp_owned", False)
 
@@ -110,6 +113,13 @@ def layer_norm_forward(self, x):
     """identity rule on LayerNorm's 1/std (ref: lxt/efficient/patches.py:126-142); instances outside an explained model
     keep torch's own forward"""
     if not _owned(self) and hasattr(self, "original_forward"):
+        if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and not _WARNED.get("layer_norm"):
+            # the reference's class-level patch covers EVERY nn.LayerNorm of the process; here only adopted instances take the rule
+            _WARNED["layer_norm"] = True
+            warn("lxt_amd.efficient: an nn.LayerNorm that is not part of an adopted model was called under autograd after monkey_patch; it "
+                 "runs torch's own forward (plain gradient, NO identity rule on 1/std).  HuggingFace models of the patched module and "
+                 "torchvision's VisionTransformer are adopted automatically; for any other model call lxt_amd.efficient.adopt(model) "
+                 "(again after adding modules) so that its LayerNorm / Linear / Conv2d instances take the LRP rules.")
         return self.original_forward(x)
     _need_cuda(x, "layer_norm_forward")
     return LayerNormFn.apply(x, self.weight, self.bias, float(self.eps))

@@ -31,6 +31,20 @@ EFFICIENT = dict(lin=0.0, add=0.0, qk=0.0, mask=0.0, pv=0.0, rope=0.0, act=1e-10
 _STATIC_ROPE = ("default", "linear", "llama3", "yarn")
 
 
+def rope_kind(hf_cfg):
+    """rope type of a HF config: transformers 5 keeps it in `rope_parameters`, transformers 4.x in `rope_scaling` (key 'rope_type', legacy
+    key 'type') next to `rope_theta` -- Llama-3.1 / 3.2 there carry {'rope_type': 'llama3', ...}, which must not be dropped silently"""
+    rp = getattr(hf_cfg, "rope_parameters", None)
+    if isinstance(rp, dict):
+        return rp.get("rope_type", rp.get("type", "default"))
+    rs = getattr(hf_cfg, "rope_scaling", None)
+    if rs is None:
+        return "default"
+    if isinstance(rs, dict) and (rs.get("rope_type") or rs.get("type")):
+        return rs.get("rope_type") or rs.get("type")
+    raise NotImplementedError(f"LlamaLRP: cannot interpret rope_scaling={rs!r}")
+
+
 def config_from_hf(hf_cfg):
     """HF LlamaConfig -> engine cfg.  Everything the fused driver does not implement is refused LOUDLY here instead of
     being ignored: other model types (use lxt_amd.efficient.monkey_patch for those), attention / MLP biases, and rope
@@ -55,12 +69,12 @@ def config_from_hf(hf_cfg):
                n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hd,
                vocab=hf_cfg.vocab_size, rope_theta=float(theta), rms_eps=float(hf_cfg.rms_norm_eps),
                act=getattr(hf_cfg, "hidden_act", "silu"))
-    kind = rp.get("rope_type", "default") if isinstance(rp, dict) else "default"
+    kind = rope_kind(hf_cfg)
     if kind not in _STATIC_ROPE:
         raise NotImplementedError(f"LlamaLRP: rope_type {kind!r} (sequence-length dependent frequencies) is not supported")
     if kind != "default":
         from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
-        inv_freq, att = ROPE_INIT_FUNCTIONS[kind](hf_cfg, "cpu")
+        inv_freq, att = ROPE_INIT_FUNCTIONS[kind](hf_cfg, "cpu")      # (the installed transformers' own initialiser for its own config class)
         cfg["inv_freq"], cfg["attention_scaling"] = inv_freq.float().cpu(), float(att)
     return cfg
 
@@ -168,57 +182,90 @@ class LlamaLRP:
         if mode not in ("explicit", "efficient"):
             raise ValueError(f"mode must be 'explicit' or 'efficient', got {mode!r}")
         self.mode = mode
+        self._graphs = {}
         self.eps = dict(EXPLICIT if mode == "explicit" else EFFICIENT)
         # identity rule (*) gate Linear eps: act/(g+eps_lin) in explicit form, act/(g+1e-10) efficient
         self.eps_g = self.eps["lin"] if mode == "explicit" else self.eps["act"]
 
     # ---------------------------------------------------------------------------------------------
+    class _Arena:
+        """Workspace arena: every activation stash and every temporary of one explanation lives in a flat buffer keyed by a tag; the
+        buffers persist across calls (same B*S -> no allocator traffic in the per-layer loops, and stable addresses for hipGraph
+        replay).  A tag is (name, layer or None); temporaries share one tag across layers."""
+
+        def __init__(self, device):
+            self.device, self.buf = device, {}
+
+        def get(self, tag, shape, dtype, zero=False):
+            n = 1
+            for s_ in shape:
+                n *= s_
+            t = self.buf.get((tag, dtype))
+            if t is None or t.numel() < n:
+                t = torch.empty(max(n, 1), device=self.device, dtype=dtype)
+                self.buf[(tag, dtype)] = t
+            v = t[:n].view(*shape)
+            return v.zero_() if zero else v
+
+        def nbytes(self):
+            return sum(t.numel() * t.element_size() for t in self.buf.values())
+
+    def release(self):
+        """drop the arena (and the captured graphs that point into it)"""
+        self._arena, self._graphs = None, {}
+
     def forward(self, emb, B, S, row_iv=None):
-        c, E = self.cfg, self.eps
+        c = self.cfg
         H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
         M = B * S
         dev, dt = self.device, self.dtype
         nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
         scale = d ** -0.5
-        new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        if getattr(self, "_arena", None) is None:
+            self._arena = LlamaLRP._Arena(dev)
+        ar = self._arena
+        new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
         stash = []
         h_prev, branch = emb, None
         last = torch.arange(B, device=dev) * S + (S - 1)
         for li, Lw in enumerate(self.layers):
             st = {}
             top = self.sparse_top and li == len(self.layers) - 1
+            x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
             if branch is None:
                 st["h"] = h_prev
-                x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"])
+                ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"], y=x, rstd=st["rstd1"])
             else:
-                st["h"] = new(M, H)
-                x, st["rstd1"] = ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"])
-            qkv = self._lin_fwd(x, Lw["wqkv"], new(M, nqkv))
-            qkr = ops.rope_fwd(qkv, new(M, nqk), self.cos, self.sin, S, nq + nk, d)
+                st["h"] = new(("h", li), M, H)
+                ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"], y=x, rstd=st["rstd1"])
+            qkv = self._lin_fwd(x, Lw["wqkv"], new(("qkv", li), M, nqkv))
+            qkr = ops.rope_fwd(qkv, new(("qkr", li), M, nqk), self.cos, self.sin, S, nq + nk, d)
             v = qkv[:, nqk:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
-            o = new(M, nq * d)
-            lse = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+            o = new(("o", li), M, nq * d)
+            lse = f32(("lse", li), B, nq, S)
             if top:
                 ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, q_begin=S - 1, row_iv=row_iv)
                 o_l, h_l = o.index_select(0, last), st["h"].index_select(0, last)
-                a_l = self._lin_fwd(o_l, Lw["wo"], new(B, H))
-                h1_l = new(B, H)
+                a_l = self._lin_fwd(o_l, Lw["wo"], new("a_l", B, H))
+                h1_l = new("h1_l", B, H)
                 x2_l, rstd2_l = ops.add_rmsnorm_fwd(h_l, a_l, Lw["ln2"], c["rms_eps"], hsum_out=h1_l)
-                gu_l = self._lin_fwd(x2_l, Lw["wgu"], new(B, 2 * I))
-                m_l = ops.gated_act_fwd(gu_l[:, :I], gu_l[:, I:], new(B, I), self.act)
-                dn_l = self._lin_fwd(m_l, Lw["wd"], new(B, H))
+                gu_l = self._lin_fwd(x2_l, Lw["wgu"], new("gu_l", B, 2 * I))
+                m_l = ops.gated_act_fwd(gu_l[:, :I], gu_l[:, I:], new("m_l", B, I), self.act)
+                dn_l = self._lin_fwd(m_l, Lw["wd"], new("dn_l", B, H))
                 st.update(top=True, qkv=qkv, qkr=qkr, lse=lse, o_l=o_l, a_l=a_l, h1_l=h1_l, rstd2_l=rstd2_l, gu_l=gu_l, dn_l=dn_l)
                 stash.append(st)
                 h_prev, branch = h1_l, dn_l
                 break
             ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
-            a = self._lin_fwd(o, Lw["wo"], new(M, H))
-            h1 = new(M, H)
-            x2, st["rstd2"] = ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1)
-            gu = self._lin_fwd(x2, Lw["wgu"], new(M, 2 * I))
-            m = ops.gated_act_fwd(gu[:, :I], gu[:, I:], new(M, I), self.act)
-            dn = self._lin_fwd(m, Lw["wd"], new(M, H))
+            a = self._lin_fwd(o, Lw["wo"], new(("a", li), M, H))
+            h1 = new(("h1", li), M, H)
+            x2, st["rstd2"] = new("x2", M, H), f32(("rstd2", li), M)
+            ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1, y=x2, rstd=st["rstd2"])
+            gu = self._lin_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I))
+            m = ops.gated_act_fwd(gu[:, :I], gu[:, I:], new("m", M, I), self.act)
+            dn = self._lin_fwd(m, Lw["wd"], new(("dn", li), M, H))
             st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
             stash.append(st)
             h_prev, branch = h1, dn
@@ -227,9 +274,9 @@ class LlamaLRP:
             h1_last, dn_last = h_prev, branch
         else:
             h1_last, dn_last = h_prev.index_select(0, last), branch.index_select(0, last)
-        hL_last = new(B, H)
+        hL_last = new("hL_last", B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h1_last, dn_last, self.norm, c["rms_eps"], hsum_out=hL_last)
-        logits = self._lin_fwd(xn, self.lm_head, torch.empty(B, c["vocab"], device=dev, dtype=torch.float32))
+        logits = self._lin_fwd(xn, self.lm_head, f32("logits", B, c["vocab"]))
         return dict(stash=stash, last=last, hL_last=hL_last, dn_last=dn_last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
 
     # ---------------------------------------------------------------------------------------------
@@ -240,10 +287,13 @@ class LlamaLRP:
         dev, dt = self.device, self.dtype
         nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
         scale = d ** -0.5
-        new = lambda *s: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        ar = self._arena
+        new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
+        zeros = lambda tag, *s: ar.get(tag, s, dt, zero=True)  # noqa: E731
         # LM head eps rule + final-norm identity rule on the single explained row of each prompt
         if seed is None:
-            Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new(B, H), 0.0, E["lin"])
+            Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new("Gh_last", B, H), 0.0, E["lin"])
         else:
             # dense seed over the last-position logits (contrastive explanations): gradient in efficient mode, relevance
             # in explicit mode (coef = R / (z + eps)); G_xn = coef @ W_lm (ops.linear_dgrad: W streamed once from its stored layout),
@@ -252,17 +302,17 @@ class LlamaLRP:
             if E["lin"] != 0.0:
                 coef = ops.eps_scale(coef, fw["logits"], 1.0, E["lin"], relevance=True)
             g_xn = ops.linear_dgrad(coef.to(dt), self.lm_head, out_dtype=torch.float32)
-            Gh_last = ops.head_norm_bwd(g_xn, self.norm, fw["rstd_f"], new(B, H))
+            Gh_last = ops.head_norm_bwd(g_xn, self.norm, fw["rstd_f"], new("Gh_last", B, H))
         # add2 at h_L = h1 + dn and the eps scale of the last down_proj, still one row per prompt
-        Gs_last, A_last = new(B, H), new(B, H)
-        rel_last = torch.empty(B, device=dev, dtype=torch.float32) if layer_relevance else None
+        Gs_last, A_last = new("Gs_last", B, H), new("A_last", B, H)
+        rel_last = f32("rel_last", B) if layer_relevance else None
         ops.rmsnorm_bwd_add2(Gh_last, None, None, None, fw["hL_last"], fw["dn_last"], Gs_last, A_last, rel_last,
                              0.0, E["add"], E["lin"])
         last, row_iv = fw["last"], fw["row_iv"]
         top_sparse = bool(fw["stash"]) and fw["stash"][-1].get("top", False)
         if not top_sparse:
-            Gs = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, Gs_last)
-            Adn = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, A_last)
+            Gs = zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, last, Gs_last)
+            Adn = zeros(("Adn", len(self.layers) & 1), M, H).index_copy_(0, last, A_last)
         layer_R = [rel_last] if layer_relevance else None
 
         for li in range(len(self.layers) - 1, -1, -1):
@@ -272,35 +322,37 @@ class LlamaLRP:
             if st.get("top", False):
                 # ---- one row per prompt through MLP, norm/add2 and o-proj; scatter into the dense attention inputs
                 gu_l = st["gu_l"]
-                Gm = self._lin_bwd(A_last, Lw["wd"], new(B, I))
-                Agu = new(B, 2 * I)
+                Gm = self._lin_bwd(A_last, Lw["wd"], new("Gm_l", B, I))
+                Agu = new("Agu_l", B, 2 * I)
                 ops.gated_act_bwd(Gm, gu_l[:, :I], gu_l[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new(B, H))
-                Gs1_l, Aa_l = new(B, H), new(B, H)
+                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2_l", B, H))
+                Gs1_l, Aa_l = new("Gs1_l", B, H), new("Aa_l", B, H)
                 ops.rmsnorm_bwd_add2(Gs_last, Gx2, Lw["ln2"], st["rstd2_l"], st["h1_l"], st["a_l"], Gs1_l, Aa_l, None, 0.0,
                                      E["add"], E["lin"])
-                Gof_l = self._lin_bwd(Aa_l, Lw["wo"], new(B, nq * d))
-                Gho_l = new(B, nq * d)
-                D_l = torch.empty(B, nq, 1, device=dev, dtype=torch.float32)
+                Gof_l = self._lin_bwd(Aa_l, Lw["wo"], new("Gof_l", B, nq * d))
+                Gho_l = new("Gho_l", B, nq * d)
+                D_l = f32("D_l", B, nq, 1)
                 ops.attn_bwd_prep(Gof_l, st["o_l"], Gho_l, D_l, B, 1, nq, d, E["pv"], 0.5)
-                Gho = torch.zeros(M, nq * d, device=dev, dtype=dt).index_copy_(0, last, Gho_l)
-                D = torch.zeros(B, nq, S, device=dev, dtype=torch.float32)
-                D[:, :, S - 1] = D_l[:, :, 0]
-                Gs1 = torch.zeros(M, H, device=dev, dtype=dt).index_copy_(0, last, Gs1_l)
+                # scatter the one live row per prompt into the dense [M, .] operands of the attention backward (library launches only:
+                # zero fill + row scatter; D's live column S-1 is a strided 2-D scatter of the same kind)
+                Gho = zeros("Gho", M, nq * d).index_copy_(0, last, Gho_l)
+                D = ar.get("D", (B, nq, S), torch.float32, zero=True)
+                D.view(B * nq, S)[:, S - 1].copy_(D_l.view(B * nq))
+                Gs1 = zeros("Gs1", M, H).index_copy_(0, last, Gs1_l)
                 q_begin = S - 1
             else:
                 gu = st["gu"]
                 # ---- MLP
-                Gm = self._lin_bwd(Adn, Lw["wd"], new(M, I))
-                Agu = new(M, 2 * I)
+                Gm = self._lin_bwd(Adn, Lw["wd"], new("Gm", M, I))
+                Agu = new("Agu", M, 2 * I)
                 ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
-                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new(M, H))
-                Gs1, Aa = new(M, H), new(M, H)
+                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
+                Gs1, Aa = new("Gs1", M, H), new("Aa", M, H)
                 ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
                 # ---- attention
-                Gof = self._lin_bwd(Aa, Lw["wo"], new(M, nq * d))
-                Gho = new(M, nq * d)
-                D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+                Gof = self._lin_bwd(Aa, Lw["wo"], new("Gof", M, nq * d))
+                Gho = new("Gho", M, nq * d)
+                D = f32("D", B, nq, S)
                 ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
             q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
             k_t = q_t = Gho_t = None
@@ -308,30 +360,30 @@ class LlamaLRP:
                 k_t = ops.transpose_heads(k, B, S, nk, d)
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
-            dqk = new(M, nqk) if q_begin == 0 else torch.zeros(M, nqk, device=dev, dtype=dt)
-            dk_h, dv_h = new(M, nq * d), new(M, nq * d)
+            dqk = new("dqk", M, nqk) if q_begin == 0 else zeros("dqk", M, nqk)
+            dk_h, dv_h = new("dk_h", M, nq * d), new("dv_h", M, nq * d)
             ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
                             q_begin=q_begin, row_iv=row_iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
                              q_begin=q_begin, row_iv=row_iv)
             ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
-            Aqkv = new(M, nqkv)
+            Aqkv = new("Aqkv", M, nqkv)
             if E["lin"] == 0.0:
                 ops.gqa_reduce(dv_h, Aqkv[:, nqk:], M, nk, rep, d)
                 ops.rope_bwd(dqk, None, None, Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, 0.0, 0.0)
             else:
-                dv = ops.gqa_reduce(dv_h, new(M, nk * d), M, nk, rep, d)
+                dv = ops.gqa_reduce(dv_h, new("dv", M, nk * d), M, nk, rep, d)
                 ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
                 ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
-            Gx = self._lin_bwd(Aqkv, Lw["wqkv"], new(M, H))
+            Gx = self._lin_bwd(Aqkv, Lw["wqkv"], new("Gx", M, H))
             # ---- input norm + the residual add below (or the embedding)
-            rel = torch.empty(M, device=dev, dtype=torch.float32) if layer_relevance else None
+            rel = f32(("rel", li), M) if layer_relevance else None
             if li > 0:
                 prev = fw["stash"][li - 1]
-                Gs, Adn = new(M, H), new(M, H)
+                Gs, Adn = new(("Gs", li & 1), M, H), new(("Adn", li & 1), M, H)
                 ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"], prev["dn"], Gs, Adn, rel, 0.0, E["add"], E["lin"])
             else:
-                Gs = new(M, H)
+                Gs = new(("Gs", 0), M, H)
                 ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"] if layer_relevance else None, None, Gs, None,
                                      rel, 0.0, 0.0, 0.0)
             if layer_relevance:
@@ -339,9 +391,29 @@ class LlamaLRP:
         return Gs, layer_R
 
     # ---------------------------------------------------------------------------------------------
+    def _run(self, input_ids, emb, B, S, row_iv, idx, layer_relevance, return_G, seed):
+        """forward + backward + read-out on the current stream: library launches only, no host synchronisation (capturable)"""
+        if emb is None:
+            emb = self.embed.index_select(0, input_ids.reshape(-1))
+        fw = self.forward(emb, B, S, row_iv)
+        if idx is None:
+            # (a dense seed explains no single logit; idx / logit then report the arg-max for convenience)
+            idx, _ = ops.argmax_rows(fw["logits"])
+        G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance, seed=seed)
+        R_tok = ops.readout(emb, G).view(B, S)
+        logits = fw["logits"].clone()                            # (the arena's buffer is overwritten by the next call)
+        out = dict(idx=idx, logit=logits.gather(1, idx.long()[:, None])[:, 0], R_tok=R_tok, logits=logits)
+        if layer_relevance:
+            rows = [layer_R[0]] + [r.view(B, S).sum(1) for r in layer_R[1:]]
+            out["layer_R"] = torch.stack(rows[::-1], 0)          # [L+1, B], index 0 = embedding
+        if return_G:
+            out["G_emb"] = G.view(B, S, -1).clone()
+            out["emb"] = emb.view(B, S, -1)
+        return out
+
     @torch.no_grad()
     def explain(self, input_ids=None, inputs_embeds=None, target=None, layer_relevance=False, return_G=False, lengths=None,
-                seed=None):
+                seed=None, graph=False):
         """input_ids [B,S] (or inputs_embeds [B,S,H]); target: None (arg-max of the last position) or
         int tensor [B].  Returns dict(idx [B], logit [B], R_tok [B,S] fp32, and optionally
         layer_R [L+1, B] (sum_h h (*) G_h at every residual-stream boundary) and G_emb [B,S,H]).
@@ -351,11 +423,13 @@ class LlamaLRP:
         single-prompt explanation up to rounding.  R_tok is exactly 0 at pad positions.
         seed [B,V] (optional, instead of target): what the reference's protocol passes to `logits[:, -1].backward(seed)` --
         a gradient over the last-position logits in efficient mode (contrastive explanations), a relevance over them
-        in explicit mode."""
+        in explicit mode.
+        graph=True (input_ids only, no lengths / seed / return_G): the ~1500 launches of one explanation of this (B, S) are captured
+        once into a hipGraph and replayed; the returned tensors are the graph's static outputs (copy them before the next call)."""
         if inputs_embeds is None:
             input_ids = input_ids.to(self.device)
             B, S = input_ids.shape
-            emb = self.embed.index_select(0, input_ids.reshape(-1))
+            emb = None
         else:
             B, S = inputs_embeds.shape[:2]
             emb = inputs_embeds.to(device=self.device, dtype=self.dtype).reshape(B * S, -1).contiguous()
@@ -372,28 +446,40 @@ class LlamaLRP:
             hi = torch.where(i[None] >= first, (i + 1)[None].expand(B, S), torch.zeros_like(lo)).contiguous()   # pad rows: empty
             row_iv = (lo, hi)
         V = self.cfg["vocab"]
+        idx = None
         if target is not None:
             tgt = torch.as_tensor(target).reshape(-1).cpu().long()
             if tgt.numel() != B or int(tgt.min()) < 0 or int(tgt.max()) >= V:
                 raise ValueError(f"target must hold {B} vocabulary indices in [0, {V})")
+            idx = tgt.to(device=self.device, dtype=torch.int32).contiguous()
         if seed is not None:
             if target is not None:
                 raise ValueError("pass either target or seed, not both")
             if tuple(seed.shape) != (B, V):
                 raise ValueError(f"seed must have shape ({B}, {V}), got {tuple(seed.shape)}")
-        fw = self.forward(emb, B, S, row_iv)
-        if target is None:
-            # (a dense seed explains no single logit; idx / logit then report the arg-max for convenience)
-            idx, _ = ops.argmax_rows(fw["logits"])
-        else:
-            idx = tgt.to(device=self.device, dtype=torch.int32).contiguous()
-        G, layer_R = self.backward(fw, emb, idx, B, S, layer_relevance, seed=seed)
-        R_tok = ops.readout(emb, G).view(B, S)
-        out = dict(idx=idx, logit=fw["logits"].gather(1, idx.long()[:, None])[:, 0], R_tok=R_tok, logits=fw["logits"])
-        if layer_relevance:
-            rows = [layer_R[0]] + [r.view(B, S).sum(1) for r in layer_R[1:]]
-            out["layer_R"] = torch.stack(rows[::-1], 0)          # [L+1, B], index 0 = embedding
-        if return_G:
-            out["G_emb"] = G.view(B, S, -1)
-            out["emb"] = emb.view(B, S, -1)
+        if not graph:
+            return self._run(input_ids, emb, B, S, row_iv, idx, layer_relevance, return_G, seed)
+        if emb is not None or lengths is not None or seed is not None or return_G:
+            raise ValueError("graph=True takes input_ids only (no inputs_embeds / lengths / seed / return_G)")
+        if not hasattr(self, "_graphs") or self._graphs is None:
+            self._graphs = {}
+        key = (B, S, idx is not None, bool(layer_relevance), self.mode)
+        g = self._graphs.get(key)
+        if g is None:
+            s_ids = input_ids.clone()
+            s_idx = idx.clone() if idx is not None else None
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                        # warm-up outside the capture: sizes the arena, loads the kernels
+                self._run(s_ids, None, B, S, None, s_idx, layer_relevance, False, None)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                out = self._run(s_ids, None, B, S, None, s_idx, layer_relevance, False, None)
+            g = self._graphs[key] = (cg, s_ids, s_idx, out)
+        cg, s_ids, s_idx, out = g
+        s_ids.copy_(input_ids)
+        if s_idx is not None:
+            s_idx.copy_(idx)
+        cg.replay()
         return out

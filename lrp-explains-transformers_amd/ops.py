@@ -439,20 +439,6 @@ def head_seed(W_lm, logits, idx, w_norm, rstd_last, out, w_offset=0.0, eps_lin=0
     return out
 
 
-def linear_eps_smallm(x, W, bias, g, eps, relevance_in=False, relevance_out=True, want_z=False, workspace=None):
-    """one-pass Linear eps rule for M <= 4 rows (W streamed once); returns fp32 [M,K] (and z fp32 [M,N])"""
-    M, K = x.shape
-    N = W.shape[0]
-    out = torch.empty(M, K, device=x.device, dtype=torch.float32)
-    z = torch.empty(M, N, device=x.device, dtype=torch.float32) if want_z else None
-    need = lib.lrp_linear_eps_smallm_ws(M, N, K)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
-    check(lib.lrp_linear_eps_smallm(p(_c(x)), p(_c(W)), p(bias), p(_c(g)), p(out), p(z), p(workspace), M, N, K, eps,
-                                    int(relevance_in), int(relevance_out), dt(x), stream()), "lrp_linear_eps_smallm")
-    return (out, z) if want_z else out
-
-
 SMALLM_MAX = 16          # rows the W-streaming small-M kernels serve (above: the skinny split-K path, then the MFMA GEMM)
 
 

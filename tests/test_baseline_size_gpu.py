@@ -188,9 +188,10 @@ def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
 def test_engine_fp32_full_width_three_seeds(case):
     """the committed evidence is all three instances, not the best one.  Efficient placement: 1e-4 on every seed.  Explicit
     placement: the engine's error beside the reference ARITHMETIC's own fp32-vs-fp64 gap and two draws of the fp64 oracle under
-    fp32-sized activation noise, per seed; asserted: on every seed the engine is within 5x the largest of those three numbers (each of
-    them is one draw of the same heavy-tailed quantity -- z/(z + eps) poles), and over the three seeds its
-    geometric-mean error is within 3x the reference arithmetic's."""
+    fp32-sized activation noise, per seed.  Each of those three numbers is one draw of the same heavy-tailed quantity -- "an fp32
+    evaluation of this instance", z/(z + eps) poles; on seeds (22,23) the two noise draws alone are 8e-4 and 0.31.
+    Asserted: on every seed the engine is within 5x the largest of the three, and over the three seeds its geometric-mean error is
+    within 3x the geometric mean of all nine reference draws."""
     import math
     table = []
     for (ws, ids_) in SEEDS:
@@ -208,8 +209,9 @@ def test_engine_fp32_full_width_three_seeds(case):
         yard = max([gap["explicit"]["R_tok"]] + list(noise))
         assert exp["R_tok"] < max(1e-4, 5 * yard), (ws, exp, yard)
     gm = lambda v: math.exp(sum(math.log(max(x, 1e-30)) for x in v) / len(v))      # noqa: E731
-    ge, gr = gm([t[3]["R_tok"] for t in table]), gm([t[4]["explicit"]["R_tok"] for t in table])
-    print(f"[H4096/S2048 fp32 explicit, 3 seeds] geometric mean: engine {ge:.2e}, reference arithmetic in fp32 {gr:.2e}")
+    ge = gm([t[3]["R_tok"] for t in table])
+    gr = gm([x for t in table for x in [t[4]["explicit"]["R_tok"]] + list(t[5])])
+    print(f"[H4096/S2048 fp32 explicit, 3 seeds] geometric mean: engine {ge:.2e}; reference arithmetic in fp32 + noise-model draws {gr:.2e}")
     assert ge < max(1e-4, 3 * gr)
 
 

@@ -162,6 +162,24 @@ def test_rope_scaling_tables_match_hf():
         E.config_from_hf(Qwen2Config(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=8))
 
 
+def test_rope_kind_reads_legacy_rope_scaling():
+    """on transformers 4.x a Llama-3.1 config has no `rope_parameters`, only rope_theta + rope_scaling = {'rope_type' (or the
+    legacy 'type'): 'llama3', ...}; the scaling must not be dropped silently, and an uninterpretable dict must be refused"""
+    import types
+    import lxt_amd.engine as E
+    ns = types.SimpleNamespace
+    assert E.rope_kind(ns(rope_parameters=dict(rope_type="llama3", rope_theta=5e5))) == "llama3"
+    assert E.rope_kind(ns(rope_theta=5e5, rope_scaling=dict(rope_type="llama3", factor=8.0))) == "llama3"
+    assert E.rope_kind(ns(rope_theta=5e5, rope_scaling=dict(type="linear", factor=2.0))) == "linear"
+    assert E.rope_kind(ns(rope_theta=1e4, rope_scaling=None)) == "default" and E.rope_kind(ns(rope_theta=1e4)) == "default"
+    with pytest.raises(NotImplementedError):
+        E.rope_kind(ns(rope_theta=5e5, rope_scaling={"factor": 2.0}))
+    # a sequence-length dependent type arriving through the legacy key is refused by config_from_hf like any other
+    with pytest.raises(NotImplementedError):
+        E.config_from_hf(ns(model_type="llama", hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                            num_key_value_heads=2, vocab_size=8, rms_norm_eps=1e-5, rope_theta=1e4, rope_scaling=dict(type="dynamic", factor=2.0)))
+
+
 def test_bert_engine_refuses_to_run_without_a_device():
     """BertLRP (like LlamaLRP) has no CPU path: constructing it without a HIP device raises"""
     import torch

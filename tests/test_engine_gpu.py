@@ -235,3 +235,38 @@ def test_two_rank_job_on_two_gpus(tmp_path):
                         "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llama_arena_reuse_and_graph_replay(eng_mod, dtype):
+    """the workspace arena is reused across calls of different (B, S) without cross-talk (results equal a fresh engine's, bit for bit),
+    and graph=True (the ~1500 launches of an explanation captured once as a hipGraph) reproduces the eager launches bit for bit -- also
+    after the static inputs are overwritten with another batch, with a given target, and with per-layer relevance"""
+    cfg, W, ids, fx = llama_case("d128" if dtype == torch.bfloat16 else "mid")
+    mk = lambda: eng_mod.LlamaLRP(cfg, W, dtype=dtype, mode="explicit", max_seq=512)      # noqa: E731
+    g = torch.Generator().manual_seed(9)
+    S = ids.shape[0]
+    a = torch.stack([ids, torch.randint(0, cfg["vocab"], (S,), generator=g)])
+    b = torch.randint(0, cfg["vocab"], (1, S // 2), generator=g)
+    c = torch.randint(0, cfg["vocab"], (2, S), generator=g)
+    eng = mk()
+    r_a1 = eng.explain(a, layer_relevance=True)
+    r_b = eng.explain(b)
+    r_a2 = eng.explain(a, layer_relevance=True)                 # same buffers, after a smaller problem used them
+    fresh_a, fresh_b = mk().explain(a, layer_relevance=True), mk().explain(b)
+    for r in (r_a1, r_a2):
+        assert torch.equal(r["R_tok"], fresh_a["R_tok"]) and torch.equal(r["layer_R"], fresh_a["layer_R"]) and torch.equal(r["logits"], fresh_a["logits"])
+    assert torch.equal(r_b["R_tok"], fresh_b["R_tok"])
+    assert eng._arena.nbytes() > 0
+    # hipGraph replay
+    g1 = eng.explain(a, layer_relevance=True, graph=True)
+    assert torch.equal(g1["R_tok"], fresh_a["R_tok"]) and torch.equal(g1["idx"], fresh_a["idx"]) and torch.equal(g1["layer_R"], fresh_a["layer_R"])
+    eager_c = mk().explain(c, layer_relevance=True)
+    g2 = eng.explain(c, layer_relevance=True, graph=True)        # replay of the captured graph on new ids
+    assert torch.equal(g2["R_tok"], eager_c["R_tok"]) and torch.equal(g2["idx"], eager_c["idx"])
+    tgt = (eager_c["idx"].cpu().long() + 1) % cfg["vocab"]
+    g3 = eng.explain(c, target=tgt, graph=True)
+    e3 = mk().explain(c, target=tgt)
+    assert torch.equal(g3["R_tok"], e3["R_tok"]) and torch.equal(g3["idx"].cpu().long(), tgt)
+    with pytest.raises(ValueError):
+        eng.explain(c, lengths=[S, S - 3], graph=True)

@@ -105,18 +105,6 @@ def bench_row(dtype, M, H, I):
     print(f"gated_act_bwd [{M},{I}]: {t*1e6:8.1f} us  {5*M*I*es/t/1e9:7.1f} GB/s", flush=True)
 
 
-def bench_smallm(dtype, M, N, K):
-    x, W = torch.randn(M, K, device="cuda").to(dtype), (torch.randn(N, K, device="cuda") * K ** -0.5).to(dtype)
-    g = torch.randn(M, N, device="cuda").to(dtype)
-    es = x.element_size()
-    try:
-        ws = torch.empty(ops.lib.lrp_linear_eps_smallm_ws(M, N, K), device="cuda")
-        t = timeit(lambda: ops.linear_eps_smallm(x, W, None, g, 1e-6, workspace=ws))
-        print(f"linear_eps_smallm {str(dtype)[6:]} M={M} N={N} K={K}: {t*1e6:8.1f} us  {es*(N*K+2*M*K+M*N)/t/1e9:7.1f} GB/s algorithmic", flush=True)
-    except RuntimeError as e:
-        print("linear_eps_smallm", M, N, K, "->", e)
-
-
 def bench_smallm_stream(dtype, M, N, K):
     """W-streaming forward and dgrad (lrp_linear_smallm_fwd / _dgrad): algorithmic bytes = sizeof * N * K (+ M-row operands)"""
     x, W = torch.randn(M, K, device="cuda").to(dtype), (torch.randn(N, K, device="cuda") * K ** -0.5).to(dtype)
@@ -128,15 +116,13 @@ def bench_smallm_stream(dtype, M, N, K):
     out = ops.linear_smallm_dgrad(g, W, z=z, eps=1e-6)
     t = timeit(lambda: ops.linear_smallm_dgrad(g, W, z=z, eps=1e-6, out=out))
     print(f"smallm dgrad {str(dtype)[6:]} M={M:2d} N={N} K={K}: {t*1e6:8.1f} us  {es*(N*K+M*K+2*M*N)/t/1e9:7.1f} GB/s algorithmic", flush=True)
-    if M <= 4 and K <= 4096:
-        bench_smallm(dtype, M, N, K)
     tt = timeit(lambda: torch.matmul(x, W.T))
     print(f"   (torch.matmul forward, same shape: {tt*1e6:8.1f} us  {es*N*K/tt/1e9:7.1f} GB/s)", flush=True)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="gemm,attn,row,smallm")
+    ap.add_argument("--what", default="gemm,attn,row,stream")
     a = ap.parse_args()
     print(torch.cuda.get_device_name(0), torch.version.hip)
     L = [(2048, 6144, 4096), (2048, 4096, 4096), (2048, 28672, 4096), (2048, 4096, 14336), (2048, 14336, 4096), (2048, 4096, 28672),
@@ -166,9 +152,3 @@ if __name__ == "__main__":
             bench_smallm_stream(torch.bfloat16, M, 4096, 14336)
         bench_smallm_stream(torch.bfloat16, 4, 128256, 4096)
         bench_smallm_stream(torch.float32, 1, 768, 768)
-    if "smallm" in a.what:
-        bench_smallm(torch.float32, 1, 768, 768)
-        bench_smallm(torch.float32, 1, 4096, 4096)
-        bench_smallm(torch.bfloat16, 1, 4096, 4096)
-        bench_smallm(torch.bfloat16, 1, 14336, 4096)
-        bench_smallm(torch.bfloat16, 2, 14336, 4096)
