@@ -50,9 +50,26 @@ LRP_DEVICE bool xcd_group_decode(int L, int ngroups, int per_group, int& group, 
 }
 inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
 
-// stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, 16 / NWV per wave
+// stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, 16 / NWV per wave.
+// A32_BUFFER_STAGING (default): buffer_load_dwordx4 .. lds -- ONE per-lane byte offset (row (l >> 4) of the group, swizzled chunk; the
+// group index only enters the chunk through grp & 3 = wave & 3), the group's first row in the scalar offset, rows >= S read as zero
+// through num_records (a zero K / V / Q / Gho row contributes nothing: masked keys, and dS^T Q = P^T Gho = 0 for a zero query row).
+// A global_load_lds piece with its 64-bit per-lane address costs ~80-120 cycles at issue, a buffer piece ~35 (profiles/r03_gemm_experiments.txt).
+#ifndef A32_BUFFER_STAGING
+#define A32_BUFFER_STAGING 1
+#endif
 template <int NWV = NW>
 LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
+#if A32_BUFFER_STAGING
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(S - 1) * ld + D) * 2), 0x00020000);
+    const int rl = lane >> 4, slot = lane & 15;
+    const int voff = (int)(rl * ld * 2) + ((slot ^ ((rl << 2) | (wave & 3))) << 4);
+#pragma unroll
+    for (int g = 0; g < 16 / NWV; ++g) {
+        const int grp = g * NWV + wave;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + grp * 1024), 16, voff, (int)((int64_t)(row0 + grp * 4) * ld * 2), 0, 0);
+    }
+#else
 #pragma unroll
     for (int g = 0; g < 16 / NWV; ++g) {
         const int grp = g * NWV + wave;
@@ -62,6 +79,7 @@ LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char
         gr = gr < S ? gr : S - 1;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)gr * ld + chunk * 8), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
     }
+#endif
 }
 // 64 fp32 row statistics -> lds[0..63]
 LRP_DEVICE void stage_stats(const float* base, int r0, int S, char* lds, int lane) {
@@ -563,6 +581,15 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     char* sVw = smem + 2 * STAGE + wave * VROWS;
     {
         const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+#if A32_BUFFER_STAGING
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)(S - 1) * ldv + D) * 2), 0x00020000);
+        const int rl = lane >> 4, slot = lane & 15;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int voff = (int)(rl * ldv * 2) + ((slot ^ ((rl << 2) | (g & 3))) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sVw + g * 1024), 16, voff, (int)((int64_t)(kw + g * 4) * ldv * 2), 0, 0);
+        }
+#else
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int row = g * 4 + (lane >> 4), slot = lane & 15;
@@ -570,6 +597,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             gr = gr < S ? gr : S - 1;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (int64_t)gr * ldv + ((slot ^ rot4(row)) * 8)), (lds_ptr_t)(sVw + g * 1024), 16, 0, 0);
         }
+#endif
     }
     f32x16 dkacc[ND32], dvacc[ND32];
 #pragma unroll

@@ -216,8 +216,8 @@ def test_engine_fp32_full_width_three_seeds(case):
 
 
 def test_engine_s4096_config5_efficient_vs_oracle():
-    """BASELINE config 5's sequence length at ENGINE level: H 4096 / I 14336 / 32+8 heads / d 128, two layers, S = 4096, two prompts in
-    one call (ref protocol: docs/source/quickstart.rst:120-141): fp32 efficient placement against the fp64 oracle (cached fixture
+    """BASELINE config 5's sequence length at ENGINE level: H 4096 / I 14336 / d 128, 16 query + 4 kv heads (the fp64 oracle with 32 heads
+    at S = 4096 exceeds the build container's 62 GB: make_golden_baseline.py), two layers, S = 4096, two prompts in one call (ref protocol: docs/source/quickstart.rst:120-141): fp32 efficient placement against the fp64 oracle (cached fixture
     baseline_s4096_seed30.npz) < 1e-4 per token and per layer; bf16: the batched call equals the single-prompt calls, token
     relevance sums to the latent relevance at the embedding, and stays close to the fp32 result."""
     if not torch.cuda.is_available():
@@ -228,11 +228,12 @@ def test_engine_s4096_config5_efficient_vs_oracle():
     if not os.path.exists(path):
         pytest.skip("fixture baseline_s4096_seed30.npz missing (tests/golden/make_golden_baseline.py 4096)")
     z = np.load(path)
-    W = ol.random_weights(CFG, seed=int(z["wseed"]))
+    cfg5 = {k: (float(v) if k in ("rope_theta", "rms_eps") else int(v)) for k, v in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist())}
+    W = ol.random_weights(cfg5, seed=int(z["wseed"]))
     if abs(_wsum(W) - float(z["wsum"])) > 1e-9 * float(z["wsum"]):
         pytest.skip("synthetic weights did not regenerate bit-identically on this host (cached oracle unusable)")
     ids = torch.from_numpy(z["ids"])
-    eng = E.LlamaLRP(CFG, W, dtype=torch.float32, mode="efficient", max_seq=4096)
+    eng = E.LlamaLRP(cfg5, W, dtype=torch.float32, mode="efficient", max_seq=4096)
     out = eng.explain(ids, layer_relevance=True)
     for b in range(2):
         assert int(out["idx"][b]) == int(z["idx"][b]) and abs(float(out["logit"][b]) - float(z["logit"][b])) < 1e-4 * max(1.0, abs(float(z["logit"][b])))
@@ -242,7 +243,7 @@ def test_engine_s4096_config5_efficient_vs_oracle():
     R32 = out["R_tok"].double().cpu()
     del eng, out
     torch.cuda.empty_cache()
-    eng = E.LlamaLRP(CFG, W, dtype=torch.bfloat16, mode="efficient", max_seq=4096)
+    eng = E.LlamaLRP(cfg5, W, dtype=torch.bfloat16, mode="efficient", max_seq=4096)
     both = eng.explain(ids, target=torch.from_numpy(z["idx"]), layer_relevance=True)
     for b in range(2):
         one = eng.explain(ids[b: b + 1], target=torch.from_numpy(z["idx"][b: b + 1]))
