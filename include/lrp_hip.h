@@ -152,6 +152,26 @@ int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64
 int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, void* Au,
                       int M, int I, int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag,
                       int64_t ldau, float eps_g, float eps_lin, int act, int dtype, void* stream);
+/* The same two rules on the INTERLEAVED output of a fused gate/up Linear and fused into the GEMMs around them (the engine's layout:
+ * the rows of the fused weight [2 I, H] are ordered in blocks of 64 = [gate rows 32 b .. 32 b + 31 | up rows 32 b .. 32 b + 31], so one
+ * 64-column block of gu = W_gu x holds gate AND up of the same 32 intermediate indices -- and so does one wave's accumulator tile):
+ *   lrp_gated_act_fwd_il / _bwd_il : the element-wise kernels on gu / Agu [M, 2 I] in that layout (small M, fp32)
+ *   lrp_gemm_gated_fwd : gu = x W_gu^T (stored, the backward needs it) AND m = act(g) (*) u written by the SAME kernel's epilogue
+ *   lrp_gemm_gated_bwd : Gm = A_dn W_dn (NN form, W_dn [H, I] as stored) is never written: the epilogue reads gu and writes
+ *                        Agu = { Gm u/2 act(g)/(g + eps_g) | Gm act(g)/2 u/(u + eps_lin) } directly
+ * bf16; when the problem is too small for the 256 x 256 ping-pong kernel the two entry points run the GEMM and the element-wise
+ * kernel one after the other (`ws`: M x I elements of scratch for Gm in that case; may be NULL when lrp_gemm_gated_bwd_ws() == 0).
+ * ref: lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281. */
+#define LRP_GATED_IL 32
+int lrp_gated_act_fwd_il(const void* gu, void* m, int M, int I, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
+int lrp_gated_act_bwd_il(const void* Gm, const void* gu, void* Agu, int M, int I, int64_t ldgm, int64_t ldgu, int64_t ldagu,
+                         float eps_g, float eps_lin, int act, int dtype, void* stream);
+int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                       int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
+int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int act, int dtype);
+int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
+                       int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws, void* stream);
+
 /* stand-alone activation identity rule (BERT/GPT-2 mlp_forward, ref: patches.py:160-168):
  * forward y = act(x); backward A = Gy * act(x)/(x+eps_g)                                  */
 int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);

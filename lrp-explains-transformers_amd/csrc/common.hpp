@@ -103,6 +103,34 @@ LRP_DEVICE float act_apply(float x, int act) {
     return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
 }
 
+// ---- the same rules for bf16 STORAGE: every result is rounded to 8 mantissa bits, so v_rcp_f32 / v_exp_f32 (1 ulp of fp32) replace the
+// IEEE division sequences (10-12 VALU each; three of them per element made the fused gated epilogue VALU-bound: 97 instructions per
+// element).  FAST = false keeps the exact fp32 forms (fp32 storage: the explicit-mode parity paths).
+template <bool FAST> LRP_DEVICE float fdiv_t(float a, float b) {
+    if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+// a / b for a denominator that may be a denormal (v_rcp_f32 flushes those to +-inf): rescaled by 2^24 first
+template <bool FAST> LRP_DEVICE float fdiv_small_t(float a, float b) {
+    if constexpr (FAST) {
+        const float sc = (fabsf(b) < 1.17549435e-38f) ? 16777216.f : 1.f;
+        return a * (__builtin_amdgcn_rcpf(b * sc) * sc);
+    } else return a / b;
+}
+template <bool FAST> LRP_DEVICE float eps_ratio_t(float z, float c, float eps) {
+    return (eps == 0.f) ? fdiv_t<FAST>(1.f, c) : fdiv_t<FAST>(z, c * z + eps);
+}
+template <bool FAST> LRP_DEVICE float act_apply_t(float x, int act) {
+    if constexpr (FAST) {
+        if (act == LRP_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+        if (act == LRP_ACT_GELU_TANH) {                                  // 0.5 x (1 + tanh z) = x sigmoid(2 z)
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            return x * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * k0 * (x + k1 * x * x * x)));
+        }
+    }
+    return act_apply(x, act);
+}
+
 // ---- MFMA 16x16 "macro" op, identical byte geometry for both dtypes ---------------------------
 // One macro step contracts a 64-BYTE K chunk: lane l supplies the 16 bytes at K-byte offset
 // (l>>4)*16 of row (l&15) for each operand (8 bf16 / 4 fp32).  bf16: one v_mfma_f32_16x16x32_bf16;

@@ -151,18 +151,19 @@ __global__ void act_bwd_kernel(const T* Gy, const T* x, T* Gx, int64_t n, float 
 
 // 2-D strided gated-MLP kernels: one chunk of W columns per thread-iteration
 template <typename T, int W>
-__global__ void gated_fwd_kernel(const T* g, const T* u, T* m, int M, int I, int64_t ldg, int64_t ldu, int64_t ldm, int act) {
+__global__ void gated_fwd_kernel(const T* g, const T* u, T* m, int M, int I, int64_t ldg, int64_t ldu, int64_t ldm, int act, int il) {
     const int cpr = I / W;
     const int64_t total = (int64_t)M * cpr;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cpr;
         const int c = (int)(i - r * cpr) * W;
+        const int cg = il ? (c / il) * 2 * il + (c % il) : c;       // interleaved [g block | u block] layout of a fused gate/up output
         Chunk<T, W> a, b, o;
-        a.load(g + r * ldg + c);
-        b.load(u + r * ldu + c);
+        a.load(g + r * ldg + cg);
+        b.load(u + r * ldu + cg);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float y = to_f32(from_f32<T>(act_apply(a.v[k], act)));   // HF rounds act(g) before the product
+            const float y = to_f32(from_f32<T>(act_apply_t<sizeof(T) == 2>(a.v[k], act)));   // HF rounds act(g) before the product
             o.v[k] = y * b.v[k];
         }
         o.store(m + r * ldm + c);
@@ -171,26 +172,28 @@ __global__ void gated_fwd_kernel(const T* g, const T* u, T* m, int M, int I, int
 template <typename T, int W>
 __global__ void gated_bwd_kernel(const T* Gm, const T* g, const T* u, T* Ag, T* Au, int M, int I,
                                  int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag, int64_t ldau,
-                                 float eps_g, float eps_lin, int act) {
+                                 float eps_g, float eps_lin, int act, int il) {
     const int cpr = I / W;
     const int64_t total = (int64_t)M * cpr;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cpr;
         const int c = (int)(i - r * cpr) * W;
+        const int cg = il ? (c / il) * 2 * il + (c % il) : c;
         Chunk<T, W> gm, a, b, og, ou;
         gm.load(Gm + r * ldgm + c);
-        a.load(g + r * ldg + c);
-        b.load(u + r * ldu + c);
+        a.load(g + r * ldg + cg);
+        b.load(u + r * ldu + cg);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const float y = to_f32(from_f32<T>(act_apply(a.v[k], act)));
+            constexpr bool FAST = sizeof(T) == 2;                      // bf16 storage: rcp / exp forms (common.hpp), as the fused epilogue
+            const float y = to_f32(from_f32<T>(act_apply_t<FAST>(a.v[k], act)));
             const float half = 0.5f * gm.v[k];
             const float den = a.v[k] + eps_g;
-            og.v[k] = (den == 0.f) ? 0.f : half * b.v[k] * (y / den);
-            ou.v[k] = half * y * eps_ratio(b.v[k], 1.f, eps_lin);
+            og.v[k] = (den == 0.f) ? 0.f : half * b.v[k] * fdiv_small_t<FAST>(y, den);
+            ou.v[k] = half * y * eps_ratio_t<FAST>(b.v[k], 1.f, eps_lin);
         }
-        og.store(Ag + r * ldag + c);
-        ou.store(Au + r * ldau + c);
+        og.store(Ag + r * ldag + cg);
+        ou.store(Au + r * ldau + cg);
     }
 }
 
@@ -445,34 +448,56 @@ extern "C" int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, f
 
 static inline bool ld_ok(int64_t ld, int epc) { return (ld % epc) == 0; }
 
-extern "C" int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64_t ldg,
-                                 int64_t ldu, int64_t ldm, int act, int dtype, void* stream) {
-    if (!g || !u || !m || M < 0 || I < 0 || act < 0 || act > 3) return LRP_EINVAL;
+static int gated_fwd_launch(const void* g, const void* u, void* m, int M, int I, int64_t ldg, int64_t ldu, int64_t ldm, int act, int il,
+                            int dtype, hipStream_t st) {
+    if (!g || !u || !m || M < 0 || I < 0 || act < 0 || act > 3 || (il && (I % il))) return LRP_EINVAL;
     if (M == 0 || I == 0) return LRP_OK;
-    hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
         constexpr int EPC = 16 / sizeof(T);
-        const bool v = al16(g) && al16(u) && al16(m) && (I % EPC == 0) && ld_ok(ldg, EPC) && ld_ok(ldu, EPC) && ld_ok(ldm, EPC);
-        if (v) hipLaunchKernelGGL((gated_fwd_kernel<T, EPC>), dim3(grid_for((int64_t)M * I / EPC)), dim3(ENT), 0, st, (const T*)g, (const T*)u, (T*)m, M, I, ldg, ldu, ldm, act);
-        else hipLaunchKernelGGL((gated_fwd_kernel<T, 1>), dim3(grid_for((int64_t)M * I)), dim3(ENT), 0, st, (const T*)g, (const T*)u, (T*)m, M, I, ldg, ldu, ldm, act);
+        const bool v = al16(g) && al16(u) && al16(m) && (I % EPC == 0) && ld_ok(ldg, EPC) && ld_ok(ldu, EPC) && ld_ok(ldm, EPC) && (il % EPC == 0);
+        if (v) hipLaunchKernelGGL((gated_fwd_kernel<T, EPC>), dim3(grid_for((int64_t)M * I / EPC)), dim3(ENT), 0, st, (const T*)g, (const T*)u, (T*)m, M, I, ldg, ldu, ldm, act, il);
+        else hipLaunchKernelGGL((gated_fwd_kernel<T, 1>), dim3(grid_for((int64_t)M * I)), dim3(ENT), 0, st, (const T*)g, (const T*)u, (T*)m, M, I, ldg, ldu, ldm, act, il);
     })
     return lrp_check_launch();
+}
+
+static int gated_bwd_launch(const void* Gm, const void* g, const void* u, void* Ag, void* Au, int M, int I, int64_t ldgm, int64_t ldg,
+                            int64_t ldu, int64_t ldag, int64_t ldau, float eps_g, float eps_lin, int act, int il, int dtype, hipStream_t st) {
+    if (!Gm || !g || !u || !Ag || !Au || M < 0 || I < 0 || act < 0 || act > 3 || (il && (I % il))) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        const bool v = al16(Gm) && al16(g) && al16(u) && al16(Ag) && al16(Au) && (I % EPC == 0) && ld_ok(ldgm, EPC) &&
+                       ld_ok(ldg, EPC) && ld_ok(ldu, EPC) && ld_ok(ldag, EPC) && ld_ok(ldau, EPC) && (il % EPC == 0);
+        if (v) hipLaunchKernelGGL((gated_bwd_kernel<T, EPC>), dim3(grid_for((int64_t)M * I / EPC)), dim3(ENT), 0, st, (const T*)Gm, (const T*)g, (const T*)u, (T*)Ag, (T*)Au, M, I, ldgm, ldg, ldu, ldag, ldau, eps_g, eps_lin, act, il);
+        else hipLaunchKernelGGL((gated_bwd_kernel<T, 1>), dim3(grid_for((int64_t)M * I)), dim3(ENT), 0, st, (const T*)Gm, (const T*)g, (const T*)u, (T*)Ag, (T*)Au, M, I, ldgm, ldg, ldu, ldag, ldau, eps_g, eps_lin, act, il);
+    })
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64_t ldg,
+                                 int64_t ldu, int64_t ldm, int act, int dtype, void* stream) {
+    return gated_fwd_launch(g, u, m, M, I, ldg, ldu, ldm, act, 0, dtype, (hipStream_t)stream);
 }
 
 extern "C" int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, void* Au,
                                  int M, int I, int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag,
                                  int64_t ldau, float eps_g, float eps_lin, int act, int dtype, void* stream) {
-    if (!Gm || !g || !u || !Ag || !Au || M < 0 || I < 0 || act < 0 || act > 3) return LRP_EINVAL;
-    if (M == 0 || I == 0) return LRP_OK;
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, {
-        constexpr int EPC = 16 / sizeof(T);
-        const bool v = al16(Gm) && al16(g) && al16(u) && al16(Ag) && al16(Au) && (I % EPC == 0) && ld_ok(ldgm, EPC) &&
-                       ld_ok(ldg, EPC) && ld_ok(ldu, EPC) && ld_ok(ldag, EPC) && ld_ok(ldau, EPC);
-        if (v) hipLaunchKernelGGL((gated_bwd_kernel<T, EPC>), dim3(grid_for((int64_t)M * I / EPC)), dim3(ENT), 0, st, (const T*)Gm, (const T*)g, (const T*)u, (T*)Ag, (T*)Au, M, I, ldgm, ldg, ldu, ldag, ldau, eps_g, eps_lin, act);
-        else hipLaunchKernelGGL((gated_bwd_kernel<T, 1>), dim3(grid_for((int64_t)M * I)), dim3(ENT), 0, st, (const T*)Gm, (const T*)g, (const T*)u, (T*)Ag, (T*)Au, M, I, ldgm, ldg, ldu, ldag, ldau, eps_g, eps_lin, act);
-    })
-    return lrp_check_launch();
+    return gated_bwd_launch(Gm, g, u, Ag, Au, M, I, ldgm, ldg, ldu, ldag, ldau, eps_g, eps_lin, act, 0, dtype, (hipStream_t)stream);
+}
+
+// the same rules on the INTERLEAVED output of a fused gate/up Linear (lrp_gemm_gated_fwd's layout): gu [M, 2 I], column block b of 64 =
+// [gate 32 b .. 32 b + 31 | up 32 b .. 32 b + 31]; Agu in the same layout
+extern "C" int lrp_gated_act_fwd_il(const void* gu, void* m, int M, int I, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
+    const size_t es = dtype == LRP_F32 ? 4 : 2;
+    return gated_fwd_launch(gu, gu ? (const char*)gu + 32 * es : nullptr, m, M, I, ldgu, ldgu, ldm, act, LRP_GATED_IL, dtype, (hipStream_t)stream);
+}
+
+extern "C" int lrp_gated_act_bwd_il(const void* Gm, const void* gu, void* Agu, int M, int I, int64_t ldgm, int64_t ldgu, int64_t ldagu,
+                                    float eps_g, float eps_lin, int act, int dtype, void* stream) {
+    const size_t es = dtype == LRP_F32 ? 4 : 2;
+    return gated_bwd_launch(Gm, gu, gu ? (const char*)gu + 32 * es : nullptr, Agu, Agu ? (char*)Agu + 32 * es : nullptr, M, I, ldgm, ldgu, ldgu,
+                            ldagu, ldagu, eps_g, eps_lin, act, LRP_GATED_IL, dtype, (hipStream_t)stream);
 }
 
 extern "C" int lrp_rope_fwd(const void* x, void* xr, const float* cos_t, const float* sin_t, int rows,

@@ -16,6 +16,11 @@
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st);
 
+int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                                 int64_t ldgu, int64_t ldm, int act, hipStream_t st);
+int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
+                                 int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, KB = 128;     // KB: bytes of K per stage and per row
@@ -472,5 +477,49 @@ extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void
     else
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, block, 0, st, (const float*)ws, (const bf16_t*)bias, (bf16_t*)C, M, N, ldw, ldc, used, slab);
     return lrp_check_launch();
+}
+
+// =================================================================================================
+// gated-MLP rules fused into the GEMMs around them (interleaved gate/up layout, include/lrp_hip.h)
+// =================================================================================================
+namespace {
+bool gated_fused_ok(int M, int Ncols, int K, int I, int64_t lda, int64_t ldb, int nn, int act) {
+    const int64_t tiles = (int64_t)((M + 255) / 256) * ((Ncols + 255) / 256);
+    return tiles >= 190 && (I % LRP_GATED_IL) == 0 && (act == LRP_ACT_SILU || act == LRP_ACT_GELU_TANH) && pp_ok(M, Ncols, K, lda, ldb, nn);
+}
+}  // namespace
+
+extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                                  int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
+    if (!x || !Wgu || !gu || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    if (I % LRP_GATED_IL) return LRP_ESHAPE;
+    if (dtype == LRP_BF16 && (ldx % 8) == 0 && (ldw % 8) == 0 && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(Wgu) & 15) &&
+        gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act))
+        return lrp_launch_gemm_pp_gated_fwd(x, Wgu, gu, m, M, I, K, ldx, ldw, ldgu, ldm, act, (hipStream_t)stream);
+    const int rc = lrp_gemm_nt(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, 0, 0, 0, dtype, dtype, stream);
+    if (rc != LRP_OK) return rc;
+    return lrp_gated_act_fwd_il(gu, m, M, I, ldgu, ldm, act, dtype, stream);
+}
+
+extern "C" int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int act, int dtype) {
+    if (dtype != LRP_BF16 || M <= 0 || I <= 0) return 0;
+    // contiguous operands assumed (lda = K, ldw = I): the fused kernel needs no scratch; the GEMM + element-wise pair needs Gm [M, I]
+    return gated_fused_ok(M, I, K, I, K, I, 1, act) ? 0 : (int64_t)M * I * 2;
+}
+
+extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
+                                  int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws,
+                                  void* stream) {
+    if (!Adn || !Wdn || !gu || !Agu || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (I % LRP_GATED_IL)) return LRP_ESHAPE;
+    if ((lda % 8) || (ldw % 8) || (reinterpret_cast<uintptr_t>(Adn) & 15) || (reinterpret_cast<uintptr_t>(Wdn) & 15)) return LRP_EALIGN;
+    if (gated_fused_ok(M, I, K, I, lda, ldw, 1, act))
+        return lrp_launch_gemm_pp_gated_bwd(Adn, Wdn, gu, Agu, M, I, K, lda, ldw, ldgu, ldagu, eps_g, eps_lin, act, (hipStream_t)stream);
+    if (!ws) return LRP_EINVAL;
+    const int rc = lrp_gemm_nn(Adn, Wdn, ws, nullptr, M, I, K, lda, ldw, I, dtype, dtype, stream);
+    if (rc != LRP_OK) return rc;
+    return lrp_gated_act_bwd_il(ws, gu, Agu, M, I, I, ldgu, ldagu, eps_g, eps_lin, act, dtype, stream);
 }
 

@@ -69,10 +69,20 @@ typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
 #define PP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define PP_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <typename TO, bool NN>
+// fused gated-MLP epilogues (EPI 1 / 2, see the end of the kernel); EPI 0 = plain (+ bias)
+struct PPEpi {
+    bf16_t* c2;            // EPI 1: m [M, I]
+    int64_t ldc2;
+    const bf16_t* gu;      // EPI 2: the stashed gate/up output [M, 2 I], interleaved
+    int64_t ldgu;
+    float eps_g, eps_lin;
+    int act;
+};
+
+template <typename TO, bool NN, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,8 +264,77 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
     const int mrow = m0 + g * 128 + (lane & 15);
     const int ncol = n0 + wc * 64;
-    const bool full = (m0 + 256 <= M) && (n0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    bool full = (m0 + 256 <= M) && (n0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    if constexpr (EPI == 1) full = full && ((ep.ldc2 & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.c2) & 15) == 0);
+    if constexpr (EPI == 2) full = full && ((ep.ldgu & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.gu) & 15) == 0);
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    bool done = false;
+    if constexpr (EPI == 2) {
+        // ---- gated-MLP backward rule in the down-projection dgrad's epilogue, full tiles.  The accumulators are Gm for 64 intermediate
+        // indices (two 32-index groups q); gate / up of group q sit at gu columns 64 (ncol/32 + q) + {0..31 | 32..63}; Agu in the same
+        // layout.  Gm is rounded to bf16 first: bit-identical to the unfused pair lrp_gemm_nn + lrp_gated_act_bwd_il.
+        // Software-pipelined over the 8 row blocks (a, i): the four 16-byte gu loads of block b + 2 are issued right after block b's
+        // stores, into the registers block b just released -- 8 loads in flight per wave.  (Written as one load pair per (i, q) inside
+        // the generic loop below, hipcc waits vmcnt(0) after every pair: 2 KiB in flight per wave, 1.9 TB/s over the epilogue.)
+        if (full) {
+            const int off = 16 * (hi & 1) + 8 * (hi >> 1);
+            const bf16_t* gsrc = ep.gu + (int64_t)mrow * ep.ldgu + 2 * (int64_t)ncol + off;
+            bf16_t* adst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + 2 * (int64_t)ncol + off;
+            u32x4 pre[2][4];
+            auto issue = [&](int b, u32x4 (&d)[4]) {
+                const bf16_t* p = gsrc + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ep.ldgu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u32x4*>(p + 32 * k);        // q0 gate, q0 up, q1 gate, q1 up
+            };
+            auto unswz = [&](const u32x4& o, f32x4 (&t)[2]) {
+                auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+                const bf16x2 a0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[0]), a1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[0]);
+                const bf16x2 b0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[1]), b1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[1]);
+                t[0] = f32x4{(float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1]};
+                t[1] = f32x4{(float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
+            };
+            auto swz = [&](const f32x4 (&t)[2]) {
+                bf16x2 x0 = {(bf16_t)t[0][0], (bf16_t)t[0][1]}, x1 = {(bf16_t)t[0][2], (bf16_t)t[0][3]};
+                bf16x2 y0 = {(bf16_t)t[1][0], (bf16_t)t[1][1]}, y1 = {(bf16_t)t[1][2], (bf16_t)t[1][3]};
+                auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
+                return u32x4{s0[0], s1[0], s0[1], s1[1]};
+            };
+            issue(0, pre[0]);
+            issue(1, pre[1]);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                bf16_t* dst = adst + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ldc;
+                u32x4 out[4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 gq[2], uq[2], ag[2], au[2];
+                    unswz(pre[b & 1][2 * q], gq);
+                    unswz(pre[b & 1][2 * q + 1], uq);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = (float)(bf16_t)act_apply_t<true>(gq[jj][e], ACT);
+                            const float half = 0.5f * (float)(bf16_t)acc[b >> 2][b & 3][2 * q + jj][e];
+                            const float den = gq[jj][e] + ep.eps_g;
+                            ag[jj][e] = (den == 0.f) ? 0.f : half * uq[jj][e] * fdiv_small_t<true>(y, den);
+                            au[jj][e] = half * y * eps_ratio_t<true>(uq[jj][e], 1.f, ep.eps_lin);
+                        }
+                    out[2 * q] = swz(ag);
+                    out[2 * q + 1] = swz(au);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + 32 * k) = out[k];
+                if (b + 2 < 8) issue(b + 2, pre[b & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = true;
+        }
+    }
+    if (!done)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -273,6 +352,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     }
                 }
             }
+            if constexpr (EPI == 1) {
+                // ---- gated-MLP forward rule in the gate/up GEMM's epilogue.  The fused weight's rows are interleaved in blocks of 64 =
+                // [32 gate | 32 up], so this wave's column tiles j = 0, 1 are gate and j = 2, 3 up of the SAME 32 intermediate indices:
+                // m = act(g) (*) u on the bf16-rounded g, u (exactly what lrp_gated_act_fwd computes from the stored gu)
+                f32x4 mv[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gq = (float)(bf16_t)v[jj][e], uq = (float)(bf16_t)v[jj + 2][e];
+                        mv[jj][e] = (float)(bf16_t)act_apply_t<true>(gq, ACT) * uq;
+                    }
+                const int mcol = ncol / 2;                               // first intermediate index of this wave's block
+                if (full) {
+                    bf16x2 x0 = {(bf16_t)mv[0][0], (bf16_t)mv[0][1]}, x1 = {(bf16_t)mv[0][2], (bf16_t)mv[0][3]};
+                    bf16x2 y0 = {(bf16_t)mv[1][0], (bf16_t)mv[1][1]}, y1 = {(bf16_t)mv[1][2], (bf16_t)mv[1][3]};
+                    auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    *reinterpret_cast<u32x4*>(ep.c2 + (int64_t)gm * ep.ldc2 + mcol + 16 * (hi & 1) + 8 * (hi >> 1)) = o;
+                } else if (gm < M) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = mcol + 16 * jj + 4 * hi + e;
+                            if (2 * ci < N) ep.c2[(int64_t)gm * ep.ldc2 + ci] = (bf16_t)mv[jj][e];
+                        }
+                }
+            }
+            if constexpr (EPI == 2) {
+                // ragged tiles of the gated backward rule (the full tiles took the pipelined path above): element-wise, bounds-checked
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int64_t gcol = 2 * (int64_t)ncol + 64 * q;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ci = 16 * jj + 4 * hi + e;
+                            if (gm < M && ncol + 32 * q + ci < N) {
+                                const float gq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + ci], uq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + 32 + ci];
+                                const float y = (float)(bf16_t)act_apply_t<true>(gq, ACT);
+                                const float half = 0.5f * (float)(bf16_t)v[2 * q + jj][e];
+                                const float den = gq + ep.eps_g;
+                                C[(int64_t)gm * ldc + gcol + ci] = (TO)((den == 0.f) ? 0.f : half * uq * fdiv_small_t<true>(y, den));
+                                C[(int64_t)gm * ldc + gcol + 32 + ci] = (TO)(half * y * eps_ratio_t<true>(uq, 1.f, ep.eps_lin));
+                            }
+                        }
+                }
+            } else
             if constexpr (sizeof(TO) == 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -336,9 +466,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-template <typename TO, bool NN>
+template <typename TO, bool NN, int EPI, int ACT = 0>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                int splits, int kt_per_split, int64_t slab_stride, hipStream_t st) {
+                int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     dim3 grid(tiles_m * tiles_n, splits), block(512);
 #ifdef PP_TIMELINE
@@ -346,14 +476,14 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 #else
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
-    auto kern = gemm_pp_kernel<TO, NN>;
+    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
-                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride);
+                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
     return lrp_check_launch();
 }
 
@@ -364,10 +494,33 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 // [splits][M][ldc] (slab_stride elements apart), each holding the partial sum of kt_per_split K tiles; no bias then.
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st) {
+    const PPEpi ep{};
     if (out_dtype == LRP_F32) {
-        if (nn) return launch_pp_t<float, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
-        return launch_pp_t<float, false>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
+        if (nn) return launch_pp_t<float, true, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+        return launch_pp_t<float, false, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
     }
-    if (nn) return launch_pp_t<bf16_t, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
-    return launch_pp_t<bf16_t, false>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, st);
+    if (nn) return launch_pp_t<bf16_t, true, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+    return launch_pp_t<bf16_t, false, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+}
+
+// gate/up forward with the gated rule in the epilogue: gu[M, 2 I] = x[M, K] . Wgu[2 I, K]^T (rows interleaved [32 gate | 32 up]), m[M, I]
+int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                                 int64_t ldgu, int64_t ldm, int act, hipStream_t st) {
+    PPEpi ep{};
+    ep.c2 = (bf16_t*)m; ep.ldc2 = ldm; ep.act = act;
+    // the activation is a compile-time parameter: with a run-time switch inside the 8-fold unrolled epilogue hipcc gives up unrolling and
+    // moves the 128 accumulators to scratch
+    if (act == LRP_ACT_SILU) return launch_pp_t<bf16_t, false, 1, LRP_ACT_SILU>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
+    if (act == LRP_ACT_GELU_TANH) return launch_pp_t<bf16_t, false, 1, LRP_ACT_GELU_TANH>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
+    return LRP_ESHAPE;
+}
+
+// down-projection dgrad with the gated rule in the epilogue: Gm = Adn[M, K] . Wdn[K, I] (NN, never stored) -> Agu[M, 2 I]
+int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
+                                 int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st) {
+    PPEpi ep{};
+    ep.gu = (const bf16_t*)gu; ep.ldgu = ldgu; ep.eps_g = eps_g; ep.eps_lin = eps_lin; ep.act = act;
+    if (act == LRP_ACT_SILU) return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+    if (act == LRP_ACT_GELU_TANH) return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+    return LRP_ESHAPE;
 }

@@ -11,7 +11,8 @@ MI355X-first decisions:
   * everything an eps-rule needs (every Linear output z, pre/post-RoPE q/k, attention o + lse,
     residual sums) is STASHED in HBM during the forward (~0.3 GB/layer at S=2048 bf16; 288 GB
     available) -- the backward never recomputes a GEMM, it runs one dgrad GEMM per Linear;
-  * every weight is kept ONCE, in its forward layout W [out,in] (QKV and gate+up fused along the output dim): the forward is an NT
+  * every weight is kept ONCE, in its forward layout W [out,in] (QKV and gate+up fused along the output dim; gate / up rows interleaved
+    in blocks of 32 so that the gated-MLP rules run inside the GEMM epilogues): the forward is an NT
     GEMM, the backward the NN form  c = s W  of the same kernel (the transposed MFMA operand is gathered in LDS by
     ds_read_b64_tr_b16); only the fp32 parity engine falls back to a W^T copy (ops.linear_dgrad);
   * bf16 / head_dim 128 attention reads its transposed operands out of row-major LDS tiles as well; fp32 and the other head dims keep
@@ -135,6 +136,10 @@ class LlamaLRP:
                 o += rows
             return dst
 
+        def put_gu(dst, wg, wu):
+            # gate / up rows interleaved in blocks of 32 (ops.interleave_gate_up): the gated-MLP rules then run inside the GEMM epilogues
+            return ops.interleave_gate_up(wg.to(device=dev, dtype=dtype), wu.to(device=dev, dtype=dtype), out=dst)
+
         self.embed, self.lm_head = put(take(V, H), W["embed"]), put(take(V, H), W["lm_head"])
         self.norm = put(take(H), W["norm"])
         self.lm_head_t = None                        # [H, V] copy, made on the first dense-seed explanation
@@ -142,7 +147,7 @@ class LlamaLRP:
         for L in W["layers"]:
             self.layers.append(dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
                                     wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
-                                    wgu=put(take(2 * I, H), L["wg"], L["wu"]), wd=put(take(H, I), L["wd"])))
+                                    wgu=put_gu(take(2 * I, H), L["wg"], L["wu"]), wd=put(take(H, I), L["wd"])))
         self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
@@ -251,8 +256,7 @@ class LlamaLRP:
                 a_l = self._lin_fwd(o_l, Lw["wo"], new("a_l", B, H))
                 h1_l = new("h1_l", B, H)
                 x2_l, rstd2_l = ops.add_rmsnorm_fwd(h_l, a_l, Lw["ln2"], c["rms_eps"], hsum_out=h1_l)
-                gu_l = self._lin_fwd(x2_l, Lw["wgu"], new("gu_l", B, 2 * I))
-                m_l = ops.gated_act_fwd(gu_l[:, :I], gu_l[:, I:], new("m_l", B, I), self.act)
+                gu_l, m_l = ops.gemm_gated_fwd(x2_l, Lw["wgu"], new("gu_l", B, 2 * I), new("m_l", B, I), self.act)
                 dn_l = self._lin_fwd(m_l, Lw["wd"], new("dn_l", B, H))
                 st.update(top=True, qkv=qkv, qkr=qkr, lse=lse, o_l=o_l, a_l=a_l, h1_l=h1_l, rstd2_l=rstd2_l, gu_l=gu_l, dn_l=dn_l)
                 stash.append(st)
@@ -263,8 +267,7 @@ class LlamaLRP:
             h1 = new(("h1", li), M, H)
             x2, st["rstd2"] = new("x2", M, H), f32(("rstd2", li), M)
             ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1, y=x2, rstd=st["rstd2"])
-            gu = self._lin_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I))
-            m = ops.gated_act_fwd(gu[:, :I], gu[:, I:], new("m", M, I), self.act)
+            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), new("m", M, I), self.act)
             dn = self._lin_fwd(m, Lw["wd"], new(("dn", li), M, H))
             st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
             stash.append(st)
@@ -322,9 +325,7 @@ class LlamaLRP:
             if st.get("top", False):
                 # ---- one row per prompt through MLP, norm/add2 and o-proj; scatter into the dense attention inputs
                 gu_l = st["gu_l"]
-                Gm = self._lin_bwd(A_last, Lw["wd"], new("Gm_l", B, I))
-                Agu = new("Agu_l", B, 2 * I)
-                ops.gated_act_bwd(Gm, gu_l[:, :I], gu_l[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
+                Agu = ops.gemm_gated_bwd(A_last, Lw["wd"], gu_l, new("Agu_l", B, 2 * I), self.eps_g, E["lin"], self.act)
                 Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2_l", B, H))
                 Gs1_l, Aa_l = new("Gs1_l", B, H), new("Aa_l", B, H)
                 ops.rmsnorm_bwd_add2(Gs_last, Gx2, Lw["ln2"], st["rstd2_l"], st["h1_l"], st["a_l"], Gs1_l, Aa_l, None, 0.0,
@@ -343,9 +344,7 @@ class LlamaLRP:
             else:
                 gu = st["gu"]
                 # ---- MLP
-                Gm = self._lin_bwd(Adn, Lw["wd"], new("Gm", M, I))
-                Agu = new("Agu", M, 2 * I)
-                ops.gated_act_bwd(Gm, gu[:, :I], gu[:, I:], Agu[:, :I], Agu[:, I:], self.eps_g, E["lin"], self.act)
+                Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, new("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
                 Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
                 Gs1, Aa = new("Gs1", M, H), new("Aa", M, H)
                 ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])

@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory (caching allocator) and the curr
 every computation below is a call into liblrp_hip.so with raw device pointers.  CPU tensors are
 rejected -- there is no fallback.
 """
+import os
+
 import torch
 
 from ._lib import lib, check, F32, BF16, ACT
@@ -316,6 +318,84 @@ def gated_act_bwd(Gm, g, u, Ag, Au, eps_g, eps_lin, act="silu"):
     check(lib.lrp_gated_act_bwd(p(Gm), p(g), p(u), p(Ag), p(Au), M, I, Gm.stride(0), g.stride(0), u.stride(0), Ag.stride(0),
                                 Au.stride(0), eps_g, eps_lin, ACT[act], dt(g), stream()), "lrp_gated_act_bwd")
     return Ag, Au
+
+
+GATED_IL = 32            # interleave block of a fused gate/up weight (include/lrp_hip.h: LRP_GATED_IL)
+
+
+def interleave_gate_up(wg, wu, out=None):
+    """fused gate/up weight [2 I, H] with its rows in blocks of 64 = [32 gate rows | 32 up rows]: one 64-column block of W_gu x -- and one
+    wave's accumulator tile of the GEMM -- then holds gate AND up of the same 32 intermediate indices (lrp_gemm_gated_fwd / _bwd)"""
+    I, H = wg.shape
+    if I % GATED_IL:
+        raise ValueError(f"intermediate size {I} is not a multiple of {GATED_IL}")
+    if out is None:
+        out = torch.empty(2 * I, H, device=wg.device, dtype=wg.dtype)
+    v = out.view(I // GATED_IL, 2, GATED_IL, H)
+    v[:, 0].copy_(wg.view(I // GATED_IL, GATED_IL, H))
+    v[:, 1].copy_(wu.view(I // GATED_IL, GATED_IL, H))
+    return out
+
+
+def gated_act_fwd_il(gu, out, act="silu"):
+    M, I = out.shape
+    same(gu, out)
+    check(lib.lrp_gated_act_fwd_il(p(gu), p(out), M, I, gu.stride(0), out.stride(0), ACT[act], dt(gu), stream()), "lrp_gated_act_fwd_il")
+    return out
+
+
+def gated_act_bwd_il(Gm, gu, Agu, eps_g, eps_lin, act="silu"):
+    M, I = Gm.shape
+    same(gu, Gm, Agu)
+    check(lib.lrp_gated_act_bwd_il(p(Gm), p(gu), p(Agu), M, I, Gm.stride(0), gu.stride(0), Agu.stride(0), eps_g, eps_lin, ACT[act], dt(gu),
+                                   stream()), "lrp_gated_act_bwd_il")
+    return Agu
+
+
+GATED_FUSION = os.environ.get("LXT_AMD_GATED_FUSION", "1") != "0"     # measurement switch: 0 = GEMM + element-wise rule kernels
+
+
+def gemm_gated_fwd(x, Wgu, gu, m, act="silu"):
+    """gu[M, 2 I] = x @ Wgu^T (Wgu interleaved, see interleave_gate_up) and m[M, I] = act(g) (*) u: ONE kernel on the big bf16 problems
+    (the gated rule runs in the GEMM's epilogue), the GEMM / skinny / small-M forward + lrp_gated_act_fwd_il otherwise"""
+    M, K = x.shape
+    I = m.shape[1]
+    same(x, Wgu, gu, m)
+    if GATED_FUSION and x.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(x, Wgu):
+        ev = GEMM_TIMER.span(2.0 * M * 2 * I * K) if GEMM_TIMER is not None else None
+        if ev:
+            ev[0].record()
+        rc = lib.lrp_gemm_gated_fwd(p(x), p(Wgu), p(gu), p(m), M, I, K, x.stride(0), Wgu.stride(0), gu.stride(0), m.stride(0), ACT[act],
+                                    dt(x), stream())
+        if ev:
+            ev[1].record()
+        check(rc, "lrp_gemm_gated_fwd")
+        return gu, m
+    linear_fwd(x, Wgu, out=gu)
+    gated_act_fwd_il(gu, m, act)
+    return gu, m
+
+
+def gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act="silu"):
+    """Agu[M, 2 I] (interleaved) from A_dn[M, H] and the stored down weight Wd [H, I]: Gm = A_dn Wd never reaches memory on the big bf16
+    problems (the gated backward rule runs in the NN GEMM's epilogue); otherwise ops.linear_dgrad + lrp_gated_act_bwd_il"""
+    M, K = Adn.shape
+    I = Wd.shape[1]
+    same(Adn, Wd, gu, Agu)
+    if GATED_FUSION and Adn.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(Adn, Wd):
+        need = lib.lrp_gemm_gated_bwd_ws(M, I, K, ACT[act], dt(Adn)) if (Adn.is_contiguous() and Wd.is_contiguous()) else M * I * 2
+        ws = workspace(need, Adn) if need else None
+        ev = GEMM_TIMER.span(2.0 * M * I * K) if GEMM_TIMER is not None else None
+        if ev:
+            ev[0].record()
+        rc = lib.lrp_gemm_gated_bwd(p(Adn), p(Wd), p(gu), p(Agu), M, I, K, Adn.stride(0), Wd.stride(0), gu.stride(0), Agu.stride(0),
+                                    eps_g, eps_lin, ACT[act], dt(Adn), p(ws), stream())
+        if ev:
+            ev[1].record()
+        check(rc, "lrp_gemm_gated_bwd")
+        return Agu
+    Gm = linear_dgrad(Adn, Wd)
+    return gated_act_bwd_il(Gm, gu, Agu, eps_g, eps_lin, act)
 
 
 def rope_fwd(x, out, cos, sin, seq, n_heads, d):

@@ -112,6 +112,57 @@ def test_gemm_skinny_split_k(ops, M, nn):
         assert not torch.isnan(out).any() and nmax(out, ref) < tol, (M, nn, odt)
 
 
+def _act64(x, act):
+    if act == "silu":
+        return x * torch.sigmoid(x)
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+@pytest.mark.parametrize("M,I,K,act", [(4096, 4096, 1024, "silu"), (3000, 3584, 256, "gelu_tanh"), (3000, 7168, 128, "silu"), (300, 512, 128, "silu"), (40, 64, 256, "silu")])
+def test_gemm_gated_fused_epilogues(ops, M, I, K, act):
+    """lrp_gemm_gated_fwd / _bwd: the gated-MLP rules (ref lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281)
+    inside the epilogues of the gate/up forward GEMM and of the down-projection dgrad (NN form), on the interleaved gate/up layout
+    (ops.interleave_gate_up).  Big shapes take the fused ping-pong kernel (full and ragged tiles), small ones the GEMM + element-wise
+    pair; both against fp64 on the same bf16 operands, and the fused kernels against the unfused pair bit for bit."""
+    g_ = torch.Generator().manual_seed(M + I)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, generator=g_).to(bf).cuda()
+    wg, wu = ((torch.randn(I, K, generator=g_) * K ** -0.5).to(bf).cuda() for _ in range(2))
+    Wgu = ops.interleave_gate_up(wg, wu)
+    v = Wgu.view(I // 32, 2, 32, K)
+    assert torch.equal(v[:, 0].reshape(I, K), wg) and torch.equal(v[:, 1].reshape(I, K), wu)
+    gu, m = torch.full((M, 2 * I), float("nan"), dtype=bf, device="cuda"), torch.full((M, I), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_gated_fwd(x, Wgu, gu, m, act)
+    gv = gu.view(M, I // 32, 2, 32)
+    g, u = gv[:, :, 0].reshape(M, I), gv[:, :, 1].reshape(M, I)
+    g64, u64 = f64(x) @ f64(wg).T, f64(x) @ f64(wu).T
+    assert nmax(g, g64) < 2e-2 and nmax(u, u64) < 2e-2
+    m_ref = _act64(f64(g), act).to(bf).double() * f64(u)          # from the STORED g, u: the rule itself is exact up to one rounding
+    assert not torch.isnan(m).any() and nmax(m, m_ref) < 1e-2
+    gu2, m2 = torch.empty_like(gu), torch.empty_like(m)            # unfused pair
+    ops.linear_fwd(x, Wgu, out=gu2)
+    ops.gated_act_fwd_il(gu2, m2, act)
+    assert torch.equal(gu, gu2) and torch.equal(m, m2)
+    # ---- backward: A_dn [M, H'] with H' = K, down weight Wd [K, I]
+    Adn = torch.randn(M, K, generator=g_).to(bf).cuda()
+    Wd = (torch.randn(K, I, generator=g_) * K ** -0.5).to(bf).cuda()
+    for eps_g, eps_lin in ((1e-10, 0.0), (1e-8, 1e-8)):
+        Agu = torch.full((M, 2 * I), float("nan"), dtype=bf, device="cuda")
+        ops.gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act)
+        Gm = ops.linear_dgrad(Adn, Wd)
+        Agu2 = torch.empty_like(Agu)
+        ops.gated_act_bwd_il(Gm, gu, Agu2, eps_g, eps_lin, act)
+        assert not torch.isnan(Agu).any() and torch.equal(Agu, Agu2)
+        av = Agu.view(M, I // 32, 2, 32)
+        Ag, Au = av[:, :, 0].reshape(M, I), av[:, :, 1].reshape(M, I)
+        y = _act64(f64(g), act).to(bf).double()
+        half = 0.5 * f64(Gm)
+        Ag_ref = half * f64(u) * (y / (f64(g) + eps_g))
+        Au_ref = half * y * (f64(u) / (f64(u) + eps_lin) if eps_lin else 1.0)
+        assert nmax(Ag, Ag_ref) < 2e-2 and nmax(Au, Au_ref) < 2e-2
+        assert nmax(Gm, f64(Adn) @ f64(Wd)) < 2e-2
+
+
 def test_gemm_batched_and_f32_out(ops):
     a, b = rnd(3, 70, 96, seed=4), rnd(3, 50, 96, seed=5)
     assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).transpose(1, 2)) < 2e-5
