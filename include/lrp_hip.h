@@ -168,7 +168,7 @@ int lrp_gated_act_bwd_il(const void* Gm, const void* gu, void* Agu, int M, int I
                          float eps_g, float eps_lin, int act, int dtype, void* stream);
 int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
                        int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
-int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int act, int dtype);
+int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype);
 int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
                        int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws, void* stream);
 

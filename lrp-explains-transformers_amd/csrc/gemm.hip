@@ -502,10 +502,10 @@ extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void
     return lrp_gated_act_fwd_il(gu, m, M, I, ldgu, ldm, act, dtype, stream);
 }
 
-extern "C" int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int act, int dtype) {
+extern "C" int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype) {
     if (dtype != LRP_BF16 || M <= 0 || I <= 0) return 0;
-    // contiguous operands assumed (lda = K, ldw = I): the fused kernel needs no scratch; the GEMM + element-wise pair needs Gm [M, I]
-    return gated_fused_ok(M, I, K, I, K, I, 1, act) ? 0 : (int64_t)M * I * 2;
+    // the fused kernel needs no scratch; the GEMM + element-wise pair needs Gm [M, I]
+    return gated_fused_ok(M, I, K, I, lda, ldw, 1, act) ? 0 : (int64_t)M * I * 2;
 }
 
 extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,

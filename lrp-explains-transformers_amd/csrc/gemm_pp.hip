@@ -441,7 +441,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             }
         }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // no LDS-DMA may outlive the workgroup's LDS allocation
+    // (every LDS-DMA load was waited for inside the last K tile; the C stores may still be in flight when the wave ends)
+#if defined(PP_TIMELINE) || defined(PP_TAIL_WAIT)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #ifdef PP_TIMELINE
     if (tl_on) {
         PP_STAMP(__builtin_amdgcn_s_memtime)                            // C stores issued (and, after the wait above, retired)

@@ -21,6 +21,8 @@ MI355X-first decisions:
     + final norm backward is a single row per prompt.
 Python only sequences kernel launches on the current stream; it performs no arithmetic.
 """
+import os
+
 import torch
 
 from . import ops
@@ -94,6 +96,17 @@ def weights_from_hf(model):
     return config_from_hf(model.config), W
 
 
+def pitch_pad(cols, elem_size):
+    """extra elements per row for a K-contiguous GEMM operand: a row pitch that is a multiple of 4 KiB puts the same K offset of every row
+    on the same memory channels; measured on MI355X at M = 8192, N = 4096 (tools/pitch_probe.py, profiles/r03_gemm_experiments.txt):
+    K = 28672 NT 1357 -> 1553 TFLOP/s with 128 bytes of padding on both operands, K = 14336 1460 -> 1545 (hipBLASLt gains too:
+    1533 -> 1603); no effect at K <= 6144 or on the C pitch"""
+    nbytes = cols * elem_size
+    if os.environ.get("LXT_AMD_PITCH_PAD", "1") == "0":          # measurement switch
+        return 0
+    return 128 // elem_size if (nbytes >= 16384 and nbytes % 4096 == 0) else 0
+
+
 class LlamaLRP:
     """Device-resident weights (both layouts) + explain()."""
 
@@ -115,7 +128,8 @@ class LlamaLRP:
         H, I, nq, nk, hd, V = cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv"], cfg["head_dim"], cfg["vocab"]
         nqkv = (nq + 2 * nk) * hd
         up = lambda n: (n + 63) // 64 * 64                                   # noqa: E731  (every view starts 128-byte aligned)
-        per_layer = 2 * up(H) + up(nqkv * H) + up(H * nq * hd) + up(2 * I * H) + up(H * I)
+        es = torch.empty(0, dtype=dtype).element_size()
+        per_layer = 2 * up(H) + up(nqkv * H) + up(H * nq * hd) + up(2 * I * H) + up(H * (I + pitch_pad(I, es)))
         total = 2 * up(V * H) + up(H) + len(W["layers"]) * per_layer
         self.flat = torch.empty(total, device=dev, dtype=dtype)
         cursor = [0]
@@ -127,6 +141,11 @@ class LlamaLRP:
             v = self.flat[cursor[0]: cursor[0] + n].view(*shape)
             cursor[0] += up(n)
             return v
+
+        def take_rows(rows, cols):
+            # [rows, cols] view with a row pitch that is not a multiple of 4 KiB (pitch_pad): the K-contiguous operand of a long-K GEMM
+            pad = pitch_pad(cols, es)
+            return take(rows, cols + pad)[:, :cols]
 
         def put(dst, *srcs):
             o = 0
@@ -147,7 +166,7 @@ class LlamaLRP:
         for L in W["layers"]:
             self.layers.append(dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
                                     wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
-                                    wgu=put_gu(take(2 * I, H), L["wg"], L["wu"]), wd=put(take(H, I), L["wd"])))
+                                    wgu=put_gu(take(2 * I, H), L["wg"], L["wu"]), wd=put(take_rows(H, I), L["wd"])))
         self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
@@ -201,16 +220,20 @@ class LlamaLRP:
         def __init__(self, device):
             self.device, self.buf = device, {}
 
-        def get(self, tag, shape, dtype, zero=False):
+        def get(self, tag, shape, dtype, zero=False, pad=0):
+            """pad: extra elements per row of a 2-D buffer (the view returned is [rows, cols] with row pitch cols + pad)"""
+            full = tuple(shape[:-1]) + (shape[-1] + pad,) if pad else tuple(shape)
             n = 1
-            for s_ in shape:
+            for s_ in full:
                 n *= s_
             t = self.buf.get((tag, dtype))
             if t is None or t.numel() < n:
                 t = torch.empty(max(n, 1), device=self.device, dtype=dtype)
                 self.buf[(tag, dtype)] = t
-            v = t[:n].view(*shape)
-            return v.zero_() if zero else v
+            v = t[:n].view(*full)
+            if zero:
+                v.zero_()
+            return v[..., : shape[-1]] if pad else v
 
         def nbytes(self):
             return sum(t.numel() * t.element_size() for t in self.buf.values())
@@ -230,6 +253,7 @@ class LlamaLRP:
             self._arena = LlamaLRP._Arena(dev)
         ar = self._arena
         new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        wide = lambda tag, r, c_: ar.get(tag, (r, c_), dt, pad=pitch_pad(c_, emb.element_size()))  # noqa: E731  (long-K GEMM operands)
         f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
         stash = []
         h_prev, branch = emb, None
@@ -267,7 +291,7 @@ class LlamaLRP:
             h1 = new(("h1", li), M, H)
             x2, st["rstd2"] = new("x2", M, H), f32(("rstd2", li), M)
             ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1, y=x2, rstd=st["rstd2"])
-            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), new("m", M, I), self.act)
+            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
             dn = self._lin_fwd(m, Lw["wd"], new(("dn", li), M, H))
             st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
             stash.append(st)
@@ -292,6 +316,7 @@ class LlamaLRP:
         scale = d ** -0.5
         ar = self._arena
         new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        wide = lambda tag, r, c_: ar.get(tag, (r, c_), dt, pad=pitch_pad(c_, emb.element_size()))  # noqa: E731
         f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
         zeros = lambda tag, *s: ar.get(tag, s, dt, zero=True)  # noqa: E731
         # LM head eps rule + final-norm identity rule on the single explained row of each prompt
@@ -344,7 +369,7 @@ class LlamaLRP:
             else:
                 gu = st["gu"]
                 # ---- MLP
-                Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, new("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
+                Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
                 Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
                 Gs1, Aa = new("Gs1", M, H), new("Aa", M, H)
                 ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])

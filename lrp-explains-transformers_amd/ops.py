@@ -383,7 +383,7 @@ def gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act="silu"):
     I = Wd.shape[1]
     same(Adn, Wd, gu, Agu)
     if GATED_FUSION and Adn.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(Adn, Wd):
-        need = lib.lrp_gemm_gated_bwd_ws(M, I, K, ACT[act], dt(Adn)) if (Adn.is_contiguous() and Wd.is_contiguous()) else M * I * 2
+        need = lib.lrp_gemm_gated_bwd_ws(M, I, K, Adn.stride(0), Wd.stride(0), ACT[act], dt(Adn))
         ws = workspace(need, Adn) if need else None
         ev = GEMM_TIMER.span(2.0 * M * I * K) if GEMM_TIMER is not None else None
         if ev:
@@ -576,7 +576,7 @@ def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
     M, K = x2.shape
     N = W.shape[0]
     odt = out_dtype or (out.dtype if out is not None else x2.dtype)
-    if M <= SKINNY_MAX and gemm_nn_ok(x2, W) and W.is_contiguous():
+    if M <= SKINNY_MAX and gemm_nn_ok(x2, W):
         if out is None:
             out = torch.empty(M, N, device=x2.device, dtype=odt)
         return gemm_skinny(x2, W, out, nn=False, bias=bias)
