@@ -71,7 +71,8 @@ int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M,
 
 /* lrp_gemm_skinny: the same two products for 1 <= M <= 256 rows (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic
  * intensity ~2 M FLOP/B in bf16): split-K over the K tiles so that every CU streams its share of the weight exactly once, fp32 partial
- * slabs in `ws` (lrp_gemm_skinny_ws(M,N,K) BYTES, caller-allocated), reduced (+ bias, cast) by a second small kernel.
+ * slabs in `ws` (lrp_gemm_skinny_ws(M,N,K) BYTES, caller-allocated), reduced (+ bias, cast) by a second small kernel; when the tile
+ * count alone fills the chip (the LM head) there is one split and the kernel writes C directly.
  *   nn = 0: C = A[M,K] . B[N,K]^T (forward z = x W^T);   nn = 1: C = A[M,K] . B[K,N] (redistribution c = s W, W as stored).
  * Same operand restrictions as lrp_gemm_nn.  ref: lxt/explicit/functional.py:351 (forward), :355-364 (backward). */
 int64_t lrp_gemm_skinny_ws(int M, int N, int K);

@@ -468,6 +468,8 @@ extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void
     const int used = (nkt + per - 1) / per;                                  // every launched split owns >= 1 K tile ...
     if (nkt - (used - 1) * per < 2 && used > 1) return LRP_ESHAPE;           // ... and the kernel needs >= 2 (never hit for K % 128 == 0)
     const int64_t ldw = (N + 3) / 4 * 4, slab = (int64_t)M * ldw;
+    // one split (the tile count alone fills the chip: the LM head): the plain kernel writes the output directly
+    if (used == 1) return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, out_dtype, nn, 1, nkt, 0, st);
     int rc = lrp_launch_gemm_pp(A, B, ws, nullptr, M, N, K, lda, ldb, ldw, LRP_F32, nn, used, per, slab, st);
     if (rc != LRP_OK) return rc;
     const int64_t nq = (int64_t)M * ((N + 3) / 4);

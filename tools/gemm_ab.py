@@ -139,6 +139,7 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--m", type=int, default=8192, help="rows (B x S)")
     a_ = ap.parse_args()
     print(torch.cuda.get_device_name(0), torch.version.hip, flush=True)
     libs = []
@@ -154,7 +155,7 @@ if __name__ == "__main__":
             check(fn, name)
     libs = [(n, f) for (n, f) in libs if not n.startswith("tl")]
     res = {}
-    for (M, N, K, what) in SHAPES:
+    for (M, N, K, what) in [(a_.m, n_, k_, w_) for (_, n_, k_, w_) in SHAPES]:
         a = torch.randn(M, K, device="cuda").bfloat16()
         b = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
