@@ -464,9 +464,12 @@ extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void
     if (!pp_ok(M, N, K, lda, ldb, nn)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int splits = skinny_splits(N, K), nkt = K / 64;
-    const int per = (nkt + splits - 1) / splits;
-    const int used = (nkt + per - 1) / per;                                  // every launched split owns >= 1 K tile ...
-    if (nkt - (used - 1) * per < 2 && used > 1) return LRP_ESHAPE;           // ... and the kernel needs >= 2 (never hit for K % 128 == 0)
+    int per = (nkt + splits - 1) / splits;
+    int used = (nkt + per - 1) / per;
+    while (used > 1 && nkt - (used - 1) * per < 2) {                         // the kernel needs >= 2 K tiles in every split, the last one too
+        ++per;                                                              // (K = 2560: 40 tiles in 16 splits of 3 would leave 1)
+        used = (nkt + per - 1) / per;
+    }
     const int64_t ldw = (N + 3) / 4 * 4, slab = (int64_t)M * ldw;
     // one split (the tile count alone fills the chip: the LM head): the plain kernel writes the output directly
     if (used == 1) return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, out_dtype, nn, 1, nkt, 0, st);

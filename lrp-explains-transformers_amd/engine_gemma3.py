@@ -1,0 +1,296 @@
+"""Fused AttnLRP driver for Gemma-3 text decoders (BASELINE config 4): forward + relevance backward of `lxt.efficient` on
+Gemma3ForCausalLM as straight sequences of liblrp_hip launches -- no autograd, no module hooks.
+
+What differs from the Llama driver (engine.py), with the reference lines that fix the behaviour:
+  * (1 + w) RMSNorm with the rstd detached (ref lxt/efficient/models/gemma3.py:11-12 `gemma3_norm`, HF Gemma3RMSNorm.forward):
+    the norm kernels' `w_offset = 1`; the backward is the row-constant scale G (1 + w) rstd;
+  * FOUR norms per layer (HF Gemma3DecoderLayer.forward): input -> attention -> post-attention norm -> residual add;
+    pre-feed-forward norm -> gated MLP -> post-feed-forward norm -> residual add;
+  * per-head q / k RMSNorm (head_dim-wide rows) in front of RoPE (HF Gemma3Attention.forward);
+  * gelu-tanh gated MLP under the same identity + uniform rules (ref gemma3.py:15 -> patches.py:145-157 `gated_mlp_forward`);
+  * sliding-window layers (5 local : 1 global in the released checkpoints) with their own rotary base, attention scale
+    query_pre_attn_scalar ** -0.5, embeddings scaled by sqrt(hidden);
+  * attention factors as everywhere in lxt.efficient (ref patches.py:193-203: q, k / 4, v / 2) -- inside the attention kernels.
+The reference defines Gemma-3 for the efficient mode only (there is no lxt.explicit Gemma-3), and so does this driver.
+Weights are held once (forward layout; dgrads run the NN GEMM on the stored weight), gate/up interleaved for the fused GEMM epilogues,
+activations live in the same tagged arena as the Llama driver's.
+"""
+import torch
+
+from . import ops
+from .engine import EFFICIENT, LlamaLRP, pitch_pad
+
+_STATIC_ROPE = ("default", "linear")
+
+
+def config_from_hf(hf_cfg):
+    """HF Gemma3TextConfig (or the text_config of a Gemma3Config) -> engine cfg; unsupported features are refused loudly"""
+    hf_cfg = getattr(hf_cfg, "text_config", hf_cfg)
+    mt = getattr(hf_cfg, "model_type", "")
+    if mt not in ("gemma3_text", "gemma3"):
+        raise NotImplementedError(f"Gemma3LRP drives Gemma-3 text decoders only (model_type={mt!r})")
+    if getattr(hf_cfg, "attention_bias", False):
+        raise NotImplementedError("Gemma3LRP: attention_bias = True is not supported by the fused driver (use monkey_patch)")
+    if getattr(hf_cfg, "attn_logit_softcapping", None) or getattr(hf_cfg, "final_logit_softcapping", None):
+        raise NotImplementedError("Gemma3LRP: logit soft-capping is not supported by the fused driver (use monkey_patch)")
+    if not getattr(hf_cfg, "use_bidirectional_attention", False) is False:
+        raise NotImplementedError("Gemma3LRP: bidirectional attention is not supported")
+    act = getattr(hf_cfg, "hidden_activation", getattr(hf_cfg, "hidden_act", "gelu_pytorch_tanh"))
+    if act not in ("gelu_pytorch_tanh", "gelu_tanh", "silu"):
+        raise NotImplementedError(f"Gemma3LRP: activation {act!r}")
+    rope = {}
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    for lt in sorted(set(hf_cfg.layer_types)):
+        rp = hf_cfg.rope_parameters[lt]
+        kind = rp.get("rope_type", "default")
+        if kind not in _STATIC_ROPE:
+            raise NotImplementedError(f"Gemma3LRP: rope_type {kind!r}")
+        if kind == "default":
+            d = hf_cfg.head_dim
+            inv, att = 1.0 / (float(rp["rope_theta"]) ** (torch.arange(0, d, 2, dtype=torch.float32) / d)), 1.0
+        else:
+            inv, att = ROPE_INIT_FUNCTIONS[kind](hf_cfg, "cpu", layer_type=lt)
+        rope[lt] = (inv.float().cpu(), float(att))
+    return dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size, n_layers=hf_cfg.num_hidden_layers,
+                n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hf_cfg.head_dim,
+                vocab=hf_cfg.vocab_size, rms_eps=float(hf_cfg.rms_norm_eps), act="silu" if act == "silu" else "gelu_tanh",
+                scale=float(hf_cfg.query_pre_attn_scalar) ** -0.5, layer_types=list(hf_cfg.layer_types),
+                window=int(hf_cfg.sliding_window), rope=rope, embed_scale=float(hf_cfg.hidden_size) ** 0.5)
+
+
+def weights_from_hf(model):
+    """plain (cfg, W) view of a HF Gemma3ForCausalLM / the language model of a Gemma3ForConditionalGeneration"""
+    lm = model.model if hasattr(model, "lm_head") else model
+    m = getattr(lm, "language_model", lm)
+    m = getattr(m, "model", m) if not hasattr(m, "layers") else m
+    W = dict(embed=m.embed_tokens.weight.detach(), norm=m.norm.weight.detach(), lm_head=model.lm_head.weight.detach(), layers=[])
+    for L in m.layers:
+        a, mlp = L.self_attn, L.mlp
+        W["layers"].append(dict(ln_in=L.input_layernorm.weight.detach(), ln_pa=L.post_attention_layernorm.weight.detach(),
+                                ln_pf=L.pre_feedforward_layernorm.weight.detach(), ln_pff=L.post_feedforward_layernorm.weight.detach(),
+                                qn=a.q_norm.weight.detach(), kn=a.k_norm.weight.detach(),
+                                wq=a.q_proj.weight.detach(), wk=a.k_proj.weight.detach(), wv=a.v_proj.weight.detach(),
+                                wo=a.o_proj.weight.detach(), wg=mlp.gate_proj.weight.detach(), wu=mlp.up_proj.weight.detach(),
+                                wd=mlp.down_proj.weight.detach()))
+    cfg = config_from_hf(model.config)
+    return cfg, W
+
+
+class Gemma3LRP:
+    """explain(input_ids) -> dict(idx, logit, R_tok, logits): AttnLRP (lxt.efficient) token relevances of a Gemma-3 text decoder"""
+
+    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", max_seq=4096):
+        if not torch.cuda.is_available():
+            raise RuntimeError("Gemma3LRP needs a HIP device: the LRP kernels have no CPU fallback")
+        self.cfg, self.dtype, self.device = dict(cfg), dtype, torch.device(device)
+        self.eps, self.act = dict(EFFICIENT), cfg["act"]
+        self.eps_g = self.eps["act"]
+        dev = self.device
+        H, I, nq, nk, d, V = cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv"], cfg["head_dim"], cfg["vocab"]
+        nqkv = (nq + 2 * nk) * d
+        es = torch.empty(0, dtype=dtype).element_size()
+        up = lambda n: (n + 63) // 64 * 64                                   # noqa: E731
+        tied = W["lm_head"].data_ptr() == W["embed"].data_ptr()
+        per_layer = 4 * up(H) + 2 * up(d) + up(nqkv * H) + up(H * nq * d) + up(2 * I * H) + up(H * (I + pitch_pad(I, es)))
+        total = (1 if tied else 2) * up(V * H) + up(H) + len(W["layers"]) * per_layer
+        self.flat = torch.empty(total, device=dev, dtype=dtype)          # ONE buffer: a multi-GPU start-up is a single broadcast
+        cursor = [0]
+
+        def take(*shape):
+            n = 1
+            for s_ in shape:
+                n *= s_
+            v = self.flat[cursor[0]: cursor[0] + n].view(*shape)
+            cursor[0] += up(n)
+            return v
+
+        def put(dst, *srcs):
+            o = 0
+            for t in srcs:
+                dst[o: o + t.shape[0]].copy_(t.to(device=dev, dtype=dtype, non_blocking=True))
+                o += t.shape[0]
+            return dst
+
+        self.embed = put(take(V, H), W["embed"])
+        self.lm_head = self.embed if tied else put(take(V, H), W["lm_head"])
+        self.norm = put(take(H), W["norm"])
+        self.layers = []
+        for L in W["layers"]:
+            pad = pitch_pad(I, es)
+            self.layers.append(dict(
+                ln_in=put(take(H), L["ln_in"]), ln_pa=put(take(H), L["ln_pa"]), ln_pf=put(take(H), L["ln_pf"]), ln_pff=put(take(H), L["ln_pff"]),
+                qn=put(take(d), L["qn"]), kn=put(take(d), L["kn"]),
+                wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * d), L["wo"]),
+                wgu=ops.interleave_gate_up(L["wg"].to(device=dev, dtype=dtype), L["wu"].to(device=dev, dtype=dtype), out=take(2 * I, H)),
+                wd=put(take(H, I + pad)[:, :I], L["wd"])))
+        self.attn_t = ops.attn_needs_transposed(self.embed, d)
+        # rotary tables per layer type (HF hands cos / sin to the layers in the model dtype: keep that rounding, store fp32)
+        self.rope = {}
+        for lt, (inv, att) in cfg["rope"].items():
+            fr = torch.arange(max_seq, dtype=torch.float32)[:, None] * inv[None, :]
+            e = torch.cat((fr, fr), dim=-1)
+            self.rope[lt] = ((e.cos() * att).to(dtype).to(torch.float32).to(dev).contiguous(),
+                             (e.sin() * att).to(dtype).to(torch.float32).to(dev).contiguous())
+        self.embed_scale = torch.tensor(cfg["embed_scale"], dtype=dtype)   # HF: the scale itself is rounded to the model dtype
+        self.max_seq = max_seq
+        self._arena = None
+        torch.cuda.synchronize(dev)
+
+    @classmethod
+    def from_hf(cls, model, **kw):
+        cfg, W = weights_from_hf(model)
+        kw.setdefault("dtype", next(model.parameters()).dtype)
+        return cls(cfg, W, **kw)
+
+    def release(self):
+        self._arena = None
+
+    def _window(self, li):
+        return self.cfg["window"] if self.cfg["layer_types"][li] == "sliding_attention" else 0
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, emb, B, S):
+        c = self.cfg
+        H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
+        M, dt, dev = B * S, self.dtype, self.device
+        nqd, nkd, nqkv = nq * d, nk * d, (nq + 2 * nk) * d
+        if self._arena is None:
+            self._arena = LlamaLRP._Arena(dev)
+        ar = self._arena
+        new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        wide = lambda tag, r, c_: ar.get(tag, (r, c_), dt, pad=pitch_pad(c_, emb.element_size()))  # noqa: E731
+        f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
+        eps = c["rms_eps"]
+        stash = []
+        h_prev, branch = emb, None
+        for li, Lw in enumerate(self.layers):
+            st = {}
+            cos, sin = self.rope[c["layer_types"][li]]
+            # input norm (fused with the previous layer's residual add: h = h1_prev + post_ff_norm(dn_prev))
+            x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
+            if branch is None:
+                h = h_prev
+                ops.add_rmsnorm_fwd(h_prev, None, Lw["ln_in"], eps, 1.0, y=x, rstd=st["rstd1"])
+            else:
+                h = new(("h", li & 1), M, H)
+                ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln_in"], eps, 1.0, hsum_out=h, y=x, rstd=st["rstd1"])
+            qkv = ops.linear_fwd(x, Lw["wqkv"], out=new(("qkv", li), M, nqkv))
+            # per-head q / k norm on contiguous [M * heads, d] rows, then RoPE with this layer type's table
+            qc = new("qc", M, nqd).copy_(qkv[:, :nqd])
+            kc = new("kc", M, nkd).copy_(qkv[:, nqd: nqd + nkd])
+            qn, st["rstd_q"] = new("qn", M, nqd), f32(("rstd_q", li), M * nq)
+            kn, st["rstd_k"] = new("kn", M, nkd), f32(("rstd_k", li), M * nk)
+            ops.add_rmsnorm_fwd(qc.view(M * nq, d), None, Lw["qn"], eps, 1.0, y=qn.view(M * nq, d), rstd=st["rstd_q"])
+            ops.add_rmsnorm_fwd(kc.view(M * nk, d), None, Lw["kn"], eps, 1.0, y=kn.view(M * nk, d), rstd=st["rstd_k"])
+            qr = ops.rope_fwd(qn, new(("qr", li), M, nqd), cos, sin, S, nq, d)
+            kr = ops.rope_fwd(kn, new(("kr", li), M, nkd), cos, sin, S, nk, d)
+            v = qkv[:, nqd + nkd:]
+            v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
+            o, lse = new(("o", li), M, nqd), f32(("lse", li), B, nq, S)
+            ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], True, self._window(li))
+            a = ops.linear_fwd(o, Lw["wo"], out=new("a", M, H))
+            # post-attention norm, residual add, pre-feed-forward norm
+            pa, st["rstd_pa"] = new("pa", M, H), f32(("rstd_pa", li), M)
+            ops.add_rmsnorm_fwd(a, None, Lw["ln_pa"], eps, 1.0, y=pa, rstd=st["rstd_pa"])
+            h1, x2, st["rstd2"] = new(("h1", li & 1), M, H), new("x2", M, H), f32(("rstd2", li), M)
+            ops.add_rmsnorm_fwd(h, pa, Lw["ln_pf"], eps, 1.0, hsum_out=h1, y=x2, rstd=st["rstd2"])
+            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
+            dn = ops.linear_fwd(m, Lw["wd"], out=new("dn", M, H))
+            pff, st["rstd_pff"] = new("pff", M, H), f32(("rstd_pff", li), M)
+            ops.add_rmsnorm_fwd(dn, None, Lw["ln_pff"], eps, 1.0, y=pff, rstd=st["rstd_pff"])
+            st.update(qkv=qkv, qr=qr, kr=kr, o=o, lse=lse, gu=gu)
+            stash.append(st)
+            h_prev, branch = h1, pff
+        last = torch.arange(B, device=dev) * S + (S - 1)
+        h_last = h_prev.index_select(0, last)
+        b_last = branch.index_select(0, last) if branch is not None else None
+        hL_last = new("hL_last", B, H)
+        xn, rstd_f = ops.add_rmsnorm_fwd(h_last, b_last, self.norm, eps, 1.0, hsum_out=hL_last)
+        logits = ops.linear_fwd(xn, self.lm_head, out=f32("logits", B, c["vocab"]))
+        return dict(stash=stash, last=last, rstd_f=rstd_f, logits=logits)
+
+    # ---------------------------------------------------------------------------------------------
+    def backward(self, fw, idx, B, S):
+        c, E = self.cfg, self.eps
+        H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
+        M, rep, dt, dev = B * S, nq // nk, self.dtype, self.device
+        nqd, nkd, nqkv = nq * d, nk * d, (nq + 2 * nk) * d
+        ar = self._arena
+        new = lambda tag, *s: ar.get(tag, s, dt)  # noqa: E731
+        wide = lambda tag, r, c_: ar.get(tag, (r, c_), dt, pad=pitch_pad(c_, torch.empty(0, dtype=dt).element_size()))  # noqa: E731
+        f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
+        zeros = lambda tag, *s: ar.get(tag, s, dt, zero=True)  # noqa: E731
+        # LM head (gradient of the explained logit) + final (1 + w) norm on the one explained row of each prompt, scattered into [M, H]
+        Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new("Gh_last", B, H), 1.0, E["lin"])
+        Gs = zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, fw["last"], Gh_last)       # gradient w.r.t. h_L = h1 + pff
+        for li in range(len(self.layers) - 1, -1, -1):
+            Lw, st = self.layers[li], fw["stash"][li]
+            cos, sin = self.rope[c["layer_types"][li]]
+            win = self._window(li)
+            # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
+            Gdn = new("Gdn", M, H)
+            ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
+            Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
+            Gx2 = ops.linear_dgrad(Agu, Lw["wgu"], out=new("Gx2", M, H))
+            Gs1 = new("Gs1", M, H)
+            ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1
+            # ---- post-attention norm, o-proj, attention
+            Ga = new("Ga", M, H)
+            ops.rmsnorm_bwd_add2(None, Gs1, Lw["ln_pa"], st["rstd_pa"], None, None, Ga, None, None, 1.0, 0.0, 0.0)
+            Gof = ops.linear_dgrad(Ga, Lw["wo"], out=new("Gof", M, nqd))
+            Gho, D = new("Gho", M, nqd), f32("D", B, nq, S)
+            ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
+            q, k, v = st["qr"], st["kr"], st["qkv"][:, nqd + nkd:]
+            k_t = q_t = Gho_t = None
+            if self.attn_t:
+                k_t = ops.transpose_heads(k, B, S, nk, d)
+                q_t = ops.transpose_heads(q, B, S, nq, d)
+                Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
+            dq, dk_h, dv_h = new("dq", M, nqd), new("dk_h", M, nqd), new("dv_h", M, nqd)
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win)
+            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win)
+            dk = ops.gqa_reduce(dk_h, new("dk", M, nkd), M, nk, rep, d)
+            Aqkv = new("Aqkv", M, nqkv)
+            ops.gqa_reduce(dv_h, Aqkv[:, nqd + nkd:], M, nk, rep, d)
+            # RoPE backward (a rotation: plain gradient), then the q / k norms' row-constant scale, written into the fused [q | k | v] operand
+            Gqn = ops.rope_bwd(dq, None, None, new("Gqn", M, nqd), cos, sin, S, nq, d, 0.0, 0.0)
+            Gkn = ops.rope_bwd(dk, None, None, new("Gkn", M, nkd), cos, sin, S, nk, d, 0.0, 0.0)
+            Gq, Gk = new("Gq", M, nqd), new("Gk", M, nkd)
+            ops.rmsnorm_bwd_add2(None, Gqn.view(M * nq, d), Lw["qn"], st["rstd_q"], None, None, Gq.view(M * nq, d), None, None, 1.0, 0.0, 0.0)
+            ops.rmsnorm_bwd_add2(None, Gkn.view(M * nk, d), Lw["kn"], st["rstd_k"], None, None, Gk.view(M * nk, d), None, None, 1.0, 0.0, 0.0)
+            Aqkv[:, :nqd].copy_(Gq)
+            Aqkv[:, nqd: nqd + nkd].copy_(Gk)
+            Gx = ops.linear_dgrad(Aqkv, Lw["wqkv"], out=new("Gx", M, H))
+            # ---- input norm + residual
+            Gs = new(("Gs", li & 1), M, H)
+            ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln_in"], st["rstd1"], None, None, Gs, None, None, 1.0, 0.0, 0.0)
+        return Gs
+
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def explain(self, input_ids=None, inputs_embeds=None, target=None, return_G=False):
+        """input_ids [B, S] (or inputs_embeds [B, S, H] = HF's scaled embeddings); target: None (arg-max of the last position) or [B]
+        vocabulary indices.  Returns dict(idx [B], logit [B], R_tok [B, S] fp32 = sum_h e (*) dlogit/de, logits [B, V])."""
+        if inputs_embeds is None:
+            input_ids = input_ids.to(self.device)
+            B, S = input_ids.shape
+            emb = self.embed.index_select(0, input_ids.reshape(-1)) * self.embed_scale.to(self.device)
+        else:
+            B, S = inputs_embeds.shape[:2]
+            emb = inputs_embeds.to(device=self.device, dtype=self.dtype).reshape(B * S, -1).contiguous()
+        if S > self.max_seq:
+            raise ValueError(f"sequence length {S} exceeds max_seq={self.max_seq}")
+        fw = self.forward(emb, B, S)
+        if target is None:
+            idx, _ = ops.argmax_rows(fw["logits"])
+        else:
+            tgt = torch.as_tensor(target).reshape(-1).cpu().long()
+            if tgt.numel() != B or int(tgt.min()) < 0 or int(tgt.max()) >= self.cfg["vocab"]:
+                raise ValueError(f"target must hold {B} vocabulary indices in [0, {self.cfg['vocab']})")
+            idx = tgt.to(device=self.device, dtype=torch.int32).contiguous()
+        G = self.backward(fw, idx, B, S)
+        logits = fw["logits"].clone()
+        out = dict(idx=idx, logit=logits.gather(1, idx.long()[:, None])[:, 0], R_tok=ops.readout(emb, G).view(B, S), logits=logits)
+        if return_G:
+            out["G_emb"], out["emb"] = G.view(B, S, -1).clone(), emb.view(B, S, -1)
+        return out

@@ -1,0 +1,96 @@
+"""GPU parity of the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP, BASELINE config 4) against
+  (1) the fixture captured from the real reference (tests/golden/gemma3_tiny.npz: lxt.efficient on a seeded Gemma3ForCausalLM with
+      sliding + global layers, q/k-norm, (1+w) norms; fp32 and fp64 runs of the reference), fp32 engine <= 1e-4 (north-star bar), and
+  (2) at the released 4B dimensions (H 2560, 8 query / 4 kv heads of d = 256, I 10240, sliding window 1024, S = 2048, 2 layers:
+      one local, one global) the drop-in path (HF model under lxt_amd.efficient.monkey_patch, autograd-driven, the path the
+      fixtures pin) on the same bf16 weights, plus the fp32 engine as the conditioning reference and batched == single."""
+import warnings
+
+import pytest
+import torch
+
+from tests.golden.hf_models import build_gemma3, wsum
+from tests.util import nmax, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g3():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lxt_amd.engine_gemma3 as e
+    return e
+
+
+def test_gemma3_engine_fp32_vs_reference_fixture(g3):
+    fx = load("gemma3_tiny.npz")
+    ids = torch.as_tensor(fx["ids"]).long()
+    model = build_gemma3(seed=3, attn="eager")
+    assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    eng = g3.Gemma3LRP.from_hf(model, dtype=torch.float32, max_seq=512)
+    out = eng.explain(ids[None])
+    assert int(out["idx"][0]) == int(fx["idx"]) and abs(float(out["logit"][0]) - float(fx["logit"])) < 1e-4
+    e32, e64 = nmax(out["R_tok"][0], fx["R_tok"]), nmax(out["R_tok"][0], fx["R_tok_fp64"])
+    print(f"[gemma3 engine fp32] tok vs reference fp32 {e32:.2e} | vs reference fp64 {e64:.2e}")
+    assert e32 < 1e-4 and e64 < 1e-4
+    # inputs_embeds entry (what the reference's protocol feeds) == input_ids entry; explicit target == arg-max
+    emb = model.get_input_embeddings()(ids[None]).detach()
+    out2 = eng.explain(inputs_embeds=emb, target=[int(fx["idx"])])
+    assert nmax(out2["R_tok"][0], out["R_tok"][0]) < 1e-6
+    # two prompts in one batch == each alone
+    ids2 = torch.stack([ids, ids.flip(0)])
+    outb = eng.explain(ids2)
+    outr = eng.explain(ids.flip(0)[None])
+    assert nmax(outb["R_tok"][0], out["R_tok"][0]) < 1e-5 and nmax(outb["R_tok"][1], outr["R_tok"][0]) < 1e-5
+
+
+def _full_dims_model(layers=2, seed=5):
+    from transformers import Gemma3TextConfig, Gemma3ForCausalLM
+    torch.manual_seed(seed)
+    cfg = Gemma3TextConfig(vocab_size=4096, hidden_size=2560, intermediate_size=10240, num_hidden_layers=layers, num_attention_heads=8,
+                           num_key_value_heads=4, head_dim=256, sliding_window=1024, max_position_embeddings=4096,
+                           layer_types=["sliding_attention", "full_attention"][:layers], query_pre_attn_scalar=256,
+                           attn_implementation="eager", tie_word_embeddings=True)
+    m = Gemma3ForCausalLM(cfg).eval()
+    with torch.no_grad():                                    # non-trivial norm weights (HF initialises them to zero)
+        g = torch.Generator().manual_seed(seed + 1)
+        for n_, p_ in m.named_parameters():
+            if "norm" in n_:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+    return m
+
+
+def test_gemma3_engine_full_dims_bf16(g3):
+    """Gemma-3-4B layer dimensions, S = 2048 (> the 1024-token window), bf16: fused driver vs the drop-in path on the same weights, both
+    against the fp32 engine (the bf16 rounding noise of the two paths must be of the same size), and batched == single"""
+    S = 2048
+    model = _full_dims_model().to(torch.bfloat16)
+    ids = torch.randint(0, 4096, (2, S), generator=torch.Generator().manual_seed(9))
+    eng = g3.Gemma3LRP.from_hf(model, max_seq=S)
+    out = eng.explain(ids)
+    one = eng.explain(ids[1:2])
+    assert torch.equal(out["idx"][1:2], one["idx"]) and nmax(out["R_tok"][1], one["R_tok"][0]) < 2e-2
+    eng32 = g3.Gemma3LRP.from_hf(model, dtype=torch.float32, max_seq=S)
+    ref = eng32.explain(ids, target=out["idx"].cpu())
+    e_eng = max(nmax(out["R_tok"][b], ref["R_tok"][b]) for b in range(2))
+    # the drop-in path: the same HF model, patched, autograd-driven
+    from transformers.models.gemma3 import modeling_gemma3
+    from lxt_amd.efficient import monkey_patch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_gemma3)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    model = model.cuda()
+    e_hf = 0.0
+    for b in range(2):
+        e = model.get_input_embeddings()(ids[b: b + 1].cuda()).requires_grad_()
+        last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+        last[int(out["idx"][b])].backward()
+        R = (e * e.grad)[0].sum(-1).float()
+        e_hf = max(e_hf, nmax(R, ref["R_tok"][b]))
+        cos = torch.nn.functional.cosine_similarity(R.double(), out["R_tok"][b].double(), dim=0)
+        assert float(cos) > 0.99
+    print(f"[gemma3 4B dims, 2 layers, S=2048, bf16] fused driver vs fp32 engine {e_eng:.2e} | drop-in path vs fp32 engine {e_hf:.2e}")
+    assert e_eng < 5e-2 and e_eng < 3 * e_hf + 1e-3

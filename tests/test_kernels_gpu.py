@@ -115,7 +115,7 @@ def test_gemm_skinny_split_k(ops, M, nn):
 def test_gemm_skinny_single_split_and_big_n(ops):
     """tile counts that fill the chip alone (one split: the plain kernel writes the output, no slabs) and the many-tile split case"""
     g = torch.Generator().manual_seed(5)
-    for (M, N, K) in [(4, 70000, 256), (8, 16384, 512), (160, 4096, 4096)]:
+    for (M, N, K) in [(4, 70000, 256), (8, 16384, 512), (160, 4096, 4096), (2, 4096, 2560), (5, 2048, 10240 + 64)]:
         a = torch.randn(M, K, generator=g).bfloat16().cuda()
         b = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
