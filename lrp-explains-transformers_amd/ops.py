@@ -118,16 +118,18 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def span(self, flops):
+    def span(self, flops, tag="plain"):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((flops, e0, e1))
+        self.records.append((flops, e0, e1, tag))
         return e0, e1
 
-    def summary(self):
-        """-> (launches, total_flops, total_seconds) ; call after a device synchronise"""
-        tot_f = sum(r[0] for r in self.records)
-        tot_t = sum(r[1].elapsed_time(r[2]) for r in self.records) * 1e-3
-        return len(self.records), tot_f, tot_t
+    def summary(self, tag=None):
+        """-> (launches, total_flops, total_seconds) of the launches with this tag (None: all); call after a device synchronise.
+        Tags: "plain" = GEMM only; "gated_fwd" / "gated_bwd" = the launches that carry a gated-MLP rule in their epilogue"""
+        recs = [r for r in self.records if tag is None or r[3] == tag]
+        tot_f = sum(r[0] for r in recs)
+        tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
+        return len(recs), tot_f, tot_t
 
 
 GEMM_TIMER = None
@@ -362,7 +364,7 @@ def gemm_gated_fwd(x, Wgu, gu, m, act="silu"):
     I = m.shape[1]
     same(x, Wgu, gu, m)
     if GATED_FUSION and x.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(x, Wgu):
-        ev = GEMM_TIMER.span(2.0 * M * 2 * I * K) if GEMM_TIMER is not None else None
+        ev = GEMM_TIMER.span(2.0 * M * 2 * I * K, "gated_fwd") if GEMM_TIMER is not None else None
         if ev:
             ev[0].record()
         rc = lib.lrp_gemm_gated_fwd(p(x), p(Wgu), p(gu), p(m), M, I, K, x.stride(0), Wgu.stride(0), gu.stride(0), m.stride(0), ACT[act],
@@ -385,7 +387,7 @@ def gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act="silu"):
     if GATED_FUSION and Adn.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(Adn, Wd):
         need = lib.lrp_gemm_gated_bwd_ws(M, I, K, Adn.stride(0), Wd.stride(0), ACT[act], dt(Adn))
         ws = workspace(need, Adn) if need else None
-        ev = GEMM_TIMER.span(2.0 * M * I * K) if GEMM_TIMER is not None else None
+        ev = GEMM_TIMER.span(2.0 * M * I * K, "gated_bwd") if GEMM_TIMER is not None else None
         if ev:
             ev[0].record()
         rc = lib.lrp_gemm_gated_bwd(p(Adn), p(Wd), p(gu), p(Agu), M, I, K, Adn.stride(0), Wd.stride(0), gu.stride(0), Agu.stride(0),
