@@ -147,7 +147,7 @@ def bert_explicit_padded():
     from oracle import bert as ob
     from tests.golden import bert_explicit_compose as C
     from tests.golden.hf_models import build_bert
-    from tests.util import fp32_conditioning_bert
+    from tests.util import bert_oracle
     model = build_bert(seed=0, attn="eager")
     W64 = C.weights_from_hf(model, torch.float64)
     model = model.cuda()
@@ -171,8 +171,8 @@ def bert_explicit_padded():
     ok = ok and float(R[1, lens[1]:].abs().max()) == 0.0
     worst = 0.0
     for b, L in enumerate(lens):
-        o64 = ob.explain(W64, ids[b, :L], target=int(idx[b]), dtype=torch.float64)
-        cond = fp32_conditioning_bert(W64, ids[b, :L], int(idx[b]), o64["R_tok"], draws=3, rel=1e-7)
+        o64 = bert_oracle(W64, ids[b, :L], int(idx[b]), draws=3, rel=1e-7)          # fp64 oracle + 3 noise draws (cached fixture)
+        cond = o64["cond"]
         err = nmax(R[b, :L], o64["R_tok"])
         print(f"[bert-base explicit padded batch, row {b}, length {L}] token vs oracle fp64 {err:.2e} (instance fp32 conditioning {cond:.1e}) "
               f"logit {float(sel[b]):+.6f} vs oracle {o64['logit']:+.6f}")

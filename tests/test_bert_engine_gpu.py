@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from tests.golden.hf_models import build_bert, wsum
-from tests.util import nmax, load, t, fp32_conditioning_bert
+from tests.util import nmax, load, t, bert_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -49,13 +49,13 @@ def test_bert_engine_explicit_fp32_vs_reference_and_oracle(bert):
     r = eng.explain(ids[None].cuda(), layer_relevance=True)
     assert int(r["idx"][0]) == int(fx["idx"]) and abs(float(r["logit"][0]) - float(fx["logit"])) < 1e-4
     W64 = C.weights_from_hf(bert, torch.float64)
-    o64 = ob.explain(W64, ids, target=int(fx["idx"]), dtype=torch.float64)
-    cond = fp32_conditioning_bert(W64, ids, int(fx["idx"]), o64["R_tok"], draws=3, rel=1e-7)
+    o64 = bert_oracle(W64, ids, int(fx["idx"]), draws=3, rel=1e-7, wsum_=wsum(bert))      # fp64 oracle + 3 noise draws (cached fixture)
+    cond = o64["cond"]
     bar = max(1e-4, 5 * cond)           # the rule of the Llama explicit tests (tests/test_baseline_size_gpu.py): heavy-tailed
     # the engine propagates a UNIT gradient on the logit; the explicit protocol seeds with the logit's value
     R = r["R_tok"][0].double().cpu()
     e1, e2 = nmax(R, fx["R_tok_fp64"]), nmax(R, o64["R_tok"])
-    eL = nmax(r["layer_R"][0], torch.tensor(o64["layer_R"]))
+    eL = nmax(r["layer_R"][0], torch.as_tensor(o64["layer_R"]))
     print(f"[BertLRP explicit fp32] token vs reference fp64 {e1:.2e} | vs oracle fp64 {e2:.2e} | per-layer latent relevance {eL:.2e} "
           f"(instance fp32 conditioning {cond:.1e}; reference's own fp32 gap {float(fx['cond_gap']):.1e})")
     assert e1 < bar and e2 < bar and eL < bar
@@ -153,16 +153,10 @@ def test_bert_engine_ragged_lengths_vs_oracle(bert, B, S):
     for mode in ("efficient", "explicit"):
         eng = BertLRP.from_hf(bert, dtype=torch.float32, mode=mode)
         r = eng.explain(ids.cuda())
-        saved = dict(ob.EPS)
-        try:
-            if mode == "efficient":
-                for k in ob.EPS:
-                    ob.EPS[k] = 0.0
-            for b in range(B if mode == "efficient" else 1):
-                o64 = ob.explain(W64, ids[b], target=int(r["idx"][b]), dtype=torch.float64)
-                e = nmax(r["R_tok"][b], o64["R_tok"])
-                bar = 1e-4 if mode == "efficient" else max(1e-4, 5 * fp32_conditioning_bert(W64, ids[b], int(r["idx"][b]), o64["R_tok"], draws=2, rel=1e-7))
-                print(f"[BertLRP {mode} B={B} S={S} prompt {b}] token vs oracle fp64 {e:.2e} (bar {bar:.1e})")
-                assert abs(float(r["logit"][b]) - o64["logit"]) < 1e-4 and e < bar
-        finally:
-            ob.EPS.update(saved)
+        for b in range(B if mode == "efficient" else 1):
+            o64 = bert_oracle(W64, ids[b], int(r["idx"][b]), eps_zero=(mode == "efficient"), draws=0 if mode == "efficient" else 2, rel=1e-7,
+                              wsum_=wsum(bert))
+            e = nmax(r["R_tok"][b], o64["R_tok"])
+            bar = 1e-4 if mode == "efficient" else max(1e-4, 5 * o64["cond"])
+            print(f"[BertLRP {mode} B={B} S={S} prompt {b}] token vs oracle fp64 {e:.2e} (bar {bar:.1e}{', cached oracle' if o64['cached'] else ''})")
+            assert abs(float(r["logit"][b]) - o64["logit"]) < 1e-4 and e < bar

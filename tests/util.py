@@ -78,3 +78,46 @@ def fp32_conditioning_bert(W64, ids, target, ref64=None, draws=3, rel=3e-7):
             return x + rel * scale * torch.randn(x.shape, generator=g, dtype=x.dtype)
         worst = max(worst, nmax(ob.explain(W64, ids, target=target, dtype=torch.float64, rnd=rnd)["R_tok"], ref64))
     return worst
+
+
+# ---- cached fp64 BERT oracle ----------------------------------------------------------------------------------------------------------
+# The explicit BERT tests compare against oracle/bert.py in fp64 plus 2-3 noise draws of it (fp32_conditioning_bert): ~10 BERT-base
+# passes in fp64 on the host per test, 30 s on an idle 128-thread host and 6 minutes on a busy one (measured: the round-3 suite went
+# from 229 s to 1257 s on one box).  The results only depend on (seeded weights, ids, target, stabilisers), so they are computed once
+# here in the build container by tests/golden/make_golden_bert_oracle_cache.py (the oracle alone, no reference needed) and committed;
+# a miss (changed case) falls back to the live computation.
+_BERT_CACHE = None
+
+
+def _bert_key(ids, target, eps_zero, draws, rel):
+    import hashlib
+    h = hashlib.sha1(np.ascontiguousarray(ids.cpu().numpy().astype(np.int64)).tobytes()).hexdigest()[:16]
+    return f"{h}_{int(target)}_{int(bool(eps_zero))}_{int(draws)}_{rel:g}"
+
+
+def bert_oracle(W64, ids, target, eps_zero=False, draws=0, rel=1e-7, wsum_=None, compute=True):
+    """-> dict(R_tok [S] f64, logit, layer_R, cond (0.0 when draws == 0)) of oracle/bert.py in fp64; eps_zero: every stabiliser 0 (the
+    efficient placement).  Served from tests/golden/bert_oracle_cache.npz when the case is there."""
+    global _BERT_CACHE
+    import os
+    from oracle import bert as ob
+    key = _bert_key(ids, target, eps_zero, draws, rel)
+    if _BERT_CACHE is None:
+        path = os.path.join(os.path.dirname(__file__), "golden", "bert_oracle_cache.npz")
+        _BERT_CACHE = dict(np.load(path)) if os.path.exists(path) else {}
+    c = _BERT_CACHE
+    if key + "/R_tok" in c and (wsum_ is None or abs(float(c["wsum"]) - wsum_) < 1e-6 * wsum_):
+        return dict(R_tok=torch.as_tensor(c[key + "/R_tok"]), logit=float(c[key + "/logit"]), layer_R=torch.as_tensor(c[key + "/layer_R"]),
+                    cond=float(c[key + "/cond"]), cached=True)
+    if not compute:
+        return None
+    saved = dict(ob.EPS)
+    try:
+        if eps_zero:
+            for k in ob.EPS:
+                ob.EPS[k] = 0.0
+        o64 = ob.explain(W64, ids, target=int(target), dtype=torch.float64)
+        cond = fp32_conditioning_bert(W64, ids, int(target), o64["R_tok"], draws=draws, rel=rel) if draws else 0.0
+    finally:
+        ob.EPS.update(saved)
+    return dict(R_tok=o64["R_tok"], logit=o64["logit"], layer_R=torch.as_tensor(o64["layer_R"]), cond=cond, cached=False)
