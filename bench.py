@@ -8,11 +8,12 @@ torch.distributed.run with one rank per GPU.  A "step" = every rank explains `--
 
   value        whole-job explanations/s = N * batch * K / max-over-ranks(time of K steps); inputs
                (ids, weights) are resident in HBM before the timed region.
-  roofline     dominant kernel = the NT GEMM behind lrp_gemm_nt (gemm_nt_pp_kernel<bf16>, the 8-wave ping-pong kernel, for the
-               256x256-tile shapes, gemm_nt_glds_kernel 128x128 for the small ones; 94 % of the algorithmic FLOPs): achieved
-               = sum over its launches of 2*M*N*K divided by the sum of their durations, both taken
-               live with HIP events on the launching stream inside the timed region; peak = 2500
-               TFLOP/s (dense bf16 MFMA, MI355X_MICROARCH.md).
+  roofline     dominant kernel = the plain instantiations of the 8-wave ping-pong GEMM (gemm_pp_kernel<bf16, NT | NN, EPI 0>: Linear
+               forward z = x W^T and eps-rule dgrad c = s W from the stored weight; 6 of the 8 GEMM launches per layer): achieved
+               = sum over its launches of 2*M*N*K divided by the sum of their durations, both taken live with HIP events on the
+               launching stream inside the timed region; peak = 2500 TFLOP/s (dense bf16 MFMA, MI355X_MICROARCH.md).  The two
+               launches per layer that carry a gated-MLP rule in their epilogue are other instantiations (separate rows in the
+               rocprofv3 summary) and are listed under roofline.with_fused_epilogue_launches.
   cpu_baseline the oracle (CPU port of the same op sequence, oracle/llama.py) timed on this box's
                host cores on a bounded sample (one decoder layer + head, fp32, extrapolated x32);
                rank 0, N=1 only.
@@ -244,8 +245,8 @@ def main():
     torch.cuda.empty_cache()
     if world > 1:
         # weights are generated from the same seed on every rank; the broadcast from rank 0 makes the replica identity explicit
-        # (C1 of SURVEY.md 8e): ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB), the W^T
-        # copies of the dgrad GEMMs are rebuilt locally -- outside the timed region
+        # (C1 of SURVEY.md 8e): ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB) -- outside the timed
+        # region; the dgrad GEMMs read the stored weights, so nothing is rebuilt (build_transposes only drops cached fp32 transposes)
         D.broadcast_weights([eng.flat], src=0)
         eng.build_transposes()
 

@@ -4,8 +4,9 @@ The path shards embarrassingly: every prompt's explanation is ind
 is NO collective on the data path.  RCCL (torch.distributed backend "nccl" on ROCm) over xGMI is used
 for exactly two things, neither per layer:
   * broadcast_weights : rank 0's weights -> every rank, once at start-up: the engine keeps every weight in ONE flat buffer
-                        (LlamaLRP.flat, forward layouts only), so this is a single collective; the W^T copies of the dgrad
-                        GEMMs are rebuilt locally (LlamaLRP.build_transposes);
+                        (LlamaLRP.flat, forward layouts only), so this is a single collective; nothing is rebuilt afterwards
+                        (the dgrad GEMMs read the stored weights: no W^T copies; LlamaLRP.build_transposes only drops the
+                        fp32 parity engine's lazily cached transposes);
   * gather_relevance  : all-gather of the [n_local, S] fp32 token relevances at the end of a job.
 Correctness contract: the rank-sharded relevance of prompt p equals the single-GPU relevance of p bit
 for bit (same kernels, same order) -- tests/test_dist_cpu.py checks the partition/gather logic with the

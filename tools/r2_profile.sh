@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     cur=sqlite3.connect(db).cursor()
     rows=cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
     for k,cn,v,n in rows:
-        if "gemm_nt_swp" in k or "attn32" in k or "smallm" in k:
+        if "gemm_nt_swp" in k or "gemm_pp" in k or "attn32" in k or "smallm" in k:
             res.setdefault(k[:60],{})[cn]=(v,n)
 for k,v in res.items(): print(k, {a:(f"{b[0]/b[1]:.4e} per launch", b[1]) for a,b in v.items()})
 json.dump({k:{a:{"sum":b[0],"launches":b[1]} for a,b in v.items()} for k,v in res.items()}, open(O+"/pmc_summary.json","w"), indent=1)
