@@ -314,7 +314,7 @@ def main():
             flops_all, secs_all, n_all = 0.0, float("nan"), 0
         achieved = flops / secs / 1e12
         fused = {}
-        for tag in ("gated_fwd", "gated_bwd"):
+        for tag in ("gated_fwd", "gated_bwd", "splitk"):
             n_t, f_t, s_t = timer.summary(tag)
             if n_t and s_t > 0.0:
                 fused[tag] = {"launches": n_t, "avg_launch_us": s_t / n_t * 1e6, "gemm_TFLOPs_incl_rule": f_t / s_t / 1e12}

@@ -427,12 +427,13 @@ bool pp_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn) {
     return (K % 64) == 0 && K >= 128 && (int64_t)M * lda < (1ll << 30) && brows * ldb < (1ll << 30);
 }
 
-// split policy of the skinny path: ONE round of workgroups (one workgroup per CU: 128 KiB of LDS each) that covers as many of the 256 CUs
+// split policy of the split-K path: ONE round of workgroups (one workgroup per CU: 128 KiB of LDS each) that covers as many of the 256 CUs
 // as the tile count allows -- a second, partial round would double the time of a kernel that only streams the weight --, at least 2 K
-// tiles per split
-int skinny_splits(int N, int K) {
-    const int tiles_n = (N + 255) / 256, nkt = K / 64;
-    int s_ = 256 / tiles_n;
+// tiles per split.  M <= 256 rows: one row of tiles (the HBM-bound regime of the Linear eps-rule).  More rows (round 3: M = 2048, one
+// prompt per step): problems of <= 128 tiles, which would leave half of the chip idle, are split over K the same way.
+int skinny_splits(int M, int N, int K) {
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nkt = K / 64;
+    int s_ = 256 / tiles;
     if (s_ > nkt / 2) s_ = nkt / 2;
     return s_ < 1 ? 1 : s_;
 }
@@ -452,18 +453,18 @@ extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* b
 extern "C" int64_t lrp_gemm_skinny_ws(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K < 128) return 0;
     const int64_t ldw = (N + 3) / 4 * 4;
-    return (int64_t)skinny_splits(N, K) * M * ldw * 4;
+    return (int64_t)skinny_splits(M, N, K) * M * ldw * 4;
 }
 
 extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                                int64_t ldc, int nn, int dtype, int out_dtype, void* ws, void* stream) {
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0) return LRP_EINVAL;
-    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32) || M > 256) return LRP_ESHAPE;
+    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
         (reinterpret_cast<uintptr_t>(ws) & 15)) return LRP_EALIGN;
     if (!pp_ok(M, N, K, lda, ldb, nn)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int splits = skinny_splits(N, K), nkt = K / 64;
+    const int splits = skinny_splits(M, N, K), nkt = K / 64;
     int per = (nkt + splits - 1) / splits;
     int used = (nkt + per - 1) / per;
     while (used > 1 && nkt - (used - 1) * per < 2) {                         // the kernel needs >= 2 K tiles in every split, the last one too

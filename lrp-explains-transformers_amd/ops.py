@@ -179,6 +179,17 @@ def gemm_nn_2d(a, w, out, bias=None):
 
 
 SKINNY_MAX = 256         # rows the split-K skinny path serves (HBM-bound regime of the Linear eps-rule: M <~ 160 in bf16)
+
+
+def splitk_ok(M, N, K):
+    """should this bf16 GEMM take the split-K path of the ping-pong kernel (lrp_gemm_skinny)?  M <= 256 rows always (W is streamed once by
+    all CUs); for more rows when the 256 x 256 tile count would leave half of the 256 CUs idle (M = 2048 against a 4096-row weight:
+    128 tiles) and every split keeps a K loop of >= 8 tiles -- measured at M = 2048 (tools/gemm_ab.py --m 2048): 978 -> 1150 ... 1039 ->
+    1440 TFLOP/s on the N = 4096 shapes"""
+    if M <= SKINNY_MAX:
+        return True
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return tiles <= 128 and K // 64 >= 8 * (256 // tiles)
 _WS = {}
 
 
@@ -203,8 +214,14 @@ def gemm_skinny(a, b, out, nn=False, bias=None):
     N = b.shape[1] if nn else b.shape[0]
     same(a, b)
     ws = workspace(lib.lrp_gemm_skinny_ws(M, N, K), a)
-    check(lib.lrp_gemm_skinny(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(aux(bias, a, N)), M, N, K, a.stride(0), b.stride(0),
-                              out.stride(0), int(nn), dt(a), _DT[out.dtype], ws.data_ptr(), stream()), "lrp_gemm_skinny")
+    ev = GEMM_TIMER.span(2.0 * M * N * K, "splitk") if (GEMM_TIMER is not None and M > SKINNY_MAX) else None
+    if ev:
+        ev[0].record()
+    rc = lib.lrp_gemm_skinny(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(aux(bias, a, N)), M, N, K, a.stride(0), b.stride(0),
+                             out.stride(0), int(nn), dt(a), _DT[out.dtype], ws.data_ptr(), stream())
+    if ev:
+        ev[1].record()
+    check(rc, "lrp_gemm_skinny")
     return out
 
 
@@ -578,7 +595,7 @@ def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
     M, K = x2.shape
     N = W.shape[0]
     odt = out_dtype or (out.dtype if out is not None else x2.dtype)
-    if M <= SKINNY_MAX and gemm_nn_ok(x2, W):
+    if splitk_ok(M, N, K) and gemm_nn_ok(x2, W):
         if out is None:
             out = torch.empty(M, N, device=x2.device, dtype=odt)
         return gemm_skinny(x2, W, out, nn=False, bias=bias)
@@ -609,7 +626,7 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     if nn:
         if out is None:
             out = torch.empty(M, K, device=s2.device, dtype=odt)
-        return gemm_skinny(s2, W, out, nn=True) if M <= SKINNY_MAX else gemm_nn_2d(s2, W, out)
+        return gemm_skinny(s2, W, out, nn=True) if splitk_ok(M, K, N) else gemm_nn_2d(s2, W, out)
     wt = weight_t(W)
     if out is not None and s2.stride(1) == 1 and s2.dtype == wt.dtype and s2.stride(0) % epc(s2) == 0:
         return gemm_nt_2d(s2, wt, out)

@@ -115,12 +115,18 @@ def test_gemm_skinny_split_k(ops, M, nn):
 def test_gemm_skinny_single_split_and_big_n(ops):
     """tile counts that fill the chip alone (one split: the plain kernel writes the output, no slabs) and the many-tile split case"""
     g = torch.Generator().manual_seed(5)
-    for (M, N, K) in [(4, 70000, 256), (8, 16384, 512), (160, 4096, 4096), (2, 4096, 2560), (5, 2048, 10240 + 64)]:
+    for (M, N, K) in [(4, 70000, 256), (8, 16384, 512), (160, 4096, 4096), (2, 4096, 2560), (5, 2048, 10240 + 64), (2048, 4096, 4096), (1000, 2048, 6144)]:
         a = torch.randn(M, K, generator=g).bfloat16().cuda()
         b = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
         ops.gemm_skinny(a, b, out)
         assert not torch.isnan(out).any() and nmax(out, f64(a) @ f64(b).T) < 2e-5
+    # more than one row of tiles (M = 2048: the one-prompt-per-step GEMMs against 4096-row weights), both operand forms, through the dispatchers
+    a = torch.randn(2048, 4096, generator=g).bfloat16().cuda()
+    w = (torch.randn(4096, 4096, generator=g) * 4096 ** -0.5).bfloat16().cuda()
+    assert ops.splitk_ok(2048, 4096, 4096) and not ops.splitk_ok(8192, 4096, 4096) and not ops.splitk_ok(2048, 6144, 4096)
+    assert nmax(ops.linear_fwd(a, w), f64(a) @ f64(w).T) < TOL[torch.bfloat16]
+    assert nmax(ops.linear_dgrad(a, w), f64(a) @ f64(w)) < TOL[torch.bfloat16]
 
 
 def _act64(x, act):
