@@ -42,8 +42,10 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 2 (lrp_attn_fwd takes v and v_t); additions that do not break callers
-                                          -- lrp_linear_smallm_*, lrp_add_bcast, LRP_ACT_TANH -- keep the number */
+int lrp_version(void);                 /* ABI version, currently 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+                                          lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
+                                          added lrp_gemm_nn, lrp_gemm_skinny[_ws], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
+                                          Every other version-2 signature is unchanged. */
 const char* lrp_build_arch(void);      /* "gfx950" */
 int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
 
