@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
+    ap.add_argument("--no-smallm", action="store_true", help="skip the small-M Linear tables that follow the headline region (profiling: their "
+                    "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (LlamaLRP.explain(graph=True)); pays at small batch")
     ap.add_argument("--dry-run", action="store_true",
@@ -338,7 +340,8 @@ def main():
                          "with_fused_epilogue_launches": {"launches": n_all, "TFLOPs": flops_all / secs_all / 1e12,
                                                           "frac": flops_all / secs_all / 1e12 / peak, **fused}},
         }
-        line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
+        if not args.no_smallm:
+            line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
         if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16:
             line["config5_seq4096"] = config5_probe(eng, ops, cfg, dev, peak)
         if world == 1 and not args.no_cpu_baseline:
