@@ -219,3 +219,47 @@ def test_explicit_bert_registers_a_mask_function():
         assert torch.allclose(ref, got, atol=1e-6)
     finally:
         xb.register_interfaces()           # restore the real attention function under the name
+
+
+def test_host_dispatch_rules_round3():
+    """host-side logic added in round 3, none of which launches a kernel: the row-pitch padding rule, the split-K dispatch predicate,
+    padded arena buffers, the gate/up interleave map, and the Gemma-3 config reader's refusals"""
+    import lxt_amd.engine as E
+    import lxt_amd.ops as O
+    # pitch: 128 bytes of padding exactly for the long-K operands whose pitch is a multiple of 4 KiB
+    assert E.pitch_pad(14336, 2) == 64 and E.pitch_pad(28672, 2) == 64 and E.pitch_pad(14336, 4) == 32
+    assert E.pitch_pad(4096, 2) == 0 and E.pitch_pad(6144, 2) == 0 and E.pitch_pad(10240 + 64, 2) == 0 and E.pitch_pad(10240, 2) == 64
+    # split-K: always for M <= 256 rows; for more rows only when <= 128 tiles of 256 x 256 and a K loop of >= 8 tiles per split remains
+    assert O.splitk_ok(1, 128256, 4096) and O.splitk_ok(256, 4096, 128)
+    assert O.splitk_ok(2048, 4096, 4096) and O.splitk_ok(2048, 4096, 28672) and O.splitk_ok(512, 4096, 4096)
+    assert not O.splitk_ok(2048, 6144, 4096) and not O.splitk_ok(8192, 4096, 4096) and not O.splitk_ok(2048, 4096, 512)
+    # arena: a padded 2-D buffer is a [rows, cols] view with the padded pitch; the same tag is reused, a larger request grows it
+    ar = E.LlamaLRP._Arena(torch.device("cpu"))
+    a = ar.get("m", (8, 14336), torch.bfloat16, pad=64)
+    assert a.shape == (8, 14336) and a.stride(0) == 14400 and ar.get("m", (8, 14336), torch.bfloat16, pad=64).data_ptr() == a.data_ptr()
+    z = ar.get("m", (4, 14336), torch.bfloat16, zero=True, pad=64)
+    assert z.data_ptr() == a.data_ptr() and float(z.abs().sum()) == 0.0
+    assert ar.get("m", (16, 14336), torch.bfloat16, pad=64).data_ptr() != a.data_ptr()
+    assert ar.get("x", (3, 5), torch.float32).is_contiguous()
+    # gate/up interleave: blocks of 64 rows = [32 gate | 32 up]
+    wg, wu = torch.arange(64.).view(64, 1).repeat(1, 2), -torch.arange(64.).view(64, 1).repeat(1, 2)
+    il = O.interleave_gate_up(wg, wu)
+    assert torch.equal(il[:32], wg[:32]) and torch.equal(il[32:64], wu[:32]) and torch.equal(il[64:96], wg[32:]) and torch.equal(il[96:], wu[32:])
+    with pytest.raises(ValueError):
+        O.interleave_gate_up(torch.zeros(48, 2), torch.zeros(48, 2))
+    # Gemma-3 config reader: the supported text config is read, unsupported features are refused loudly
+    import lxt_amd.engine_gemma3 as G
+    from transformers import Gemma3TextConfig, LlamaConfig
+    ok = Gemma3TextConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                          head_dim=16, sliding_window=8, layer_types=["sliding_attention", "full_attention"], query_pre_attn_scalar=16)
+    c = G.config_from_hf(ok)
+    assert c["act"] == "gelu_tanh" and c["window"] == 8 and abs(c["scale"] - 0.25) < 1e-12 and set(c["rope"]) == {"sliding_attention", "full_attention"}
+    assert c["rope"]["full_attention"][0].shape == (8,) and abs(c["embed_scale"] - 32 ** 0.5) < 1e-12
+    bad = Gemma3TextConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                           head_dim=16, layer_types=["full_attention"], final_logit_softcapping=30.0)
+    with pytest.raises(NotImplementedError):
+        G.config_from_hf(bad)
+    with pytest.raises(NotImplementedError):
+        G.config_from_hf(LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2))
+    with pytest.raises(RuntimeError):
+        G.Gemma3LRP(c, {})
