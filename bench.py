@@ -164,6 +164,45 @@ def config5_probe(eng, ops, cfg, dev, peak, steps=3):
             "gemm_TFLOPs": flops / secs / 1e12, "gemm_frac_of_peak": flops / secs / 1e12 / peak, "gemm_time_frac_of_step": secs / el}
 
 
+def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048):
+    """BASELINE config 4's text tower through the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP), AFTER and OUTSIDE the headline
+    timed region: Gemma-3-4B shape (34 layers, H 2560, 8 / 4 heads of d = 256, I 10240, sliding window 1024 on 5 of 6 layers, tied
+    262208-token head), random init on the device, seq = 2048, 4 prompts per step."""
+    from lxt_amd.engine_gemma3 import Gemma3LRP
+    L, H, I, nq, nk, d, V = 34, 2560, 10240, 8, 4, 256, 262208
+    g = torch.Generator(device=dev).manual_seed(7)
+    rn = lambda sd, *s: (torch.randn(*s, generator=g, device=dev) * sd).to(dtype)  # noqa: E731
+    inv = lambda theta, f: 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d)) / f  # noqa: E731
+    cfg = dict(hidden=H, inter=I, n_layers=L, n_heads=nq, n_kv=nk, head_dim=d, vocab=V, rms_eps=1e-6, act="gelu_tanh", scale=256 ** -0.5,
+               layer_types=[("full_attention" if (i + 1) % 6 == 0 else "sliding_attention") for i in range(L)], window=1024,
+               rope={"sliding_attention": (inv(1e4, 1.0), 1.0), "full_attention": (inv(1e6, 8.0), 1.0)}, embed_scale=H ** 0.5)
+    emb = rn(0.02, V, H)
+    W = dict(embed=emb, lm_head=emb, norm=rn(0.1, H), layers=[
+        dict(ln_in=rn(0.1, H), ln_pa=rn(0.1, H), ln_pf=rn(0.1, H), ln_pff=rn(0.1, H), qn=rn(0.1, d), kn=rn(0.1, d), wq=rn(0.02, nq * d, H),
+             wk=rn(0.02, nk * d, H), wv=rn(0.02, nk * d, H), wo=rn(0.02, H, nq * d), wg=rn(0.02, I, H), wu=rn(0.02, I, H), wd=rn(0.02, H, I))
+        for _ in range(L)])
+    eng = Gemma3LRP(cfg, W, dtype=dtype, device=dev, max_seq=S4)
+    del W, emb
+    ids = torch.randint(0, V, (B4 * (steps + 1), S4), generator=torch.Generator().manual_seed(99)).to(dev)
+    R = eng.explain(ids[:B4])["R_tok"]
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(steps):
+        R = eng.explain(ids[(i + 1) * B4: (i + 2) * B4])["R_tok"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    n_launch, flops, secs = timer.summary()
+    assert torch.isfinite(R).all()
+    eng.release()
+    return {"workload": f"Gemma-3-4B text tower shape, lxt.efficient rule placement, seq={S4}, {B4} prompts per step, {steps} steps after the "
+                        "headline region (fused driver engine_gemma3.Gemma3LRP)",
+            "value": B4 * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3,
+            "gemm_TFLOPs": flops / secs / 1e12, "gemm_frac_of_peak": flops / secs / 1e12 / peak, "gemm_time_frac_of_step": secs / el}
+
+
 def dry_run(args):
     """the N-rank control flow of main() with the explanation replaced by a pure function of the ids (no engine, no device):
     what torch.distributed.run + this script must get right before any kernel matters"""
@@ -218,6 +257,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
+    ap.add_argument("--no-config4", action="store_true", help="skip the Gemma-3-4B text-tower probe that follows the headline region")
     ap.add_argument("--no-smallm", action="store_true", help="skip the small-M Linear tables that follow the headline region (profiling: their "
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
@@ -344,6 +384,8 @@ def main():
             line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
         if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16:
             line["config5_seq4096"] = config5_probe(eng, ops, cfg, dev, peak)
+        if not args.no_config4 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
+            line["config4_gemma3_4b_text"] = config4_probe(ops, dev, dtype, peak)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)

@@ -8,7 +8,7 @@ O=gpurun_out/r3ab_$V
 mkdir -p $O
 export PYTHONUNBUFFERED=1
 for r in 1 2; do for f in 1 0; do
-env $V=$f timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5 > $O/bench_${f}_r$r.json 2> $O/bench_${f}_r$r.err
+env $V=$f timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5 --no-config4 > $O/bench_${f}_r$r.json 2> $O/bench_${f}_r$r.err
 python - <<PY
 import json
 d=json.load(open("$O/bench_${f}_r$r.json")); r=d["roofline"]

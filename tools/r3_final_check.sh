@@ -6,7 +6,7 @@ mkdir -p $O
 export PYTHONUNBUFFERED=1
 ( time timeout 900 python -m pytest tests/test_bert_engine_gpu.py tests/test_hf_gpu.py -q -x -k "bert" --durations=8 ) > $O/pytest_bert.txt 2>&1; tail -16 $O/pytest_bert.txt
 for extra in "--mode explicit" "--batch 1" "--batch 1 --graph"; do
-  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5 $extra > $O/bench_x.json 2> $O/bench_x.err
+  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5 --no-config4 $extra > $O/bench_x.json 2> $O/bench_x.err
   python - "$extra" <<PY
 import json, sys
 d=json.load(open("$O/bench_x.json")); r=d["roofline"]

@@ -7,13 +7,13 @@ O=$GRAFT_REPO_ROOT/gpurun_out/r3prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for f in 1 0; do
-  LXT_AMD_GATED_FUSION=$f rocprofv3 --kernel-trace --stats -d $O/kt$f -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 --no-smallm > $O/bench_under_rocprof_f$f.json 2> $O/kt$f.log
+  LXT_AMD_GATED_FUSION=$f rocprofv3 --kernel-trace --stats -d $O/kt$f -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 --no-config4 --no-smallm > $O/bench_under_rocprof_f$f.json 2> $O/kt$f.log
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find $O/kt$f -name "*.db" | head -1) > $O/kernel_stats_f$f.txt 2>&1
   head -30 $O/kernel_stats_f$f.txt | cut -c1-220
 done
 if [ "$1" != "nopmc" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --layers 4 --no-cpu-baseline --no-config5 --no-smallm > $O/pmc_$c.json 2> $O/pmc_$c.log
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --layers 4 --no-cpu-baseline --no-config5 --no-config4 --no-smallm > $O/pmc_$c.json 2> $O/pmc_$c.log
 done
 python - <<'PY'
 import sqlite3, glob, os, json
