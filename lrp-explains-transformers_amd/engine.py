@@ -342,6 +342,7 @@ class LlamaLRP:
             Gs = zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, last, Gs_last)
             Adn = zeros(("Adn", len(self.layers) & 1), M, H).index_copy_(0, last, A_last)
         layer_R = [rel_last] if layer_relevance else None
+        plain_add = E["add"] == 0.0 and E["lin"] == 0.0          # efficient placement: add2 / Linear eps factors are exactly 1
 
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
@@ -371,8 +372,13 @@ class LlamaLRP:
                 # ---- MLP
                 Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
                 Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
-                Gs1, Aa = new("Gs1", M, H), new("Aa", M, H)
-                ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
+                Gs1 = new("Gs1", M, H)
+                if plain_add:         # no stabiliser on the add / the branch's Linear: the branch gradient IS the residual gradient
+                    ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], None, None, Gs1, None, None, 0.0, 0.0, 0.0)
+                    Aa = Gs1
+                else:
+                    Aa = new("Aa", M, H)
+                    ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
                 # ---- attention
                 Gof = self._lin_bwd(Aa, Lw["wo"], new("Gof", M, nq * d))
                 Gho = new("Gho", M, nq * d)
@@ -404,8 +410,13 @@ class LlamaLRP:
             rel = f32(("rel", li), M) if layer_relevance else None
             if li > 0:
                 prev = fw["stash"][li - 1]
-                Gs, Adn = new(("Gs", li & 1), M, H), new(("Adn", li & 1), M, H)
-                ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"], prev["dn"], Gs, Adn, rel, 0.0, E["add"], E["lin"])
+                Gs = new(("Gs", li & 1), M, H)
+                if plain_add:
+                    ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"] if layer_relevance else None, None, Gs, None, rel, 0.0, 0.0, 0.0)
+                    Adn = Gs
+                else:
+                    Adn = new(("Adn", li & 1), M, H)
+                    ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"], prev["dn"], Gs, Adn, rel, 0.0, E["add"], E["lin"])
             else:
                 Gs = new(("Gs", 0), M, H)
                 ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln1"], st["rstd1"], st["h"] if layer_relevance else None, None, Gs, None,
