@@ -76,10 +76,12 @@ int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M,
  * intensity ~2 M FLOP/B in bf16): split-K over the K tiles so that every CU streams its share of the weight exactly once, fp32 partial
  * slabs in `ws` (lrp_gemm_skinny_ws(M,N,K) BYTES, caller-allocated), reduced (+ bias, cast) by a second small kernel; when the tile
  * count alone fills the chip (the LM head) there is one split and the kernel writes C directly.  Larger M is accepted too: with <= 128
- * tiles (M = 2048 rows against a 4096-row weight) the K range is split 2 ... 8 ways so that every CU has a workgroup.
+ * tiles (M = 2048 rows against a 4096-row weight) the K range is split 2 ... 8 ways so that every CU has a workgroup, and with 257 ... 384
+ * tiles and K >= 8192 (8192 x 2560: 1.25 rounds of the chip) two ways.
  *   nn = 0: C = A[M,K] . B[N,K]^T (forward z = x W^T);   nn = 1: C = A[M,K] . B[K,N] (redistribution c = s W, W as stored).
  * Same operand restrictions as lrp_gemm_nn.  ref: lxt/explicit/functional.py:351 (forward), :355-364 (backward). */
 int64_t lrp_gemm_skinny_ws(int M, int N, int K);
+int lrp_gemm_skinny_splits(int M, int N, int K);      /* K splits lrp_gemm_skinny would use (1: the plain GEMM serves the problem as well) */
 int lrp_gemm_skinny(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                     int64_t ldc, int nn, int dtype, int out_dtype, void* ws, void* stream);
 

@@ -433,6 +433,9 @@ bool pp_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn) {
 // prompt per step): problems of <= 128 tiles, which would leave half of the chip idle, are split over K the same way.
 int skinny_splits(int M, int N, int K) {
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nkt = K / 64;
+    // 1 ... 1.5 rounds of the 256 CUs (Gemma-3-4B: 8192 x 2560 = 320 tiles): the second round would run on a quarter of the chip for a
+    // full tile time; with the K range halved it is 2.5 half-length rounds.  Pays once a tile's K loop outweighs the slab round trip.
+    if (tiles > 256 && tiles <= 384 && nkt >= 128) return 2;
     int s_ = 256 / tiles;
     if (s_ > nkt / 2) s_ = nkt / 2;
     return s_ < 1 ? 1 : s_;
@@ -448,6 +451,11 @@ extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* b
     if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Bt) & 15)) return LRP_EALIGN;
     if (!pp_ok(M, N, K, lda, ldb, 1)) return LRP_ESHAPE;
     return lrp_launch_gemm_pp(A, Bt, C, bias, M, N, K, lda, ldb, ldc, out_dtype, 1, 1, K / 64, 0, (hipStream_t)stream);
+}
+
+extern "C" int lrp_gemm_skinny_splits(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 128) return 1;
+    return skinny_splits(M, N, K);
 }
 
 extern "C" int64_t lrp_gemm_skinny_ws(int M, int N, int K) {

@@ -189,7 +189,11 @@ def splitk_ok(M, N, K):
     if M <= SKINNY_MAX:
         return True
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    return tiles <= 128 and K // 64 >= 8 * (256 // tiles)
+    if tiles <= 128:
+        return K // 64 >= 8 * (256 // tiles)
+    return lib.lrp_gemm_skinny_splits(M, N, K) >= 2         # 257 ... 384 tiles with a long K loop (Gemma-3-4B: 8192 x 2560 x 10240)
+
+
 _WS = {}
 
 

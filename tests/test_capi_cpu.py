@@ -233,6 +233,8 @@ def test_host_dispatch_rules_round3():
     assert O.splitk_ok(1, 128256, 4096) and O.splitk_ok(256, 4096, 128)
     assert O.splitk_ok(2048, 4096, 4096) and O.splitk_ok(2048, 4096, 28672) and O.splitk_ok(512, 4096, 4096)
     assert not O.splitk_ok(2048, 6144, 4096) and not O.splitk_ok(8192, 4096, 4096) and not O.splitk_ok(2048, 4096, 512)
+    # 1 ... 1.5 rounds of the chip with a long K loop (Gemma-3-4B down projection): two K splits; not with a short one, not at 2 rounds
+    assert O.splitk_ok(8192, 2560, 10240) and not O.splitk_ok(8192, 2560, 4096) and not O.splitk_ok(8192, 4096, 14336)
     # arena: a padded 2-D buffer is a [rows, cols] view with the padded pitch; the same tag is reused, a larger request grows it
     ar = E.LlamaLRP._Arena(torch.device("cpu"))
     a = ar.get("m", (8, 14336), torch.bfloat16, pad=64)

@@ -127,6 +127,10 @@ def test_gemm_skinny_single_split_and_big_n(ops):
     assert ops.splitk_ok(2048, 4096, 4096) and not ops.splitk_ok(8192, 4096, 4096) and not ops.splitk_ok(2048, 6144, 4096)
     assert nmax(ops.linear_fwd(a, w), f64(a) @ f64(w).T) < TOL[torch.bfloat16]
     assert nmax(ops.linear_dgrad(a, w), f64(a) @ f64(w)) < TOL[torch.bfloat16]
+    # 320 tiles (1.25 rounds of the chip) with a long K loop: two K splits
+    a = torch.randn(8192, 8192, generator=g).bfloat16().cuda()
+    w = (torch.randn(2560, 8192, generator=g) * 8192 ** -0.5).bfloat16().cuda()
+    assert ops.splitk_ok(8192, 2560, 8192) and nmax(ops.linear_fwd(a, w)[:512], f64(a[:512]) @ f64(w).T) < TOL[torch.bfloat16]
 
 
 def _act64(x, act):
