@@ -44,7 +44,7 @@ extern "C" {
 /* library identity / sanity */
 int lrp_version(void);                 /* ABI version, currently 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
-                                          added lrp_gemm_nn, lrp_gemm_skinny[_ws], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
+                                          added lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
 const char* lrp_build_arch(void);      /* "gfx950" */
 int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
