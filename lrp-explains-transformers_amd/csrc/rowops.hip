@@ -239,16 +239,35 @@ __global__ void head_seed_kernel(const T* Wlm, const float* logits, const int* i
         out[(int64_t)b * H + c] = from_f32<T>(f * to_f32(Wlm[(int64_t)i * H + c]) * (to_f32(wn[c]) + w_off));
 }
 
-__global__ void argmax_rows_kernel(const float* logits, int* idx, float* val, int V, int64_t ld) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+// one workgroup of 1024 threads per row; 16-byte loads, four independent ones in flight per thread (the one-dword-at-a-time loop of
+// round 2 took 150-440 us on a 128 k ... 262 k vocabulary: latency-bound).  Ties resolve to the lowest index.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* logits, int* idx, float* val, int V, int64_t ld) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
     const float* p = logits + (int64_t)blockIdx.x * ld;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = threadIdx.x; c < V; c += blockDim.x) {
-        const float v = p[c];
+    auto take = [&](float v, int c) {
         if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    const int nv = vec ? V / 4 : 0;
+    int q = threadIdx.x;
+    for (; q + 3 * 1024 < nv; q += 4 * 1024) {
+        f32x4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(p + 4 * (q + u * 1024));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take(x[u][e], 4 * (q + u * 1024) + e);
     }
+    for (; q < nv; q += 1024) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(x[e], 4 * q + e);
+    }
+    for (int c = 4 * nv + threadIdx.x; c < V; c += 1024) take(p[c], c);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);
@@ -259,7 +278,7 @@ __global__ void argmax_rows_kernel(const float* logits, int* idx, float* val, in
     if ((threadIdx.x & 63) == 0) { sv[w] = bv; si[w] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+        for (int k = 1; k < 16; ++k)
             if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
         idx[blockIdx.x] = bi;
         if (val) val[blockIdx.x] = bv;
@@ -419,7 +438,7 @@ extern "C" int lrp_head_seed(const void* W_lm, const float* logits, const int* i
 extern "C" int lrp_argmax_rows(const float* logits, int* idx, float* val, int B, int V, int64_t ld, void* stream) {
     if (!logits || !idx || B < 0 || V < 1) return LRP_EINVAL;
     if (B == 0) return LRP_OK;
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, idx, val, V, ld);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logits, idx, val, V, ld);
     return lrp_check_launch();
 }
 

@@ -393,6 +393,14 @@ def test_readout_argmax_headseed(ops):
     logits[1, 77] = 50.0
     idx, val = ops.argmax_rows(logits)
     assert torch.equal(idx.long().cpu(), logits.argmax(-1).cpu()) and torch.equal(val, logits.max(-1).values)
+    # vocabulary-sized rows (16-byte loads, unrolled body + remainders), an unaligned row pitch, ties -> lowest index, maximum in the tail
+    for V, ld in ((128256, 128256), (262208, 262208), (50257, 50257 + 3), (4099, 4099)):
+        big = torch.randn(4, ld, device="cuda")[:, :V]
+        big[0, V - 1] = 60.0
+        big[1, 5] = big[1, V // 2] = 55.0
+        big[2, 4 * (V // 4) - 1] = 70.0
+        i2, v2 = ops.argmax_rows(big)
+        assert i2.tolist() == [V - 1, 5, 4 * (V // 4) - 1, int(big[3].argmax())] and torch.equal(v2, big.max(-1).values)
     W, wn, rstd = rnd(1000, 264, seed=4), rnd(264, seed=5), rnd(3, seed=6).abs()
     out = ops.head_seed(W, logits, idx, wn, rstd, torch.empty(3, 264, device="cuda"), 0.0, 1e-8)
     z = val.double()
