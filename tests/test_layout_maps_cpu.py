@@ -104,6 +104,37 @@ def test_gemm_pp_lds_image_staging_map_and_epilogue():
     assert sorted(cols) == list(range(32))
 
 
+def test_gemm_pp_nn_operand_image():
+    """gemm_pp.hip, NN form (dgrad c = s W from the stored weight): the B operand of a K tile is an LDS image [64 contraction rows][512 B =
+    256 output columns], 16-byte chunk c of row r at position c ^ f(r), f(r) = 2 ((r & 3) + 4 ((r >> 3) & 1)).
+    (1) staging: piece p of wave w = rows 8 w + 2 p + (l >> 5), lane l -> LDS slot l of the piece, SOURCE chunk (l & 31) ^ f(row): the
+        eight waves' 32 pieces tile the image exactly once and a reader of (row, chunk c) finds source chunk c;
+    (2) the MFMA operand of column tile j (8 consecutive contraction indices of one output column) is gathered by ds_read_b64_tr_b16 at
+        row 8 hi + (i16 >> 2) (+4 for the second half, +32 for the second k-step), chunk (8 wc + 2 j + ((i16 & 3) >> 1)) ^ f(row),
+        byte 8 (i16 & 1): conflict-free under the 32-lane groups of the transpose read, for every wave column wc, tile j, half, k-step"""
+    f = lambda r: 2 * ((r & 3) + 4 * ((r >> 3) & 1))           # noqa: E731
+    seen = {}
+    for w, p_, lane in itertools.product(range(8), range(4), range(64)):
+        row, pos = 8 * w + 2 * p_ + (lane >> 5), lane & 31
+        lds = (8 * w + 2 * p_) * 512 + lane * 16                  # lane-linear 1-KiB piece at the piece's first row
+        assert lds == row * 512 + pos * 16
+        # the kernel's per-lane source offset uses r = 2 (p & 1) + (l >> 5) and (wave & 1): the same f as f(row)
+        assert 2 * (((2 * (p_ & 1) + (lane >> 5)) & 3) + 4 * (w & 1)) == f(row)
+        seen[(row, pos)] = pos ^ f(row)                          # source chunk stored at this position
+    assert len(seen) == 64 * 32
+    for row, c in itertools.product(range(64), range(32)):
+        assert seen[(row, c ^ f(row))] == c
+        assert 0 <= (c ^ f(row)) < 32
+    for wc, j, half, ks in itertools.product(range(4), range(4), range(2), range(2)):
+        def tr(lane, wc=wc, j=j, half=half, ks=ks):
+            hi, i16 = lane >> 4, lane & 15
+            row = 8 * hi + (i16 >> 2) + 4 * half + 32 * ks
+            fl = 2 * (((i16 >> 2) & 3) + 4 * (hi & 1))         # what the kernel computes from the lane id alone
+            assert fl == f(row)
+            return row * 512 + (((8 * wc + 2 * j + ((i16 & 3) >> 1)) ^ fl) << 4) + 8 * (i16 & 1)
+        assert conflicts(tr, TR_GROUPS, 8) == 0
+
+
 def test_gemm_product_chunk_swizzle():
     """gemm.hip: LDS rows of 128 B, 16-byte chunk XOR (row & 7): fragment reads (row l&15, chunk kk*4 + l>>4) are conflict-free"""
     for kk in range(2):
