@@ -382,7 +382,7 @@ def main():
         }
         if not args.no_smallm:
             line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
-        if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16:
+        if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
             line["config5_seq4096"] = config5_probe(eng, ops, cfg, dev, peak)
         if not args.no_config4 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
             line["config4_gemma3_4b_text"] = config4_probe(ops, dev, dtype, peak)
