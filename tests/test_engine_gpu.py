@@ -181,6 +181,31 @@ def test_full_width_properties_bf16(eng_mod):
 
 
 @pytest.mark.parametrize("mode", ["explicit", "efficient"])
+def test_fused_gated_epilogues_equal_unfused_at_engine_level(eng_mod, mode):
+    """full layer width, bf16, both rule placements: the explanation with the gated-MLP rules inside the GEMM epilogues (lrp_gemm_gated_fwd /
+    _bwd, what the product runs) equals the one with GEMM + element-wise rule kernels bit for bit, and so does the padded-pitch layout"""
+    import lxt_amd.ops as O
+    cfg = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=2048, rope_theta=5e5, rms_eps=1e-5)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rn = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.02).bfloat16()  # noqa: E731
+    H, I, d = 4096, 14336, 128
+    W = dict(embed=rn(2048, H), norm=1 + rn(H), lm_head=rn(2048, H),
+             layers=[dict(ln1=1 + rn(H), ln2=1 + rn(H), wq=rn(32 * d, H), wk=rn(8 * d, H), wv=rn(8 * d, H), wo=rn(H, 32 * d), wg=rn(I, H),
+                          wu=rn(I, H), wd=rn(H, I)) for _ in range(2)])
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode=mode, max_seq=1024, sparse_top=False)
+    ids = torch.randint(0, 2048, (4, 1024), generator=torch.Generator().manual_seed(2))       # M = 4096 rows: the 256 x 256 ping-pong kernel
+    assert O.GATED_FUSION
+    fused = eng.explain(ids, layer_relevance=True)
+    try:
+        O.GATED_FUSION = False
+        plain = eng.explain(ids, layer_relevance=True)
+    finally:
+        O.GATED_FUSION = True
+    assert torch.isfinite(fused["R_tok"]).all() and float(fused["R_tok"].abs().max()) > 0
+    assert torch.equal(fused["R_tok"], plain["R_tok"]) and torch.equal(fused["layer_R"], plain["layer_R"]) and torch.equal(fused["logits"], plain["logits"])
+
+
+@pytest.mark.parametrize("mode", ["explicit", "efficient"])
 def test_top_layer_sparsity_equals_dense(eng_mod, mode):
     """evaluating the last layer's o-proj / MLP / attention rows only for the last token of each prompt
     (M = B) must give the same relevance as the dense evaluation"""
