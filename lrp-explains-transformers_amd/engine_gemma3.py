@@ -149,7 +149,7 @@ class Gemma3LRP:
         return self.cfg["window"] if self.cfg["layer_types"][li] == "sliding_attention" else 0
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, emb, B, S):
+    def forward(self, emb, B, S, row_iv=None):
         c = self.cfg
         H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
         M, dt, dev = B * S, self.dtype, self.device
@@ -187,7 +187,7 @@ class Gemma3LRP:
             v = qkv[:, nqd + nkd:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o, lse = new(("o", li), M, nqd), f32(("lse", li), B, nq, S)
-            ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], True, self._window(li))
+            ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], True, self._window(li), row_iv=row_iv)
             a = ops.linear_fwd(o, Lw["wo"], out=new("a", M, H))
             # post-attention norm, residual add, pre-feed-forward norm
             pa, st["rstd_pa"] = new("pa", M, H), f32(("rstd_pa", li), M)
@@ -207,7 +207,7 @@ class Gemma3LRP:
         hL_last = new("hL_last", B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h_last, b_last, self.norm, eps, 1.0, hsum_out=hL_last)
         logits = ops.linear_fwd(xn, self.lm_head, out=f32("logits", B, c["vocab"]))
-        return dict(stash=stash, last=last, rstd_f=rstd_f, logits=logits)
+        return dict(stash=stash, last=last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
 
     # ---------------------------------------------------------------------------------------------
     def backward(self, fw, idx, B, S):
@@ -247,8 +247,9 @@ class Gemma3LRP:
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dq, dk_h, dv_h = new("dq", M, nqd), new("dk_h", M, nqd), new("dv_h", M, nqd)
-            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win)
-            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win)
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win, row_iv=fw["row_iv"])
+            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win,
+                             row_iv=fw["row_iv"])
             dk = ops.gqa_reduce(dk_h, new("dk", M, nkd), M, nk, rep, d)
             Aqkv = new("Aqkv", M, nqkv)
             ops.gqa_reduce(dv_h, Aqkv[:, nqd + nkd:], M, nk, rep, d)
@@ -268,9 +269,11 @@ class Gemma3LRP:
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def explain(self, input_ids=None, inputs_embeds=None, target=None, return_G=False):
+    def explain(self, input_ids=None, inputs_embeds=None, target=None, return_G=False, lengths=None):
         """input_ids [B, S] (or inputs_embeds [B, S, H] = HF's scaled embeddings); target: None (arg-max of the last position) or [B]
-        vocabulary indices.  Returns dict(idx [B], logit [B], R_tok [B, S] fp32 = sum_h e (*) dlogit/de, logits [B, V])."""
+        vocabulary indices.  Returns dict(idx [B], logit [B], R_tok [B, S] fp32 = sum_h e (*) dlogit/de, logits [B, V]).
+        lengths [B] (optional): prompts of different lengths in one call, LEFT-padded to S (as LlamaLRP.explain: pad keys are masked through
+        the attention kernels' per-row key intervals, RoPE is relative, R_tok is exactly 0 at pad positions)."""
         if inputs_embeds is None:
             input_ids = input_ids.to(self.device)
             B, S = input_ids.shape
@@ -280,7 +283,17 @@ class Gemma3LRP:
             emb = inputs_embeds.to(device=self.device, dtype=self.dtype).reshape(B * S, -1).contiguous()
         if S > self.max_seq:
             raise ValueError(f"sequence length {S} exceeds max_seq={self.max_seq}")
-        fw = self.forward(emb, B, S)
+        row_iv = None
+        if lengths is not None:
+            lens = torch.as_tensor(lengths, device=self.device).to(torch.int32).reshape(B)
+            if int(lens.min()) < 1 or int(lens.max()) > S:
+                raise ValueError("lengths must lie in [1, S]")
+            i = torch.arange(S, device=self.device, dtype=torch.int32)
+            first = (S - lens)[:, None]
+            lo = first.expand(B, S).contiguous()
+            hi = torch.where(i[None] >= first, (i + 1)[None].expand(B, S), torch.zeros_like(lo)).contiguous()      # pad rows: empty interval
+            row_iv = (lo, hi)
+        fw = self.forward(emb, B, S, row_iv)
         if target is None:
             idx, _ = ops.argmax_rows(fw["logits"])
         else:

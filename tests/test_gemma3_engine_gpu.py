@@ -45,6 +45,27 @@ def test_gemma3_engine_fp32_vs_reference_fixture(g3):
     assert nmax(outb["R_tok"][0], out["R_tok"][0]) < 1e-5 and nmax(outb["R_tok"][1], outr["R_tok"][0]) < 1e-5
 
 
+def test_gemma3_engine_left_padded_lengths(g3):
+    """prompts of different lengths in one call (left-padded; sliding-window AND global layers see the per-row key intervals): each row equals
+    the un-padded single-prompt explanation, pad positions carry exactly zero relevance"""
+    fx = load("gemma3_tiny.npz")
+    ids = torch.as_tensor(fx["ids"]).long()
+    model = build_gemma3(seed=3, attn="eager")
+    eng = g3.Gemma3LRP.from_hf(model, dtype=torch.float32, max_seq=512)
+    S, lens = ids.numel(), (ids.numel(), 61, 17)
+    batch = torch.zeros(3, S, dtype=torch.long)
+    for b, L in enumerate(lens):
+        batch[b, S - L:] = ids[:L]
+    out = eng.explain(batch, lengths=list(lens))
+    for b, L in enumerate(lens):
+        one = eng.explain(ids[None, :L])
+        assert int(out["idx"][b]) == int(one["idx"][0]) and abs(float(out["logit"][b]) - float(one["logit"][0])) < 1e-4
+        assert nmax(out["R_tok"][b, S - L:], one["R_tok"][0]) < 1e-5
+        assert float(out["R_tok"][b, : S - L].abs().max()) == 0.0 if L < S else True
+    with pytest.raises(ValueError):
+        eng.explain(batch, lengths=[0, 1, 2])
+
+
 def _full_dims_model(layers=2, seed=5):
     from transformers import Gemma3TextConfig, Gemma3ForCausalLM
     torch.manual_seed(seed)
