@@ -66,6 +66,32 @@ def test_gemma3_engine_left_padded_lengths(g3):
         eng.explain(batch, lengths=[0, 1, 2])
 
 
+def test_gemma3_engine_from_conditional_generation_model(g3):
+    """from_hf on a Gemma3ForConditionalGeneration (the released 4B / 12B / 27B checkpoints are multi-modal): the language model's weights
+    and text_config are picked up; a text-only prompt equals the drop-in path (monkey_patch, autograd) on the same model in fp32"""
+    from tests.golden.hf_models import build_gemma3_mm
+    from transformers.models.gemma3 import modeling_gemma3
+    from lxt_amd.efficient import monkey_patch
+    model = build_gemma3_mm(seed=11, attn="eager")
+    eng = g3.Gemma3LRP.from_hf(model, dtype=torch.float32, max_seq=256)
+    ids = torch.randint(0, 290, (1, 40), generator=torch.Generator().manual_seed(4))
+    out = eng.explain(ids)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_gemma3)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    model = model.cuda()
+    e = model.get_input_embeddings()(ids.cuda()).requires_grad_()
+    last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+    assert int(last.argmax()) == int(out["idx"][0]) and abs(float(last.max()) - float(out["logit"][0])) < 1e-4
+    last[int(out["idx"][0])].backward()
+    R = (e * e.grad)[0].sum(-1)
+    err = nmax(out["R_tok"][0], R.detach())
+    print(f"[gemma3 mm model, text-only prompt] fused driver vs drop-in path {err:.2e}")
+    assert err < 1e-4
+
+
 def _full_dims_model(layers=2, seed=5):
     from transformers import Gemma3TextConfig, Gemma3ForCausalLM
     torch.manual_seed(seed)
