@@ -44,7 +44,7 @@ extern "C" {
 /* library identity / sanity */
 int lrp_version(void);                 /* ABI version, currently 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
-                                          added lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
+                                          added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
 const char* lrp_build_arch(void);      /* "gfx950" */
 int lrp_last_hip_error(void);          /* last HIP error code seen by this thread */
@@ -127,6 +127,14 @@ int lrp_linear_smallm_dgrad(const void* g, const void* z, const void* W, const v
  *           rel_out[row] (optional, fp32) = sum_h hsum*Gh  (latent relevance per token)
  *   branch == NULL means "no residual below" (embedding): Gs_out = Gh, A_out untouched.
  * --------------------------------------------------------------------------------------- */
+/* per-head RMSNorm (HF Gemma3Attention q_norm / k_norm: rows of head_dim elements inside a fused projection output [rows, >= heads*d],
+ * row pitches ldx / ldy in elements): y = (w + w_offset) (*) x * rstd, rstd[rows*heads] = rsqrt(mean_d(x^2) + eps); the backward treats
+ * rstd as a constant (ref lxt/efficient/models/gemma3.py:11-12): out = G (*) (w + w_offset) * rstd.  d * sizeof(T) / 16 must be a power
+ * of two <= 64. */
+int lrp_head_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int heads, int d, int64_t ldx, int64_t ldy,
+                         float eps, float w_offset, int dtype, void* stream);
+int lrp_head_rmsnorm_bwd(const void* G, const void* w, const float* rstd, void* out, int64_t rows, int heads, int d, int64_t ldg,
+                         int64_t ldo, float w_offset, int dtype, void* stream);
 int lrp_add_rmsnorm_fwd(const void* h, const void* branch, const void* w, void* hsum_out,
                         void* y, float* rstd, int M, int H, float eps, float w_offset,
                         int dtype, void* stream);

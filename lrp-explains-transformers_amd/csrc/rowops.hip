@@ -320,6 +320,53 @@ __global__ void attn_bwd_prep_kernel(const T* Go, const T* o, T* Gho, float* D, 
     }
 }
 
+// ---- per-head RMSNorm (Gemma-3 q_norm / k_norm: head_dim-wide rows inside a fused [rows, heads*d (+ ...)] projection output) --------------
+// one lane group of d/W lanes per (row, head), 16-byte chunk per lane (as attn_bwd_prep): strided in, strided out, no contiguous copies.
+// forward: y = (w + w_off) (*) x * rstd, rstd = rsqrt(mean_d(x^2) + eps) (detached in the backward: ref lxt/efficient/models/gemma3.py:11-12)
+// backward: out = G (*) (w + w_off) * rstd
+template <typename T, int W>
+__global__ void head_rmsnorm_fwd_kernel(const T* x, const T* w, T* y, float* rstd, int64_t rows, int heads, int d, int64_t ldx, int64_t ldy,
+                                        float eps, float w_off) {
+    const int lpg = d / W, gpb = blockDim.x / lpg, lg = threadIdx.x % lpg;
+    const int64_t ngroups = rows * heads;
+    for (int64_t gidx = (int64_t)blockIdx.x * gpb + threadIdx.x / lpg; gidx < ngroups; gidx += (int64_t)gridDim.x * gpb) {
+        const int h = (int)(gidx % heads);
+        const int64_t row = gidx / heads;
+        RChunk<T, W> a, ww, o;
+        a.load(x + row * ldx + (int64_t)h * d + lg * W);
+        ww.load(w + lg * W);
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < W; ++k) ss += a.v[k] * a.v[k];
+        for (int off = lpg >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float rs = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (w_off == 0.f) o.v[k] = ww.v[k] * to_f32(from_f32<T>(a.v[k] * rs));
+            else o.v[k] = (a.v[k] * rs) * (w_off + ww.v[k]);
+        }
+        o.store(y + row * ldy + (int64_t)h * d + lg * W);
+        if (lg == 0) rstd[gidx] = rs;
+    }
+}
+template <typename T, int W>
+__global__ void head_rmsnorm_bwd_kernel(const T* G, const T* w, const float* rstd, T* out, int64_t rows, int heads, int d, int64_t ldg,
+                                        int64_t ldo, float w_off) {
+    const int lpg = d / W, gpb = blockDim.x / lpg, lg = threadIdx.x % lpg;
+    const int64_t ngroups = rows * heads;
+    for (int64_t gidx = (int64_t)blockIdx.x * gpb + threadIdx.x / lpg; gidx < ngroups; gidx += (int64_t)gridDim.x * gpb) {
+        const int h = (int)(gidx % heads);
+        const int64_t row = gidx / heads;
+        const float rs = rstd[gidx];
+        RChunk<T, W> g, ww, o;
+        g.load(G + row * ldg + (int64_t)h * d + lg * W);
+        ww.load(w + lg * W);
+#pragma unroll
+        for (int k = 0; k < W; ++k) o.v[k] = g.v[k] * (ww.v[k] + w_off) * rs;
+        o.store(out + row * ldo + (int64_t)h * d + lg * W);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                                              \
@@ -458,6 +505,42 @@ extern "C" int lrp_attn_bwd_prep(const void* Go, const void* o, void* Gho, float
         int64_t nb = (ngroups + gpb - 1) / gpb;
         if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL((attn_bwd_prep_kernel<T, EPC>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)Go, (const T*)o, (T*)Gho, D, B, S, Hq, d, ldgo, ldo, ldgho, eps_pv, factor);
+    })
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_head_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int heads, int d, int64_t ldx,
+                                    int64_t ldy, float eps, float w_offset, int dtype, void* stream) {
+    if (!x || !w || !y || !rstd || rows < 0 || heads < 1 || d < 1) return LRP_EINVAL;
+    if (rows == 0) return LRP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        const int lpg = d / EPC;
+        if (d % EPC || lpg < 1 || lpg > 64 || (lpg & (lpg - 1))) return LRP_ESHAPE;
+        if (!al16(x) || !al16(w) || !al16(y) || (ldx % EPC) || (ldy % EPC)) return LRP_EALIGN;
+        const int gpb = 256 / lpg;
+        int64_t nb = (rows * heads + gpb - 1) / gpb;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL((head_rmsnorm_fwd_kernel<T, EPC>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, (const T*)w, (T*)y, rstd, rows, heads, d, ldx, ldy, eps, w_offset);
+    })
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_head_rmsnorm_bwd(const void* G, const void* w, const float* rstd, void* out, int64_t rows, int heads, int d, int64_t ldg,
+                                    int64_t ldo, float w_offset, int dtype, void* stream) {
+    if (!G || !w || !rstd || !out || rows < 0 || heads < 1 || d < 1) return LRP_EINVAL;
+    if (rows == 0) return LRP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        const int lpg = d / EPC;
+        if (d % EPC || lpg < 1 || lpg > 64 || (lpg & (lpg - 1))) return LRP_ESHAPE;
+        if (!al16(G) || !al16(w) || !al16(out) || (ldg % EPC) || (ldo % EPC)) return LRP_EALIGN;
+        const int gpb = 256 / lpg;
+        int64_t nb = (rows * heads + gpb - 1) / gpb;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL((head_rmsnorm_bwd_kernel<T, EPC>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)G, (const T*)w, rstd, (T*)out, rows, heads, d, ldg, ldo, w_offset);
     })
     return lrp_check_launch();
 }

@@ -175,13 +175,11 @@ class Gemma3LRP:
                 h = new(("h", li & 1), M, H)
                 ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln_in"], eps, 1.0, hsum_out=h, y=x, rstd=st["rstd1"])
             qkv = ops.linear_fwd(x, Lw["wqkv"], out=new(("qkv", li), M, nqkv))
-            # per-head q / k norm on contiguous [M * heads, d] rows, then RoPE with this layer type's table
-            qc = new("qc", M, nqd).copy_(qkv[:, :nqd])
-            kc = new("kc", M, nkd).copy_(qkv[:, nqd: nqd + nkd])
+            # per-head q / k norm straight out of the fused projection output (strided rows), then RoPE with this layer type's table
             qn, st["rstd_q"] = new("qn", M, nqd), f32(("rstd_q", li), M * nq)
             kn, st["rstd_k"] = new("kn", M, nkd), f32(("rstd_k", li), M * nk)
-            ops.add_rmsnorm_fwd(qc.view(M * nq, d), None, Lw["qn"], eps, 1.0, y=qn.view(M * nq, d), rstd=st["rstd_q"])
-            ops.add_rmsnorm_fwd(kc.view(M * nk, d), None, Lw["kn"], eps, 1.0, y=kn.view(M * nk, d), rstd=st["rstd_k"])
+            ops.head_rmsnorm_fwd(qkv[:, :nqd], Lw["qn"], qn, st["rstd_q"], nq, d, eps, 1.0)
+            ops.head_rmsnorm_fwd(qkv[:, nqd: nqd + nkd], Lw["kn"], kn, st["rstd_k"], nk, d, eps, 1.0)
             qr = ops.rope_fwd(qn, new(("qr", li), M, nqd), cos, sin, S, nq, d)
             kr = ops.rope_fwd(kn, new(("kr", li), M, nkd), cos, sin, S, nk, d)
             v = qkv[:, nqd + nkd:]
@@ -256,11 +254,8 @@ class Gemma3LRP:
             # RoPE backward (a rotation: plain gradient), then the q / k norms' row-constant scale, written into the fused [q | k | v] operand
             Gqn = ops.rope_bwd(dq, None, None, new("Gqn", M, nqd), cos, sin, S, nq, d, 0.0, 0.0)
             Gkn = ops.rope_bwd(dk, None, None, new("Gkn", M, nkd), cos, sin, S, nk, d, 0.0, 0.0)
-            Gq, Gk = new("Gq", M, nqd), new("Gk", M, nkd)
-            ops.rmsnorm_bwd_add2(None, Gqn.view(M * nq, d), Lw["qn"], st["rstd_q"], None, None, Gq.view(M * nq, d), None, None, 1.0, 0.0, 0.0)
-            ops.rmsnorm_bwd_add2(None, Gkn.view(M * nk, d), Lw["kn"], st["rstd_k"], None, None, Gk.view(M * nk, d), None, None, 1.0, 0.0, 0.0)
-            Aqkv[:, :nqd].copy_(Gq)
-            Aqkv[:, nqd: nqd + nkd].copy_(Gk)
+            ops.head_rmsnorm_bwd(Gqn, Lw["qn"], st["rstd_q"], Aqkv[:, :nqd], nq, d, 1.0)
+            ops.head_rmsnorm_bwd(Gkn, Lw["kn"], st["rstd_k"], Aqkv[:, nqd: nqd + nkd], nk, d, 1.0)
             Gx = ops.linear_dgrad(Aqkv, Lw["wqkv"], out=new("Gx", M, H))
             # ---- input norm + residual
             Gs = new(("Gs", li & 1), M, H)

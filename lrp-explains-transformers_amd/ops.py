@@ -464,6 +464,28 @@ def rmsnorm_bwd_add2(Gres, Gx, w, rstd, hsum, branch, Gs_out, A_out, rel_out=Non
     return Gs_out, A_out
 
 
+def head_rmsnorm_fwd(x, w, y, rstd, heads, d, eps, w_offset=0.0):
+    """per-head RMSNorm of the first heads*d columns of x [rows, >= heads*d] (2-D views: row pitch = stride(0)) into y; rstd fp32 [rows*heads]"""
+    rows = x.shape[0]
+    same(x, y)
+    f32(rstd)
+    w = aux(w, x, d)
+    check(lib.lrp_head_rmsnorm_fwd(p(x), p(w), p(y), p(rstd), rows, heads, d, x.stride(0), y.stride(0), eps, w_offset, dt(x), stream()),
+          "lrp_head_rmsnorm_fwd")
+    return y, rstd
+
+
+def head_rmsnorm_bwd(G, w, rstd, out, heads, d, w_offset=0.0):
+    """out = G (*) (w + w_offset) * rstd per (row, head): the backward of head_rmsnorm_fwd with rstd detached"""
+    rows = G.shape[0]
+    same(G, out)
+    f32(rstd)
+    w = aux(w, G, d)
+    check(lib.lrp_head_rmsnorm_bwd(p(G), p(w), p(rstd), p(out), rows, heads, d, G.stride(0), out.stride(0), w_offset, dt(G), stream()),
+          "lrp_head_rmsnorm_bwd")
+    return out
+
+
 def head_norm_bwd(g_xn, w, rstd, out, w_offset=0.0):
     """final-norm identity rule on the head rows: out = g_xn * (w + w_offset) * rstd  (g_xn fp32 or model dtype [B,H])"""
     g = g_xn if g_xn.dtype == out.dtype else cast(g_xn, out.dtype)

@@ -386,6 +386,29 @@ def test_rmsnorm_fwd_bwd(ops, dtype, M, H):
     assert nmax(Gs, f64(Gx) * f64(w) * rstd.double()[:, None]) < TOL[dtype] * 5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("heads,d", [(4, 32), (8, 256), (3, 128), (2, 64)])
+def test_head_rmsnorm_fwd_bwd(ops, dtype, heads, d):
+    """per-head RMSNorm on strided slices of a fused projection output (Gemma-3 q_norm / k_norm; ref lxt/efficient/models/gemma3.py:11-12:
+    rstd detached): forward y = (1 + w) x rstd and backward G (1 + w) rstd vs fp64, written into a strided slice as well"""
+    rows, lead, tail = 77, 16, 24
+    g = torch.Generator().manual_seed(heads * d)
+    big = torch.randn(rows, lead + heads * d + tail, generator=g).to(dtype).cuda()
+    x = big[:, lead: lead + heads * d]
+    w = (torch.randn(d, generator=g) * 0.1).to(dtype).cuda()
+    y = torch.empty(rows, heads * d, dtype=dtype, device="cuda")
+    rstd = torch.empty(rows * heads, dtype=torch.float32, device="cuda")
+    ops.head_rmsnorm_fwd(x, w, y, rstd, heads, d, 1e-6, 1.0)
+    x64 = f64(x).view(rows, heads, d)
+    r64 = torch.rsqrt(x64.pow(2).mean(-1, keepdim=True) + 1e-6)
+    assert nmax(y.view(rows, heads, d), x64 * r64 * (1 + f64(w))) < TOL[dtype] and nmax(rstd.view(rows, heads, 1), r64) < 1e-5
+    G = torch.randn(rows, heads * d, generator=g).to(dtype).cuda()
+    outb = torch.zeros(rows, lead + heads * d + tail, dtype=dtype, device="cuda")
+    ops.head_rmsnorm_bwd(G, w, rstd, outb[:, lead: lead + heads * d], heads, d, 1.0)
+    assert nmax(outb[:, lead: lead + heads * d].reshape(rows, heads, d), f64(G).view(rows, heads, d) * (1 + f64(w)) * r64) < TOL[dtype]
+    assert float(outb[:, :lead].abs().max()) == 0.0 and float(outb[:, lead + heads * d:].abs().max()) == 0.0
+
+
 def test_readout_argmax_headseed(ops):
     e, G = rnd(50, 264, seed=1), rnd(50, 264, seed=2)
     assert nmax(ops.readout(e, G), (f64(e) * f64(G)).sum(-1)) < 1e-5
