@@ -641,7 +641,7 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     STORED weight layout:
        M <= 4, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
        M <= 256, bf16, N % 64 == 0                           : split-K skinny path, NN form
-       larger bf16 problems                                  : lrp_gemm_nn (no W^T copy)
+       bf16 problems of >= 190 tiles of 256 x 256            : lrp_gemm_nn (no W^T copy)
        everything else (fp32 parity path, odd shapes)        : lrp_gemm_nt on a W^T copy cached on the weight (ops.weight_t)"""
     M, N = s2.shape
     K = W.shape[1]
@@ -650,9 +650,13 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     if (M <= 4 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
         return linear_smallm_dgrad(s2, W, out=out, out_dtype=odt)
     if nn:
-        if out is None:
-            out = torch.empty(M, K, device=s2.device, dtype=odt)
-        return gemm_skinny(s2, W, out, nn=True) if splitk_ok(M, K, N) else gemm_nn_2d(s2, W, out)
+        split = splitk_ok(M, K, N)
+        # the NN form exists only in the 256 x 256 ping-pong kernel: problems it cannot fill (fewer than 190 tiles and no split-K: BERT-sized
+        # weights at a few thousand rows) run the 128 x 128 / 64 x 64 NT kernels on a cached W^T instead, as in round 2
+        if split or ((M + 255) // 256) * ((K + 255) // 256) >= 190:
+            if out is None:
+                out = torch.empty(M, K, device=s2.device, dtype=odt)
+            return gemm_skinny(s2, W, out, nn=True) if split else gemm_nn_2d(s2, W, out)
     wt = weight_t(W)
     if out is not None and s2.stride(1) == 1 and s2.dtype == wt.dtype and s2.stride(0) % epc(s2) == 0:
         return gemm_nt_2d(s2, wt, out)
