@@ -265,3 +265,29 @@ def test_host_dispatch_rules_round3():
         G.config_from_hf(LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2))
     with pytest.raises(RuntimeError):
         G.Gemma3LRP(c, {})
+
+
+def test_header_is_plain_c_and_gemma3_weight_views():
+    """(1) include/lrp_hip.h is what a C caller binds: it compiles as C99 and as C++ on its own (no torch / HIP types in the signatures);
+    (2) Gemma3LRP's weight reader finds the text tower in both HF model classes (no copies, tied head detected)"""
+    import shutil
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    hdr = os.path.join(root, "include", "lrp_hip.h")
+    if shutil.which("gcc"):
+        for lang, std in (("c", "-std=c99"), ("c++", "-std=c++11")):
+            r = subprocess.run(["gcc", "-fsyntax-only", "-x", lang, std, "-Wall", "-Werror", hdr], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+    import re
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)     # declarations only (the comments cite torch / HIP names)
+    assert "torch" not in code and "hipStream_t" not in code and "#include <hip" not in code     # streams cross the boundary as void*
+    import lxt_amd.engine_gemma3 as G
+    from tests.golden.hf_models import build_gemma3, build_gemma3_mm
+    m1 = build_gemma3(seed=3)
+    cfg, W = G.weights_from_hf(m1)
+    assert len(W["layers"]) == 4 and W["layers"][0]["wq"].data_ptr() == m1.model.layers[0].self_attn.q_proj.weight.data_ptr()
+    assert cfg["layer_types"][-1] == "full_attention" and W["lm_head"].data_ptr() != W["embed"].data_ptr()      # untied in this fixture
+    m2 = build_gemma3_mm(seed=11)
+    cfg2, W2 = G.weights_from_hf(m2)
+    assert len(W2["layers"]) == 3 and cfg2["hidden"] == 64 and W2["lm_head"].data_ptr() == W2["embed"].data_ptr()   # tied (HF default)
+    assert W2["layers"][0]["qn"].shape == (32,) and W2["layers"][0]["ln_pff"].shape == (64,)
