@@ -51,38 +51,62 @@ def synth_weights(cfg, device, dtype, seed=0):
 
 
 def cpu_baseline(cfg, S, budget_s=30.0):
-    """time the oracle (CPU port) on ONE decoder layer + head of the same shape, fp32, all host
-    cores; extrapolate to the full depth.  Bounded: a single timed pass after one warm-up if it fits
-    the budget."""
+    """time the oracle (CPU port) on ONE decoder layer + head of the same shape on all host cores and extrapolate to the full depth:
+    fp32 (the oracle's parity dtype; `value`) and bf16 (the dtype the reference's own CPU number in BASELINE.md was taken in, and the
+    GPU line's dtype; `bf16`).  Bounded: a single timed pass after one warm-up if it fits the budget."""
     from oracle import llama as ol
     c1 = dict(cfg, n_layers=1)
     W = ol.random_weights(c1, seed=0)
     ids = torch.randint(0, c1["vocab"], (S,), generator=torch.Generator().manual_seed(1234))
     cores = torch.get_num_threads()
-    t0 = time.time()
-    ol.explain(c1, W, ids=ids, mode="efficient", dtype=torch.float32)
-    t_first = time.time() - t0
-    t_layer = t_first
-    if t_first < budget_s / 2:
+
+    def one(dt, budget):
         t0 = time.time()
-        ol.explain(c1, W, ids=ids, mode="efficient", dtype=torch.float32)
-        t_layer = time.time() - t0
-    total = t_layer * cfg["n_layers"]
-    return dict(value=1.0 / total, unit="explanations/s", cores=cores, kind="port",
-                sample=f"oracle/llama.py, 1 of {cfg['n_layers']} decoder layers + last-token head at S={S}, fp32, "
-                       f"{t_layer:.2f} s measured, extrapolated x{cfg['n_layers']}")
+        ol.explain(c1, W, ids=ids, mode="efficient", dtype=dt)
+        t_first = time.time() - t0
+        if t_first < budget / 2:
+            t0 = time.time()
+            ol.explain(c1, W, ids=ids, mode="efficient", dtype=dt)
+            return time.time() - t0
+        return t_first
+    t32 = one(torch.float32, budget_s * 0.6)
+    out = dict(value=1.0 / (t32 * cfg["n_layers"]), unit="explanations/s", cores=cores, kind="port",
+               sample=f"oracle/llama.py, 1 of {cfg['n_layers']} decoder layers + last-token head at S={S}, fp32, "
+                      f"{t32:.2f} s measured, extrapolated x{cfg['n_layers']}")
+    try:
+        t16 = one(torch.bfloat16, budget_s * 0.4)
+        out["bf16"] = dict(value=1.0 / (t16 * cfg["n_layers"]), unit="explanations/s",
+                           sample=f"same sample in bf16 (torch CPU bf16 matmuls), {t16:.2f} s measured, extrapolated x{cfg['n_layers']}")
+    except Exception as e:  # noqa: BLE001  (a CPU build without bf16 kernels for some op)
+        out["bf16"] = dict(value=None, note=f"bf16 oracle pass failed on this host: {type(e).__name__}")
+    return out
+
+
+def _sha16(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r03_gemm_traffic.json); None if absent.
-    PMC counters cannot be collected inside the timed run itself."""
-    path = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except Exception:  # noqa: BLE001
-        return None
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE; tools/r4_traffic.py -> profiles/r0N_gemm_traffic.json); PMC counters cannot be collected inside the timed run itself.
+    The JSON is stamped with the hash of the kernel source it was measured on (`gemm_pp_sha16`): the newest file whose stamp matches
+    the gemm_pp.hip of THIS tree is used; a stale measurement is reported as null (+ `traffic_note`), never as a number."""
+    import glob
+    want = _sha16(os.path.join(ROOT, "lrp-explains-transformers_amd", "csrc", "gemm_pp.hip"))
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_gemm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("gemm_pp_sha16") == want:
+                return float(d["traffic_bytes_per_launch"]), f"{os.path.basename(path)} (kernel source hash {want} matches)"
+            stale = stale or os.path.basename(path)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, (f"no PMC measurement for gemm_pp.hip {want} (newest: {stale}, measured on another version of the kernel)" if stale
+                  else "no PMC measurement committed")
 
 
 def smallm_roofline(ops, dtype, device, cfg, batch):
@@ -164,6 +188,40 @@ def config5_probe(eng, ops, cfg, dev, peak, steps=3):
             "gemm_TFLOPs": flops / secs / 1e12, "gemm_frac_of_peak": flops / secs / 1e12 / peak, "gemm_time_frac_of_step": secs / el}
 
 
+def mode_batch_probes(eng, ops, cfg, dev, peak, S, steps=3):
+    """driver-visible numbers for the OTHER rule placement and for one prompt per step, AFTER and OUTSIDE the headline region, same
+    engine and weights: `mode_explicit` = lxt.explicit placement (every stabiliser of lxt/explicit/models/llama.py:83-93 live), 4 prompts
+    per step; `batch1` = one prompt per step (M = S rows: the 128-tile GEMMs take the split-K path), eager and as one hipGraph."""
+    def run(B, n, graph=False, mode=None):
+        if mode is not None:
+            eng.set_mode(mode)
+        ids = torch.randint(0, cfg["vocab"], (B * (n + 1), S), generator=torch.Generator().manual_seed(777 + B)).to(dev)
+        R = eng.explain(ids[:B], graph=graph)["R_tok"]
+        torch.cuda.synchronize()
+        timer = ops.KernelTimer()
+        ops.GEMM_TIMER = None if graph else timer
+        t0 = time.perf_counter()
+        for i in range(n):
+            R = eng.explain(ids[(i + 1) * B: (i + 2) * B], graph=graph)["R_tok"]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ops.GEMM_TIMER = None
+        assert torch.isfinite(R).all()
+        d = {"value": B * n / el, "unit": "explanations/s", "ms_per_step": el / n * 1e3, "prompts_per_step": B}
+        if not graph:
+            _, flops, secs = timer.summary()
+            d.update(gemm_TFLOPs=flops / secs / 1e12, gemm_frac_of_peak=flops / secs / 1e12 / peak, gemm_time_frac_of_step=secs / el)
+        return d
+    out = {}
+    try:
+        out["mode_explicit"] = dict(run(4, steps, mode="explicit"), workload=f"lxt.explicit placement, seq={S}, 4 prompts per step")
+    finally:
+        eng.set_mode("efficient")
+    out["batch1"] = {"workload": f"lxt.efficient placement, seq={S}, ONE prompt per step", "eager": run(1, 2 * steps),
+                     "graph": run(1, 2 * steps, graph=True)}
+    return out
+
+
 def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048):
     """BASELINE config 4's text tower through the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP), AFTER and OUTSIDE the headline
     timed region: Gemma-3-4B shape (34 layers, H 2560, 8 / 4 heads of d = 256, I 10240, sliding window 1024 on 5 of 6 layers, tied
@@ -219,6 +277,12 @@ def dry_run(args):
         chunk = ids_all[i * n_total: (i + 1) * n_total]
         lo, hi = D.shard_range(n_total, rank, world)
         return D.gather_relevance(fake(chunk[lo:hi]), n_total)
+    # the same start-up self-checks as the real run: zero the non-source replicas, broadcast, compare checksums; gather order
+    flat = torch.arange(4096, dtype=torch.float32).to(torch.bfloat16) * (1.0 if rank == 0 else 0.0)
+    D.broadcast_weights([flat], src=0)
+    sums = D.check_replicas([flat])
+    assert len(sums) == world and float(flat.float().abs().sum()) > 0.0
+    D.check_gather_order(n_total, S, "cpu")
     for i in range(args.warmup):
         R = step(i)
     if world > 1:
@@ -258,9 +322,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
     ap.add_argument("--no-config4", action="store_true", help="skip the Gemma-3-4B text-tower probe that follows the headline region")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the explicit-mode and one-prompt-per-step probes that follow the headline region")
     ap.add_argument("--no-smallm", action="store_true", help="skip the small-M Linear tables that follow the headline region (profiling: their "
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
+    ap.add_argument("--unfused-gated", action="store_true", help="A/B knob: gated-MLP rules as separate kernels (ops.GATED_FUSION = False)")
+    ap.add_argument("--no-pitch-pad", action="store_true", help="A/B knob: no row-pitch padding of the long-K GEMM operands (engine.PITCH_PAD = False)")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (LlamaLRP.explain(graph=True)); pays at small batch")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing self-test WITHOUT kernels or a GPU (gloo): rank env, sharding, barrier, max-over-ranks, gather, "
@@ -274,6 +341,8 @@ def main():
     import lxt_amd.ops as ops
     import torch.distributed as dist
 
+    ops.GATED_FUSION = not args.unfused_gated
+    E.PITCH_PAD = not args.no_pitch_pad
     rank, world, local = D.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
@@ -285,12 +354,24 @@ def main():
     eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=max(args.seq, 4096), sparse_top=not args.dense_top)
     del W
     torch.cuda.empty_cache()
+    selfcheck = None
     if world > 1:
-        # weights are generated from the same seed on every rank; the broadcast from rank 0 makes the replica identity explicit
-        # (C1 of SURVEY.md 8e): ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB) -- outside the timed
-        # region; the dgrad GEMMs read the stored weights, so nothing is rebuilt (build_transposes only drops cached fp32 transposes)
+        # C1 of SURVEY.md 8e: ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB) -- outside the timed region;
+        # the dgrad GEMMs read the stored weights, so nothing is rebuilt (build_transposes only drops cached fp32 transposes).  SELF-CHECKING
+        # (VERDICT r3): every rank but 0 ZEROES its replica first, so the ranks can only produce finite, equal results if the broadcast
+        # really delivered rank 0's bytes; the per-rank byte checksums are all-gathered and must agree; and the job's all-gather is
+        # exercised once with rank-tagged rows before the timed region (global prompt order, right owner)
+        if rank != 0:
+            eng.flat.zero_()
+        t_b = time.perf_counter()
         D.broadcast_weights([eng.flat], src=0)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter() - t_b
+        sums = D.check_replicas([eng.flat])
+        D.check_gather_order(world * args.batch * args.steps, args.seq, dev)
         eng.build_transposes()
+        selfcheck = {"broadcast_bytes": eng.flat.numel() * eng.flat.element_size(), "broadcast_s": t_b, "replica_checksums_equal": True,
+                     "checksum": sums[0] & 0xFFFFFFFF, "gather_order_checked": True}
 
     B, S = args.batch, args.seq
     n_total = world * B
@@ -350,6 +431,7 @@ def main():
         # beside it: their duration includes the rule's own HBM traffic (gu read + Agu written: 0.94 GB per down-dgrad launch)
         n_launch, flops, secs = timer.summary("plain")
         n_all, flops_all, secs_all = timer.summary()
+        traffic, traffic_note = pmc_traffic()
         peak = 2500.0 if dtype == torch.bfloat16 else 157.3
         if secs <= 0.0:       # --graph: the launches are replayed by the graph, no per-launch events exist (dev option; the judged run is eager)
             flops, secs, n_launch = 0.0, float("nan"), 0
@@ -376,15 +458,23 @@ def main():
                                                     "eps-rule dgrad c = s W from the stored weight), 6 launches per layer",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
-                         "gemm_time_frac_of_step": secs_all / elapsed, "traffic": pmc_traffic(),
+                         "gemm_time_frac_of_step": secs_all / elapsed, "traffic": traffic, "traffic_note": traffic_note,
+                         # every GEMM launch of the step (plain + the two per layer that carry a gated-MLP rule in their epilogue + split-K):
+                         # the figure that is comparable across rounds (r01/r02 counted all launches)
+                         "frac_all_gemm_launches": flops_all / secs_all / 1e12 / peak,
                          "with_fused_epilogue_launches": {"launches": n_all, "TFLOPs": flops_all / secs_all / 1e12,
                                                           "frac": flops_all / secs_all / 1e12 / peak, **fused}},
         }
+        if selfcheck is not None:
+            line["multi_gpu_selfcheck"] = selfcheck
         if not args.no_smallm:
             line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
         if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
             line["config5_seq4096"] = config5_probe(eng, ops, cfg, dev, peak)
+        if not args.no_extra_modes and args.layers == 32 and dtype == torch.bfloat16 and world == 1 and args.mode == "efficient":
+            line.update(mode_batch_probes(eng, ops, cfg, dev, peak, S))
         if not args.no_config4 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
+            eng.release()
             line["config4_gemma3_4b_text"] = config4_probe(ops, dev, dtype, peak)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)

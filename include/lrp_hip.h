@@ -53,8 +53,9 @@ int lrp_last_hip_error(void);          /* last HIP error code seen by this threa
  * K1  Linear.   ref: forward  lxt/explicit/functional.py:345-351 (F.linear),
  *               backward lxt/explicit/functional.py:355-364, lxt/explicit/rules.py:206-222
  * lrp_gemm_nt: C[b][M,N] = A[b][M,K] . B[b][N,K]^T (+ bias[N]), fp32 accumulate on MFMA.
- *   Both operands are K-contiguous ("NT"); the engine keeps W ([out,in]) for the forward
- *   and a W^T copy ([in,out]) for the backward so every contraction is NT.
+ *   Both operands are K-contiguous ("NT"): the forward z = x W^T with W in its stored [out,in] layout.  The backward
+ *   c = s W uses lrp_gemm_nn on the SAME stored weight (bf16; no W^T copy exists); only the fp32 parity path and shapes
+ *   lrp_gemm_nn refuses transpose a weight once (host side) and come back here.
  *   lda/ldb/ldc in elements; K, lda, ldb multiples of 16 bytes' worth of elements.
  *   batch >= 1 with element strides sA/sB/sC (sB may be 0 to share B).
  *   out_dtype may differ from dtype only as LRP_F32 (fp32 output from bf16 operands).
@@ -66,7 +67,8 @@ int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
 
 /* lrp_gemm_nn: C[M,N] = A[M,K] . Bt[K,N] (+ bias[N]) -- the eps-rule's redistribution  c = s W  with W in its STORED forward layout
  * [out, in] as Bt (contraction over W's rows): no W^T copy of a weight exists anywhere.  bf16 operands, out bf16 / fp32, K a multiple
- * of 64 (>= 128), operands below 2^30 elements; other shapes return LRP_ESHAPE (the caller then transposes once and uses lrp_gemm_nt).
+ * of 64 (>= 128), Bt below 2^30 elements and 256 rows of A below 2^30 elements (more rows of A are issued as several launches over
+ * row chunks); other shapes return LRP_ESHAPE (the caller then transposes once and uses lrp_gemm_nt).
  * ref: lxt/explicit/functional.py:355-364 (backward of linear_epsilon_fn: `relevance_norm @ weight`). */
 int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int dtype, int out_dtype, void* stream);
@@ -222,9 +224,10 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
  * (slices of a fused QKV GEMM output are consumed in place); o [B*S, Hq, d] (ldo);
  * lse fp32 [B, Hq, S] = log-sum-exp of the scaled scores; d in {16,32,64,128,256}.
  * "_t" operands are head-transposed copies [B, H, d, ldt] (ldt >= S, multiple of 16 bytes'
- * worth of elements, pad columns FINITE -- zero them once) made by lrp_transpose_heads: with
- * 288 GB of HBM the engine keeps both layouts so every MFMA operand is K-contiguous and every
- * LDS fill is a straight 16-byte copy (no in-kernel transposes).
+ * worth of elements, pad columns FINITE -- zero them once) made by lrp_transpose_heads.  They are read ONLY by the kernels
+ * for which lrp_attn_needs_transposed(dtype, d) returns 1 (fp32, and bf16 head dims without a transpose-read kernel); the
+ * bf16 kernels of attention32.hip gather the transposed MFMA operand out of the row-major LDS tile (ds_read_b64_tr_b16)
+ * and take NULL for every "_t" pointer.
  * window <= 0: none; window = w: key j visible to query i iff i-w < j <= i (Gemma3 local).
  * q_begin (0 = everything): only query rows >= q_begin are needed / carry relevance -- query blocks
  *   entirely below it are skipped (top-layer sparsity: above the last attention layer only the last

@@ -18,6 +18,23 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 extern thread_local int g_lrp_last_hip_error;
 
+// opt a kernel in to more than 64 KiB of dynamic LDS, once per DEVICE (the attribute is per device; a process that drives two devices
+// must set it on both) and safely from several host threads (main thread + autograd worker): one bit per device in a per-call-site mask
+#include <atomic>
+static inline void lrp_set_max_lds_once(std::atomic<uint64_t>& done, const void* kern, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+#define LRP_SET_MAX_LDS(kern, bytes)                                                       \
+    do {                                                                                   \
+        static std::atomic<uint64_t> lds_done_{0};                                         \
+        lrp_set_max_lds_once(lds_done_, reinterpret_cast<const void*>(kern), (bytes));     \
+    } while (0)
+
 static inline int lrp_check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_lrp_last_hip_error = (int)e; return LRP_ELAUNCH; }

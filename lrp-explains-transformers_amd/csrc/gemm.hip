@@ -311,11 +311,7 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
     dim3 grid(tiles_m * tiles_n, batch), block(64 * WM * WN);
     const size_t lds = 2 * (size_t)(TBM + TBN) * KB;
     auto kern = gemm_nt_glds_kernel<T, TO, TBM, TBN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const T*)A, (const T*)B, (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc,
                        sA, sB, sC, tiles_m, tiles_n);
     return lrp_check_launch();
@@ -325,6 +321,12 @@ int launch_glds(const void* A, const void* B, void* C, const void* bias, int M, 
 // Tile selection (measured on MI355X, profiles/r01_gemm_tiles.txt, r01..r03_gemm_experiments.txt): the 256x256 8-wave ping-pong
 // kernel of gemm_pp.hip once the problem yields >= ~190 tiles (every CU busy), the 128x128 4-wave kernel (2 workgroups per
 // CU) below that.  Everything else that was tried is logged in profiles/ (the code of the losing variants is not kept).
+// rows of A one launch of the ping-pong kernel can address (32-bit buffer byte offsets: rows * lda < 2^30 elements), a multiple of 256;
+// problems with more rows are issued as several launches over row chunks (rows are independent) -- no silent change of kernel or layout
+inline int pp_row_chunk(int64_t lda) {
+    const int64_t r = (((1ll << 30) - 1) / (lda > 0 ? lda : 1)) / 256 * 256;
+    return (int)(r < 256 ? 0 : (r > (1 << 30) ? (1 << 30) : r));
+}
 template <typename T, typename TO>
 int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
@@ -333,8 +335,15 @@ int launch_fast(const void* A, const void* B, void* C, const void* bias, int M, 
     // fp32 is the parity path, not the throughput path (1/16 of the bf16 MFMA rate): always the 128x128 kernel, whose fp32
     // instantiation accumulates in blocks
     if (sizeof(T) == 2 && tiles256 >= 190) {
-        if (batch == 1 && K / KE >= 2 && (int64_t)M * lda < (1ll << 30) && (int64_t)N * ldb < (1ll << 30))
-            return lrp_launch_gemm_pp(A, B, C, bias, M, N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, 0, 1, K / KE, 0, st);
+        if (batch == 1 && K / KE >= 2 && pp_row_chunk(lda) > 0 && (int64_t)N * ldb < (1ll << 30)) {
+            const int chunk = pp_row_chunk(lda);
+            for (int m0 = 0; m0 < M; m0 += chunk) {
+                const int rc = lrp_launch_gemm_pp((const T*)A + (int64_t)m0 * lda, B, (TO*)C + (int64_t)m0 * ldc, bias, M - m0 < chunk ? M - m0 : chunk,
+                                                  N, K, lda, ldb, ldc, sizeof(TO) == 4 ? LRP_F32 : LRP_BF16, 0, 1, K / KE, 0, st);
+                if (rc != LRP_OK) return rc;
+            }
+            return LRP_OK;
+        }
         return launch_glds<T, TO, 256, 256, 4, 4>(A, B, C, bias, M, N, K, lda, ldb, ldc, batch, sA, sB, sC, st);
     }
     // small problems (BERT-sized M = 128: 6..24 tiles of 128x128 on 256 CUs, each walking the whole K alone): 64x64 or 32x32
@@ -355,12 +364,7 @@ int launch_gemm(const void* A, const void* B, void* C, const void* bias, int M, 
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, batch), block(NT);
     const size_t lds = 2 * (BM + BN) * KB;
-    static bool attr_set = false;   // per instantiation; idempotent, so a race is harmless
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    LRP_SET_MAX_LDS((&gemm_nt_kernel<T, TO>), lds);
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, block, lds, st, (const T*)A, (const T*)B,
                        (TO*)C, (const T*)bias, M, N, K, lda, ldb, ldc, sA, sB, sC, tiles_m, tiles_n);
     return lrp_check_launch();
@@ -424,7 +428,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const bf16_t*
 
 bool pp_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn) {
     const int64_t brows = nn ? K : N;
-    return (K % 64) == 0 && K >= 128 && (int64_t)M * lda < (1ll << 30) && brows * ldb < (1ll << 30);
+    return (K % 64) == 0 && K >= 128 && pp_row_chunk(lda) > 0 && brows * ldb < (1ll << 30);
 }
 
 // split policy of the split-K path: ONE round of workgroups (one workgroup per CU: 128 KiB of LDS each) that covers as many of the 256 CUs
@@ -450,7 +454,14 @@ extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* b
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Bt) & 15)) return LRP_EALIGN;
     if (!pp_ok(M, N, K, lda, ldb, 1)) return LRP_ESHAPE;
-    return lrp_launch_gemm_pp(A, Bt, C, bias, M, N, K, lda, ldb, ldc, out_dtype, 1, 1, K / 64, 0, (hipStream_t)stream);
+    const int chunk = pp_row_chunk(lda);
+    const int64_t osz = (out_dtype == LRP_F32) ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp((const char*)A + (int64_t)m0 * lda * 2, Bt, (char*)C + (int64_t)m0 * ldc * osz, bias,
+                                          M - m0 < chunk ? M - m0 : chunk, N, K, lda, ldb, ldc, out_dtype, 1, 1, K / 64, 0, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
 }
 
 extern "C" int lrp_gemm_skinny_splits(int M, int N, int K) {
@@ -470,7 +481,7 @@ extern "C" int lrp_gemm_skinny(const void* A, const void* B, void* C, const void
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
         (reinterpret_cast<uintptr_t>(ws) & 15)) return LRP_EALIGN;
-    if (!pp_ok(M, N, K, lda, ldb, nn)) return LRP_ESHAPE;
+    if (!pp_ok(M, N, K, lda, ldb, nn) || M > pp_row_chunk(lda)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int splits = skinny_splits(M, N, K), nkt = K / 64;
     int per = (nkt + splits - 1) / splits;
@@ -509,8 +520,16 @@ extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void
     if (M == 0 || I == 0) return LRP_OK;
     if (I % LRP_GATED_IL) return LRP_ESHAPE;
     if (dtype == LRP_BF16 && (ldx % 8) == 0 && (ldw % 8) == 0 && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(Wgu) & 15) &&
-        gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act))
-        return lrp_launch_gemm_pp_gated_fwd(x, Wgu, gu, m, M, I, K, ldx, ldw, ldgu, ldm, act, (hipStream_t)stream);
+        gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act)) {
+        const int chunk = pp_row_chunk(ldx);
+        for (int m0 = 0; m0 < M; m0 += chunk) {
+            const int rc = lrp_launch_gemm_pp_gated_fwd((const char*)x + (int64_t)m0 * ldx * 2, Wgu, (char*)gu + (int64_t)m0 * ldgu * 2,
+                                                        (char*)m + (int64_t)m0 * ldm * 2, M - m0 < chunk ? M - m0 : chunk, I, K, ldx, ldw, ldgu,
+                                                        ldm, act, (hipStream_t)stream);
+            if (rc != LRP_OK) return rc;
+        }
+        return LRP_OK;
+    }
     const int rc = lrp_gemm_nt(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, 0, 0, 0, dtype, dtype, stream);
     if (rc != LRP_OK) return rc;
     return lrp_gated_act_fwd_il(gu, m, M, I, ldgu, ldm, act, dtype, stream);
@@ -529,8 +548,16 @@ extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* 
     if (M == 0 || I == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (I % LRP_GATED_IL)) return LRP_ESHAPE;
     if ((lda % 8) || (ldw % 8) || (reinterpret_cast<uintptr_t>(Adn) & 15) || (reinterpret_cast<uintptr_t>(Wdn) & 15)) return LRP_EALIGN;
-    if (gated_fused_ok(M, I, K, I, lda, ldw, 1, act))
-        return lrp_launch_gemm_pp_gated_bwd(Adn, Wdn, gu, Agu, M, I, K, lda, ldw, ldgu, ldagu, eps_g, eps_lin, act, (hipStream_t)stream);
+    if (gated_fused_ok(M, I, K, I, lda, ldw, 1, act)) {
+        const int chunk = pp_row_chunk(lda);
+        for (int m0 = 0; m0 < M; m0 += chunk) {
+            const int rc = lrp_launch_gemm_pp_gated_bwd((const char*)Adn + (int64_t)m0 * lda * 2, Wdn, (const char*)gu + (int64_t)m0 * ldgu * 2,
+                                                        (char*)Agu + (int64_t)m0 * ldagu * 2, M - m0 < chunk ? M - m0 : chunk, I, K, lda, ldw,
+                                                        ldgu, ldagu, eps_g, eps_lin, act, (hipStream_t)stream);
+            if (rc != LRP_OK) return rc;
+        }
+        return LRP_OK;
+    }
     if (!ws) return LRP_EINVAL;
     const int rc = lrp_gemm_nn(Adn, Wdn, ws, nullptr, M, I, K, lda, ldw, I, dtype, dtype, stream);
     if (rc != LRP_OK) return rc;

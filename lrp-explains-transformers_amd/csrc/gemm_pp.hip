@@ -480,11 +480,7 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
     auto kern = gemm_pp_kernel<TO, NN, EPI, ACT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
                        ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
     return lrp_check_launch();

@@ -52,6 +52,51 @@ def broadcast_weights(tensors, src=0):
         dist.broadcast(t, src=src)
 
 
+def checksum(t, chunk=1 << 27):
+    """exact integer checksum of a tensor's BYTES (sum of its 16-bit words as int64, in chunks: no 4x-sized temporary for a 16-GB
+    weight buffer) -> python int; equal bytes <=> equal checksum up to collisions, independent of device and dtype"""
+    v = t.detach().contiguous().view(-1).view(torch.int16)
+    tot = 0
+    for i in range(0, v.numel(), chunk):
+        tot += int(v[i: i + chunk].to(torch.int64).sum())
+    return tot
+
+
+def check_replicas(tensors):
+    """after broadcast_weights: every rank's copy of `tensors` carries rank 0's bytes -- one all-gather of the per-rank checksums,
+    AssertionError on every rank if any replica differs.  Returns the checksum list (one entry per rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [sum(checksum(t) for t in tensors)]
+    dev = tensors[0].device
+    # (an int64 does not survive a float reduction; split into two 31-bit halves carried as int64 through all_gather)
+    mine = sum(checksum(t) for t in tensors)
+    loc = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF, (mine >> 62) & 0x7FFFFFFF], dtype=torch.int64, device=dev)
+    allc = torch.empty(dist.get_world_size() * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, loc)
+    sums = [int(a) | (int(b) << 31) | (int(c) << 62) for a, b, c in allc.view(-1, 3).tolist()]
+    assert all(x == sums[0] for x in sums), f"weight replicas differ after the broadcast: per-rank checksums {sums}"
+    return sums
+
+
+def check_gather_order(n_total, S, device, dtype=torch.float32):
+    """gather_relevance puts row p of the job at row p on every rank: each rank tags its shard's rows with their GLOBAL prompt index
+    (and its own rank in column 1), gathers, and checks the result against arange -- the same code path as the job's own all-gather"""
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    lo, hi = shard_range(n_total, rank, world)
+    tag = torch.zeros(hi - lo, S, device=device, dtype=dtype)
+    tag[:, 0] = torch.arange(lo, hi, device=device, dtype=dtype)
+    if S > 1:
+        tag[:, 1] = float(rank)
+    out = gather_relevance(tag, n_total)
+    assert out.shape == (n_total, S), out.shape
+    assert torch.equal(out[:, 0].cpu(), torch.arange(n_total, dtype=dtype)), "gathered rows are not in global prompt order"
+    if S > 1:
+        owner = torch.cat([torch.full((b - a,), float(r)) for r in range(world) for a, b in [shard_range(n_total, r, world)]]).to(dtype)
+        assert torch.equal(out[:, 1].cpu(), owner), "gathered rows do not come from the ranks that own them"
+    return True
+
+
 def gather_relevance(R_local, n_total):
     """R_local [n_local, S] -> [n_total, S] on every rank, rows in global prompt order."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -21,8 +21,6 @@ MI355X-first decisions:
     + final norm backward is a single row per prompt.
 Python only sequences kernel launches on the current stream; it performs no arithmetic.
 """
-import os
-
 import torch
 
 from . import ops
@@ -96,19 +94,22 @@ def weights_from_hf(model):
     return config_from_hf(model.config), W
 
 
+PITCH_PAD = True          # module attribute, not an environment knob: tools/r3_ab_bench.sh-style A/B scripts set engine.PITCH_PAD = False
+
+
 def pitch_pad(cols, elem_size):
     """extra elements per row for a K-contiguous GEMM operand: a row pitch that is a multiple of 4 KiB puts the same K offset of every row
     on the same memory channels; measured on MI355X at M = 8192, N = 4096 (tools/pitch_probe.py, profiles/r03_gemm_experiments.txt):
     K = 28672 NT 1357 -> 1553 TFLOP/s with 128 bytes of padding on both operands, K = 14336 1460 -> 1545 (hipBLASLt gains too:
     1533 -> 1603); no effect at K <= 6144 or on the C pitch"""
     nbytes = cols * elem_size
-    if os.environ.get("LXT_AMD_PITCH_PAD", "1") == "0":          # measurement switch
+    if not PITCH_PAD:
         return 0
     return 128 // elem_size if (nbytes >= 16384 and nbytes % 4096 == 0) else 0
 
 
 class LlamaLRP:
-    """Device-resident weights (both layouts) + explain()."""
+    """Device-resident weights (each ONCE, forward layout, one flat buffer) + explain()."""
 
     def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096, sparse_top=True):
         if not torch.cuda.is_available():
@@ -219,6 +220,7 @@ class LlamaLRP:
 
         def __init__(self, device):
             self.device, self.buf = device, {}
+            self.gen = 0          # bumped whenever a buffer is REPLACED by a larger one: captured graphs hold the old address (engine drops them)
 
         def get(self, tag, shape, dtype, zero=False, pad=0):
             """pad: extra elements per row of a 2-D buffer (the view returned is [rows, cols] with row pitch cols + pad)"""
@@ -228,6 +230,8 @@ class LlamaLRP:
                 n *= s_
             t = self.buf.get((tag, dtype))
             if t is None or t.numel() < n:
+                if t is not None:
+                    self.gen += 1
                 t = torch.empty(max(n, 1), device=self.device, dtype=dtype)
                 self.buf[(tag, dtype)] = t
             v = t[:n].view(*full)
@@ -500,6 +504,11 @@ class LlamaLRP:
             self._graphs = {}
         key = (B, S, idx is not None, bool(layer_relevance), self.mode)
         g = self._graphs.get(key)
+        # a graph captured before the arena re-allocated one of its buffers (a later, larger call) points into freed memory: drop it
+        # and capture again against the arena as it is now
+        if g is not None and g[4] != self._arena.gen:
+            del self._graphs[key]
+            g = None
         if g is None:
             s_ids = input_ids.clone()
             s_idx = idx.clone() if idx is not None else None
@@ -511,8 +520,8 @@ class LlamaLRP:
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
                 out = self._run(s_ids, None, B, S, None, s_idx, layer_relevance, False, None)
-            g = self._graphs[key] = (cg, s_ids, s_idx, out)
-        cg, s_ids, s_idx, out = g
+            g = self._graphs[key] = (cg, s_ids, s_idx, out, self._arena.gen)
+        cg, s_ids, s_idx, out, _ = g
         s_ids.copy_(input_ids)
         if s_idx is not None:
             s_idx.copy_(idx)

@@ -39,18 +39,23 @@ def config_from_hf(hf_cfg):
     if act not in ("gelu_pytorch_tanh", "gelu_tanh", "silu"):
         raise NotImplementedError(f"Gemma3LRP: activation {act!r}")
     rope = {}
-    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    rp_all = getattr(hf_cfg, "rope_parameters", None)
     for lt in sorted(set(hf_cfg.layer_types)):
-        rp = hf_cfg.rope_parameters[lt]
+        if isinstance(rp_all, dict) and isinstance(rp_all.get(lt), dict):
+            rp = rp_all[lt]                                   # transformers 5: one parameter set per layer type
+        elif lt == "sliding_attention":                       # transformers 4.x schema: rope_local_base_freq for the local layers,
+            rp = dict(rope_type="default", rope_theta=getattr(hf_cfg, "rope_local_base_freq", 10000.0))
+        else:                                                 # rope_theta (+ rope_scaling, key 'rope_type' or legacy 'type') for the global ones
+            rs = dict(getattr(hf_cfg, "rope_scaling", None) or {})
+            rp = dict(rs, rope_type=rs.get("rope_type", rs.get("type", "default")), rope_theta=getattr(hf_cfg, "rope_theta", 1e6))
         kind = rp.get("rope_type", "default")
         if kind not in _STATIC_ROPE:
-            raise NotImplementedError(f"Gemma3LRP: rope_type {kind!r}")
-        if kind == "default":
-            d = hf_cfg.head_dim
-            inv, att = 1.0 / (float(rp["rope_theta"]) ** (torch.arange(0, d, 2, dtype=torch.float32) / d)), 1.0
-        else:
-            inv, att = ROPE_INIT_FUNCTIONS[kind](hf_cfg, "cpu", layer_type=lt)
-        rope[lt] = (inv.float().cpu(), float(att))
+            raise NotImplementedError(f"Gemma3LRP: rope_type {kind!r} (layer type {lt!r}) is not supported by the fused driver")
+        d = hf_cfg.head_dim
+        inv = 1.0 / (float(rp["rope_theta"]) ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        if kind == "linear":                                  # HF `_compute_linear_scaling_rope_parameters`: inv_freq / factor, no post-scale
+            inv = inv / float(rp["factor"])
+        rope[lt] = (inv.float().cpu(), 1.0)
     return dict(hidden=hf_cfg.hidden_size, inter=hf_cfg.intermediate_size, n_layers=hf_cfg.num_hidden_layers,
                 n_heads=hf_cfg.num_attention_heads, n_kv=hf_cfg.num_key_value_heads, head_dim=hf_cfg.head_dim,
                 vocab=hf_cfg.vocab_size, rms_eps=float(hf_cfg.rms_norm_eps), act="silu" if act == "silu" else "gelu_tanh",

@@ -4,8 +4,6 @@ PyTorch is plumbing here: it owns device memory (caching allocator) and the curr
 every computation below is a call into liblrp_hip.so with raw device pointers.  CPU tensors are
 rejected -- there is no fallback.
 """
-import os
-
 import torch
 
 from ._lib import lib, check, F32, BF16, ACT
@@ -154,12 +152,13 @@ def gemm_nt_2d(a, b, out, bias=None):
 
 def gemm_nn_ok(a, w):
     """can lrp_gemm_nn / lrp_gemm_skinny serve C = a[M,K] @ w[K,N] (w = a weight in its stored [out,in] layout)?  bf16, K % 64 == 0,
-    K >= 128, 16-byte aligned K-/N-contiguous operands below 2^30 elements"""
+    K >= 128, 16-byte aligned K-/N-contiguous operands, the weight below 2^30 elements (activations with more elements are issued in
+    row chunks by the library: no fallback to a W^T copy for large batches)"""
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2:
         return False
     M, K = a.shape
     return (K % 64 == 0 and K >= 128 and a.stride(1) == 1 and w.stride(1) == 1 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
-            and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and M * a.stride(0) < 2 ** 30 and w.shape[0] * w.stride(0) < 2 ** 30)
+            and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and 256 * a.stride(0) < 2 ** 30 and w.shape[0] * w.stride(0) < 2 ** 30)
 
 
 def gemm_nn_2d(a, w, out, bias=None):
@@ -242,18 +241,29 @@ def transpose(x, out=None):
     return out
 
 
+_WT = {}            # storage id -> {(offset, shape, stride, dtype): (version, W^T)}; entries die with the weight's storage (weakref.finalize)
+TRANSPOSE_CALLS = [0]    # weight transposes actually executed (tests: the cache must hit on the second backward)
+
+
 def weight_t(w):
-    """W^T copy ([in, out]) of a frozen weight for the dgrad GEMM, cached ON the weight tensor object: valid while that
-    object keeps its storage, shape and in-place version (a replaced Parameter is a new object without the cache)."""
-    key = (w.data_ptr(), tuple(w.shape), w.dtype, w.device, w._version)
-    hit = w.__dict__.get("_lrp_wt") if hasattr(w, "__dict__") else None
-    if hit is not None and hit[0] == key:
+    """W^T copy ([in, out]) of a frozen weight for the fp32 / odd-shape dgrad GEMM.  Cached per STORAGE of the weight (not per tensor
+    object: the patched forwards hand `param.detach()` -- a fresh object on every call -- to the autograd Functions), keyed by
+    the view's offset / shape / strides / dtype and invalidated by the in-place version counter, which detach() aliases share with the
+    Parameter; the entry is dropped when the storage dies, so an address re-used by another weight can never hit."""
+    import weakref
+    st = w.untyped_storage()
+    sid = st._cdata
+    per = _WT.get(sid)
+    if per is None:
+        per = _WT[sid] = {}
+        weakref.finalize(st, _WT.pop, sid, None)
+    key = (w.storage_offset(), tuple(w.shape), tuple(w.stride()), w.dtype)
+    hit = per.get(key)
+    if hit is not None and hit[0] == w._version:
         return hit[1]
+    TRANSPOSE_CALLS[0] += 1
     wt = transpose(w.detach())
-    try:
-        w._lrp_wt = (key, wt)
-    except Exception:  # noqa: BLE001  (tensor subclasses without attribute storage: just do not cache)
-        pass
+    per[key] = (w._version, wt)
     return wt
 
 
@@ -375,7 +385,8 @@ def gated_act_bwd_il(Gm, gu, Agu, eps_g, eps_lin, act="silu"):
     return Agu
 
 
-GATED_FUSION = os.environ.get("LXT_AMD_GATED_FUSION", "1") != "0"     # measurement switch: 0 = GEMM + element-wise rule kernels
+GATED_FUSION = True      # module attribute (no environment knobs): False = GEMM + element-wise rule kernels, for A/B measurements and the
+                         # fused-equals-unfused tests
 
 
 def gemm_gated_fwd(x, Wgu, gu, m, act="silu"):
@@ -671,8 +682,7 @@ def clear_weight_cache(*weights):
     """drop the cached W^T copies (fp32 / odd-shape dgrad path) of the given weight tensors -- call after writing to a weight through
     `.data` (optimizers, adapter / quantisation loaders), which does not bump `_version` and would leave a stale W^T behind"""
     for w in weights:
-        if hasattr(w, "__dict__"):
-            w.__dict__.pop("_lrp_wt", None)
+        _WT.pop(w.untyped_storage()._cdata, None)
 
 
 # -------------------------------------------------------------------------------------- attention

@@ -161,9 +161,12 @@ def round_through(dtype):
     return lambda x: x.to(dtype).to(x.dtype)
 
 
-def forward(cfg, W, emb, rnd=None):
+def forward(cfg, W, emb, rnd=None, kv_chunk=None):
     """emb [S,H] -> cache of every activation the backward needs (one prompt).  rnd: optional storage-rounding model
-    (round_through); attention scores / probabilities stay un-rounded (fused attention keeps them on chip)."""
+    (round_through); attention scores / probabilities stay un-rounded (fused attention keeps them on chip).
+    kv_chunk (optional): evaluate the attention of `kv_chunk` kv groups at a time and do NOT keep scores / probabilities ([heads,S,S]:
+    4.3 GB each in fp64 at 32 heads, S = 4096); the backward recomputes them per chunk from the cached q / k -- same operations on the
+    same data, only the memory high-water mark changes (BASELINE config 5's real head count on a 62-GB host)."""
     R = rnd or _ident
     S, H = emb.shape
     d, nq, nk = cfg["head_dim"], cfg["n_heads"], cfg["n_kv"]
@@ -183,13 +186,22 @@ def forward(cfg, W, emb, rnd=None):
         v = R(x @ Lw["wv"].T).view(S, nk, d).transpose(0, 1)
         qr = R(q * cos + rotate_half(q) * sin)
         kr = R(k * cos + rotate_half(k) * sin)
-        kx = kr.repeat_interleave(rep, dim=0)
-        vx = v.repeat_interleave(rep, dim=0)
-        s = qr @ kx.transpose(-1, -2)                              # raw scores (lf.matmul output)
-        s2 = s * scale
-        s3 = s2.masked_fill(~causal, float("-inf"))
-        p = F.softmax(s3, dim=-1)
-        o = R(p @ vx)                                              # [nq,S,d]
+        if kv_chunk is None:
+            kx = kr.repeat_interleave(rep, dim=0)
+            vx = v.repeat_interleave(rep, dim=0)
+            s = qr @ kx.transpose(-1, -2)                          # raw scores (lf.matmul output)
+            s2 = s * scale
+            s3 = s2.masked_fill(~causal, float("-inf"))
+            p = F.softmax(s3, dim=-1)
+            o = R(p @ vx)                                          # [nq,S,d]
+        else:
+            o = torch.empty_like(qr)
+            for g0 in range(0, nk, kv_chunk):
+                g1 = min(nk, g0 + kv_chunk)
+                s_c, p_c = _scores_probs(qr[g0 * rep: g1 * rep], kr[g0:g1], rep, scale, causal)
+                o[g0 * rep: g1 * rep] = R(p_c @ v[g0:g1].repeat_interleave(rep, dim=0))
+                del s_c, p_c
+            s = p = None
         of = o.transpose(0, 1).reshape(S, nq * d)
         a = R(of @ Lw["wo"].T)
         h1 = R(h + a)
@@ -209,7 +221,14 @@ def forward(cfg, W, emb, rnd=None):
     xn = R(xn)
     logits_last = xn[-1] @ W["lm_head"].T
     return dict(layers=layers, hf=h, xn=xn, rstdf=rstdf, logits_last=logits_last, cos=cos, sin=sin,
-                scale=scale, causal=causal)
+                scale=scale, causal=causal, kv_chunk=kv_chunk)
+
+
+def _scores_probs(qr_c, kr_c, rep, scale, causal):
+    """raw scores s = q k^T and p = softmax(s * scale + causal mask) of the query heads of a range of kv groups"""
+    s = qr_c @ kr_c.repeat_interleave(rep, dim=0).transpose(-1, -2)
+    p = F.softmax((s * scale).masked_fill(~causal, float("-inf")), dim=-1)
+    return s, p
 
 
 # ----------------------------------------------------------------------------- backward
@@ -260,19 +279,32 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None, rnd=None):
         Go = Gof.view(S, nq, d).transpose(0, 1)                    # [nq,S,d]
         # P.V : UniformEpsilon rule (c=1, then /2)
         Ghat_o = R(0.5 * Go * ratio(c["o"], 1, E["pv"]))
-        vx = c["v"].repeat_interleave(rep, dim=0)
-        kx = c["kr"].repeat_interleave(rep, dim=0)
-        dP = Ghat_o @ vx.transpose(-1, -2)
-        dVx = c["p"].transpose(-1, -2) @ Ghat_o
-        # softmax (Prop 3.1 == ordinary softmax VJP in gradient form)
-        dS3 = c["p"] * (dP - (dP * c["p"]).sum(-1, keepdim=True))
-        # add2(s2, mask): unmasked entries have s3 = s2
-        s2 = c["s"] * scale
-        dS2 = torch.where(causal, dS3 * ratio(s2, 1, E["mask"]), torch.zeros_like(dS3))
-        dS = dS2 * scale                                            # mul2 by the constant 1/sqrt(d)
-        Ghat_s = dS * ratio(c["s"], 2, E["qk"])                     # lf.matmul: R/(2 s + eps)
-        dQr = R(Ghat_s @ kx)
-        dKx = R(Ghat_s.transpose(-1, -2) @ c["qr"])
+        def attn_core(h0, h1_, g0, g1, s_c, p_c):
+            """softmax rule (Prop 3.1), add2(mask), mul2(scale), lf.matmul, uniform-eps P.V for query heads h0..h1_ (kv groups g0..g1)"""
+            vx = c["v"][g0:g1].repeat_interleave(rep, dim=0)
+            kx = c["kr"][g0:g1].repeat_interleave(rep, dim=0)
+            Gh_c = Ghat_o[h0:h1_]
+            dP = Gh_c @ vx.transpose(-1, -2)
+            dVx = p_c.transpose(-1, -2) @ Gh_c
+            # softmax (Prop 3.1 == ordinary softmax VJP in gradient form)
+            dS3 = p_c * (dP - (dP * p_c).sum(-1, keepdim=True))
+            # add2(s2, mask): unmasked entries have s3 = s2
+            s2 = s_c * scale
+            dS2 = torch.where(causal, dS3 * ratio(s2, 1, E["mask"]), torch.zeros_like(dS3))
+            dS = dS2 * scale                                        # mul2 by the constant 1/sqrt(d)
+            Ghat_s = dS * ratio(s_c, 2, E["qk"])                    # lf.matmul: R/(2 s + eps)
+            return R(Ghat_s @ kx), R(Ghat_s.transpose(-1, -2) @ c["qr"][h0:h1_]), dVx
+
+        kvc = cache.get("kv_chunk")
+        if kvc is None:
+            dQr, dKx, dVx = attn_core(0, nq, 0, nk, c["s"], c["p"])
+        else:
+            dQr, dKx, dVx = torch.empty_like(c["qr"]), torch.empty_like(c["qr"]), torch.empty_like(c["qr"])
+            for g0 in range(0, nk, kvc):
+                g1 = min(nk, g0 + kvc)
+                s_c, p_c = _scores_probs(c["qr"][g0 * rep: g1 * rep], c["kr"][g0:g1], rep, scale, causal)
+                dQr[g0 * rep: g1 * rep], dKx[g0 * rep: g1 * rep], dVx[g0 * rep: g1 * rep] = attn_core(g0 * rep, g1 * rep, g0, g1, s_c, p_c)
+                del s_c, p_c
         dKr = R(dKx.view(nk, rep, S, d).sum(1))
         dV = R(R(dVx).view(nk, rep, S, d).sum(1))
         # RoPE: add2 eps on the rotated tensor, then ordinary transpose of the rotation
@@ -290,13 +322,13 @@ def backward(cfg, W, cache, target, mode="explicit", seed=None, rnd=None):
     return Gh, layer_R[::-1]
 
 
-def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32, seed=None, rnd=None):
+def explain(cfg, W, ids=None, emb=None, target=None, mode="explicit", dtype=torch.float32, seed=None, rnd=None, kv_chunk=None):
     """One explanation: returns dict(idx, logit, R_tok [S], R_emb [S,H], layer_R [L+1])."""
     Wd = cast_weights(W, dtype)
     if emb is None:
         emb = Wd["embed"][ids]
     emb = emb.to(dtype)
-    cache = forward(cfg, Wd, emb, rnd=rnd)
+    cache = forward(cfg, Wd, emb, rnd=rnd, kv_chunk=kv_chunk)
     if target is None:
         target = int(cache["logits_last"].argmax())
     G, layer_R = backward(cfg, Wd, cache, target, mode, seed=seed, rnd=rnd)

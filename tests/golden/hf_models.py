@@ -24,6 +24,25 @@ def build_gemma3(seed=3, attn="eager"):
     return Gemma3ForCausalLM(cfg).eval()
 
 
+def build_gemma3_4bdims(layers=2, seed=5, attn="eager", vocab=4096):
+    """Gemma-3-4B-it TEXT-tower layer dimensions (BASELINE config 4; public model card: H 2560, 8 query / 4 kv heads of d = 256, I 10240,
+    sliding window 1024, query_pre_attn_scalar 256, tied embeddings), `layers` decoder layers alternating local / global, small
+    vocabulary, seeded init with non-trivial norm weights (HF initialises Gemma's (1 + w) norm weights to zero)"""
+    from transformers import Gemma3TextConfig, Gemma3ForCausalLM
+    torch.manual_seed(seed)
+    cfg = Gemma3TextConfig(vocab_size=vocab, hidden_size=2560, intermediate_size=10240, num_hidden_layers=layers, num_attention_heads=8,
+                           num_key_value_heads=4, head_dim=256, sliding_window=1024, max_position_embeddings=4096,
+                           layer_types=["sliding_attention", "full_attention"][:layers], query_pre_attn_scalar=256,
+                           attn_implementation=attn, tie_word_embeddings=True)
+    m = Gemma3ForCausalLM(cfg).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        for n_, p_ in m.named_parameters():
+            if "norm" in n_:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+    return m
+
+
 def build_gemma3_mm(seed=11, attn="eager"):
     """tiny Gemma3ForConditionalGeneration: text tower (sliding + global layers) + SigLIP tower (head_dim 72 like the real
     SigLIP-So400m: 1152 / 16) + multi-modal projector.  HF leaves the projector weight at zeros on random init -> seeded here."""

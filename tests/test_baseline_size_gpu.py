@@ -1,6 +1,7 @@
 """GPU parity AT THE BASELINE WIDTH AND SEQUENCE LENGTH (BASELINE.json configs 3 and 5): Llama-3-8B layer shape
 H 4096 / I 14336 / 32 query + 8 kv heads / d 128 at S = 2048, two decoder layers, small vocabulary -- the shapes that put
-the 256x256 software-pipelined GEMM, the 8-wave attention kernels and the one-pass small-M Linear kernel on the path.
+the 256x256 GEMMs (fp32: the 128x128 blocked-accumulation kernel), the flash attention kernels and the small-M / split-K Linear
+kernels of the one-row-per-prompt top layer on the path.
 
   (a) fused engine, fp32, mode explicit AND efficient, against oracle/llama.py in fp64 on the host   -- bar 1e-4
       (what the reference defines at this size: lxt/explicit/models/llama.py:83-93,379-391,481-488);
@@ -44,7 +45,9 @@ def _oracle_both_modes(W, ids, dtype, target=None, rnd=None, modes=("explicit", 
     return out, idx, float(cache["logits_last"][idx])
 
 
-SEEDS = ((20, 21), (22, 23), (24, 25))        # (weights, ids); the module fixture `case` is the first one
+# (weights, ids) seed pairs with cached fp64 + reference-arithmetic-fp32 fixtures (tests/golden/make_golden_baseline.py); the module
+# fixture `case` is the first one
+SEEDS = ((20, 21), (22, 23), (24, 25), (26, 27), (28, 29), (32, 33), (34, 35), (36, 37), (38, 39), (40, 41))
 
 
 def _wsum(W):
@@ -74,12 +77,11 @@ def _instance(wseed, idseed, modes):
         ref64 = {m: dict(R_tok=torch.from_numpy(fx[f"{m}_R_tok"]), layer_R=torch.from_numpy(fx[f"{m}_layer_R"]),
                          R_emb_rows=torch.from_numpy(fx[f"{m}_R_emb_rows"]).double(), R_emb_absmax=float(fx[f"{m}_R_emb_absmax"])) for m in modes}
         gap = {m: dict(R_tok=float(fx[f"{m}_gap"][0]), R_emb=float(fx[f"{m}_gap"][1]), layer_R=float(fx[f"{m}_gap"][2])) for m in modes}
-        return dict(W=W, ids=ids, idx=int(fx["idx"]), logit=float(fx["logit"]), ref64=ref64, gap=gap, rows=rows, cached=True,
-                    noise=[float(x) for x in fx["explicit_noise_draws"]])
+        return dict(W=W, ids=ids, idx=int(fx["idx"]), logit=float(fx["logit"]), ref64=ref64, gap=gap, rows=rows, cached=True)
     ref64, idx, logit = _oracle_both_modes(W, ids, torch.float64, modes=modes)
     ref32, _, _ = _oracle_both_modes(W, ids, torch.float32, target=idx, modes=modes)
     gap = {m: {k: nmax(ref32[m][k], ref64[m][k]) for k in ("R_tok", "R_emb", "layer_R")} for m in ref64}
-    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap, rows=None, cached=False, noise=None)
+    return dict(W=W, ids=ids, idx=idx, logit=logit, ref64=ref64, gap=gap, rows=None, cached=False)
 
 
 @pytest.fixture(scope="module")
@@ -123,24 +125,17 @@ def test_engine_fp32_full_width_efficient_vs_oracle(case):
 
 
 def test_engine_fp32_full_width_explicit_vs_oracle(case):
-    """lxt.explicit placement.  z/(z+eps) has a pole at z = -eps; at this size a few of the 2 x 8.4 M P.V
-    outputs (eps 1e-6) and 4 x 8.4 M residual sums (eps 1e-8) land within a fraction of a percent of it on EVERY instance, and an
-    fp32 evaluation -- the reference's own included -- then disagrees with the exact (fp64) result by a heavy-tailed amount:
-    the reference's arithmetic in fp32 is off by 3e-5 ... 6e-3 (token relevance) depending on the seed
-    (profiles/r02_explicit_conditioning.txt), i.e. "1e-4 against lxt.explicit" is not defined at this size even for lxt.explicit
-    in fp32.  What is asserted on this instance: the engine is within 5x the instance's own fp32 conditioning
-    (tests/util.fp32_conditioning: the fp64 oracle under fp32-sized activation noise, 1.2e-4 here), and within 1e-4 wherever that
-    conditioning allows it.  The reference's fp32-vs-fp64 gap on the same instance is printed next to it."""
-    from tests.util import fp32_conditioning
+    """lxt.explicit placement on the first instance.  z/(z+eps) has a pole at z = -eps; at this size a few of the
+    2 x 8.4 M P.V outputs (eps 1e-6) and 4 x 8.4 M residual sums (eps 1e-8) land within a fraction of a percent of it on EVERY
+    instance, and an fp32 evaluation -- the reference's own arithmetic included -- then disagrees with the exact (fp64) result by a
+    heavy-tailed amount.  The yardstick is the reference ARITHMETIC's own fp32-vs-fp64 gap on this instance (oracle/llama.py run in
+    fp32: the op sequence of lxt/explicit/models/llama.py on CPU BLAS), nothing builder-made: engine within 1e-4 or 3x that gap.
+    The distributional evidence over ten instances is test_engine_fp32_full_width_seed_set."""
     err, gap = _engine_errors(case, "explicit"), case["gap"]["explicit"]
-    if case["noise"] is not None:
-        cond = max(case["noise"])
-    else:
-        cond = fp32_conditioning(CFG, case["W"], case["ids"], case["idx"], "explicit", ref64=case["ref64"]["explicit"]["R_tok"], draws=2)
     print(f"[H4096/S2048 fp32 explicit seeds {SEEDS[0]}] token {err['R_tok']:.2e} | neuron {err['R_emb']:.2e} | layer {err['layer_R']:.2e} "
-          f"(instance fp32 conditioning {cond:.1e}; the reference's own fp32-vs-fp64 gap: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
-    assert err["R_tok"] < max(1e-4, 5 * cond) and err["layer_R"] < max(1e-4, 5 * cond)
-    assert err["R_emb"] < max(1e-4, 5 * cond * max(1.0, gap["R_emb"] / gap["R_tok"]))      # per-neuron: the same poles, un-summed
+          f"(the reference arithmetic's own fp32-vs-fp64 gap: {gap['R_tok']:.1e} | {gap['R_emb']:.1e} | {gap['layer_R']:.1e})")
+    for k in ("R_tok", "R_emb", "layer_R"):
+        assert err[k] < max(1e-4, 3 * gap[k]), (k, err[k], gap[k])
 
 
 def test_engine_bf16_full_width_vs_oracle(case):
@@ -185,34 +180,40 @@ def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_engine_fp32_full_width_three_seeds(case):
-    """the committed evidence is all three instances, not the best one.  Efficient placement: 1e-4 on every seed.  Explicit
-    placement: the engine's error beside the reference ARITHMETIC's own fp32-vs-fp64 gap and two draws of the fp64 oracle under
-    fp32-sized activation noise, per seed.  Each of those three numbers is one draw of the same heavy-tailed quantity -- "an fp32
-    evaluation of this instance", z/(z + eps) poles; on seeds (22,23) the two noise draws alone are 8e-4 and 0.31.
-    Asserted: on every seed the engine is within 5x the largest of the three, and over the three seeds its geometric-mean error is
-    within 3x the geometric mean of all nine reference draws."""
+def test_engine_fp32_full_width_seed_set(case):
+    """distributional evidence at BASELINE width, yardstick = the reference ARITHMETIC in fp32 ONLY (no noise model).
+    TEN instances (weights seed, ids seed) with cached fp64 and fp32 runs of oracle/llama.py (the op sequence of
+    lxt/explicit/models/llama.py:83-93,379-391,481-488 on CPU BLAS; tests/golden/make_golden_baseline.py).
+    Efficient placement (no stabilisers, no poles): < 1e-4 on every instance.
+    Explicit placement: each fp32 evaluation of an instance -- the reference's or ours -- is one draw of a heavy-tailed quantity
+    (z/(z+eps) poles), so the claim is about the distribution: the engine's geometric-mean AND median token error over
+    the set are within 3x of the reference arithmetic's own fp32 figures; per instance only a gross bound is asserted (30x the LARGEST
+    reference gap of the set: an implementation error shows up as O(1))."""
     import math
+    import statistics
     table = []
     for (ws, ids_) in SEEDS:
         c = case if (ws, ids_) == SEEDS[0] else _instance(ws, ids_, modes=("explicit", "efficient"))
         eff, exp = _engine_errors(c, "efficient"), _engine_errors(c, "explicit")
-        noise = c["noise"] or []
-        table.append((ws, ids_, eff, exp, c["gap"], noise))
+        table.append((ws, ids_, eff, exp, c["gap"]))
         print(f"[H4096/S2048 fp32 seeds ({ws},{ids_})] efficient token {eff['R_tok']:.2e} neuron {eff['R_emb']:.2e} layer {eff['layer_R']:.2e} | "
               f"explicit token {exp['R_tok']:.2e} neuron {exp['R_emb']:.2e} layer {exp['layer_R']:.2e} | reference arithmetic fp32 gap (explicit) "
-              f"{c['gap']['explicit']['R_tok']:.1e} / {c['gap']['explicit']['R_emb']:.1e} / {c['gap']['explicit']['layer_R']:.1e}; noise-model draws "
-              + " ".join(f"{x:.1e}" for x in noise))
+              f"{c['gap']['explicit']['R_tok']:.1e} / {c['gap']['explicit']['R_emb']:.1e} / {c['gap']['explicit']['layer_R']:.1e} | ratio "
+              f"{exp['R_tok'] / max(c['gap']['explicit']['R_tok'], 1e-30):.2f}")
         del c
-    for ws, ids_, eff, exp, gap, noise in table:
-        assert max(eff.values()) < 1e-4, (ws, eff)
-        yard = max([gap["explicit"]["R_tok"]] + list(noise))
-        assert exp["R_tok"] < max(1e-4, 5 * yard), (ws, exp, yard)
     gm = lambda v: math.exp(sum(math.log(max(x, 1e-30)) for x in v) / len(v))      # noqa: E731
-    ge = gm([t[3]["R_tok"] for t in table])
-    gr = gm([x for t in table for x in [t[4]["explicit"]["R_tok"]] + list(t[5])])
-    print(f"[H4096/S2048 fp32 explicit, 3 seeds] geometric mean: engine {ge:.2e}; reference arithmetic in fp32 + noise-model draws {gr:.2e}")
-    assert ge < max(1e-4, 3 * gr)
+    eng = [t[3]["R_tok"] for t in table]
+    ref = [t[4]["explicit"]["R_tok"] for t in table]
+    print(f"[H4096/S2048 fp32 explicit, {len(table)} seeds] geometric mean: engine {gm(eng):.2e} vs reference arithmetic in fp32 {gm(ref):.2e} "
+          f"(ratio {gm(eng) / gm(ref):.2f}); median: engine {statistics.median(eng):.2e} vs {statistics.median(ref):.2e} "
+          f"(ratio {statistics.median(eng) / statistics.median(ref):.2f}); instances under 1e-4: engine {sum(e < 1e-4 for e in eng)}, "
+          f"reference fp32 {sum(r < 1e-4 for r in ref)}")
+    for ws, ids_, eff, exp, gap in table:
+        assert max(eff.values()) < 1e-4, (ws, eff)
+        assert exp["R_tok"] < max(1e-4, 30 * max(ref)), (ws, exp)
+    assert len(table) >= 8
+    assert gm(eng) < max(1e-4, 3 * gm(ref))
+    assert statistics.median(eng) < max(1e-4, 3 * statistics.median(ref))
 
 
 def test_engine_s4096_config5_efficient_vs_oracle():

@@ -302,3 +302,26 @@ def test_llama_arena_reuse_and_graph_replay(eng_mod, dtype):
     assert torch.equal(g3["R_tok"], e3["R_tok"]) and torch.equal(g3["idx"].cpu().long(), tgt)
     with pytest.raises(ValueError):
         eng.explain(c, lengths=[S, S - 3], graph=True)
+
+
+def test_llama_graph_survives_arena_growth(eng_mod):
+    """a graph captured at a SMALL (B, S) must not be replayed into freed memory after a later, larger call re-allocated
+    the arena's buffers: graph small -> eager large (the arena grows, its old blocks return to the allocator and are overwritten by
+    fresh tensors) -> replay small.  The stale graph is dropped and re-captured (arena generation in the graph record)."""
+    cfg, W, ids, fx = llama_case("mid")
+    g = torch.Generator().manual_seed(11)
+    S = ids.shape[0]
+    small = torch.randint(0, cfg["vocab"], (1, S // 2), generator=g)
+    big = torch.randint(0, cfg["vocab"], (3, S), generator=g)
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=512)
+    ref_small = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=512).explain(small)
+    g1 = eng.explain(small, graph=True)
+    assert torch.equal(g1["R_tok"], ref_small["R_tok"])
+    gen0 = eng._arena.gen
+    r_big = eng.explain(big)                                  # grows every arena buffer
+    assert eng._arena.gen > gen0
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(16)]      # land on the freed blocks
+    g2 = eng.explain(small, graph=True)
+    assert torch.equal(g2["R_tok"], ref_small["R_tok"]) and torch.isfinite(g2["R_tok"]).all()
+    assert torch.isfinite(r_big["R_tok"]).all()
+    del junk

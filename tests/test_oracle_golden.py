@@ -101,3 +101,19 @@ def test_llama_oracle_vs_reference(name):
     assert nmax(oe["R_tok"], fx["eff_R_tok"]) < 5e-6             # vs reference lxt.efficient
     # conservation sanity: sum of token relevance stays O(logit)
     assert abs(float(o64["R_tok"].sum())) < 10 * abs(float(fx["logit"])) + 1.0
+
+
+def test_oracle_kv_chunk_equals_unchunked():
+    """the head-chunked attention of the oracle (kv_chunk: scores / probabilities recomputed per kv group in the backward instead of kept
+    for every layer -- what lets the fp64 oracle run BASELINE config 5's 32 / 8 heads at S = 4096 on a 62-GB host) is the same arithmetic
+    as the un-chunked oracle that the fixtures pin: bit-identical relevance in both modes"""
+    import torch
+    from oracle import llama as ol
+    cfg = dict(hidden=64, inter=128, n_layers=2, n_heads=8, n_kv=4, head_dim=16, vocab=100, rope_theta=10000.0, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=3)
+    ids = torch.randint(0, 100, (40,), generator=torch.Generator().manual_seed(1))
+    for mode in ("explicit", "efficient"):
+        a = ol.explain(cfg, W, ids=ids, mode=mode, dtype=torch.float64)
+        for kc in (1, 3):
+            b = ol.explain(cfg, W, ids=ids, mode=mode, dtype=torch.float64, kv_chunk=kc)
+            assert a["idx"] == b["idx"] and torch.equal(a["R_tok"], b["R_tok"]) and a["layer_R"] == b["layer_R"]

@@ -18,9 +18,12 @@ SITES = ["lin", "add", "qk", "mask", "pv", "rope", "ALL"]
 
 
 def main():
+    """usage: explicit_site_sensitivity.py [WSEED IDSEED]   (default: the first instance of tests/test_baseline_size_gpu.py)"""
+    ws, is_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else T.SEEDS[0]
+    print(f"# one stabiliser site at a time, H4096/I14336/d128/S2048, 2 layers, seeds ({ws},{is_}); {torch.get_num_threads()} host threads", flush=True)
     cfg = dict(T.CFG)
-    W = ol.random_weights(cfg, seed=T.WSEED)
-    ids = torch.randint(0, cfg["vocab"], (T.S,), generator=torch.Generator().manual_seed(T.IDSEED))
+    W = ol.random_weights(cfg, seed=ws)
+    ids = torch.randint(0, cfg["vocab"], (T.S,), generator=torch.Generator().manual_seed(is_))
     caches = {}
     for dt in (torch.float64, torch.float32):
         Wd = ol.cast_weights(W, dt)
