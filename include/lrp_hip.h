@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -72,6 +72,17 @@ int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
  * ref: lxt/explicit/functional.py:355-364 (backward of linear_epsilon_fn: `relevance_norm @ weight`). */
 int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int dtype, int out_dtype, void* stream);
+
+/* lrp_linear_stream_fwd: z[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) for 1 <= M <= 256 rows in ONE launch -- the Linear forward in its
+ * HBM-bound regime as a narrow-N, full-K weight-streaming MFMA kernel (csrc/linear_stream.hip): a workgroup owns 64 rows of W and the
+ * whole K range, W goes HBM -> registers exactly once (no split-K, no fp32 slabs, no second launch), x is staged through LDS, 16-row
+ * blocks past M are not multiplied.  bf16 operands, out bf16 / fp32, K a multiple of 512, ldx / ldw multiples of 8 elements, operands
+ * below 2^30 elements; anything else returns LRP_ESHAPE / LRP_EALIGN.  lrp_linear_stream_ok(M, N, K, ldx, ldw) = 1 when the kernel
+ * applies AND its ceil(N / 64) workgroups fill the chip (>= 192); otherwise the caller uses lrp_gemm_skinny.
+ * ref: lxt/explicit/functional.py:345-351 (forward of linear_epsilon_fn), lxt/explicit/rules.py:188-205. */
+int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ldw);
+int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
+                          int64_t ldz, int dtype, int out_dtype, void* stream);
 
 /* lrp_gemm_skinny: the same two products with SPLIT-K, for problems whose 256 x 256 tile count alone leaves CUs idle: 1 <= M <= 256 rows
  * (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic

@@ -419,8 +419,37 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const bf16_t*
     if (q >= (int64_t)M * nq) return;
     const int m = (int)(q / nq), n = (int)(q % nq) * 4;
     const float* p = ws + (int64_t)m * ldw + n;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(p);
-    for (int s_ = 1; s_ < splits; ++s_) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s_ * slab);
+    // eight slab loads in flight per lane (the kernel is pure latency: a few MB out of L2 / Infinity Cache right behind the GEMM that wrote
+    // them), summed in slab order: the result does not depend on the unroll
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s_ = 0;
+    for (; s_ + 8 <= splits; s_ += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(s_ + u) * slab);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s_ + 2 <= splits; s_ += 2) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (int64_t)s_ * slab), v1 = *reinterpret_cast<const f32x4*>(p + (int64_t)(s_ + 1) * slab);
+        acc += v0;
+        acc += v1;
+    }
+    if (s_ < splits) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)s_ * slab);
+    if (n + 3 < N && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        if constexpr (sizeof(TO) == 2) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[e] + (bias ? to_f32(bias[n + e]) : 0.f));
+            *reinterpret_cast<bf16x4*>(out + (int64_t)m * ldo + n) = o;
+        } else {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[e] + (bias ? to_f32(bias[n + e]) : 0.f);
+            *reinterpret_cast<f32x4*>(out + (int64_t)m * ldo + n) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (n + e < N) out[(int64_t)m * ldo + n + e] = from_f32<TO>(acc[e] + (bias ? to_f32(bias[n + e]) : 0.f));

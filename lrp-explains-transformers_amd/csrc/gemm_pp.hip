@@ -79,7 +79,10 @@ struct PPEpi {
     int act;
 };
 
-template <typename TO, bool NN, int EPI, int ACT>
+// SK ("skinny"): the problem has ONE row of tiles and fewer than 241 rows (the HBM-bound regime of the Linear eps-rule, M <~ 160): 16-row
+// blocks of the 256-row tile that lie past M are not multiplied -- the full tile's 2 x 256 x 256 x 64 FLOP per K tile would make a
+// 16-row problem MATRIX-pipe-bound (13.7 us per workgroup for a [14336, 4096] weight) under the 15-us weight stream it serves.
+template <typename TO, bool NN, int EPI, int ACT, bool SK = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
@@ -165,6 +168,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         cB[2] = cB[3] = 0;
     }
 
+    // SK: live 16-row blocks of this wave's two row halves (wave-uniform: g comes from readfirstlane)
+    int nb[2] = {4, 4};
+    if constexpr (SK) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = (M - (m0 + g * 128 + a * 64) + 15) >> 4;
+            nb[a] = r < 0 ? 0 : (r > 4 ? 4 : r);
+        }
+    }
     f32x4 acc[2][4][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -218,8 +230,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #define PP_MMA(AH)                                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks].v, fa[i][ks], acc[AH][i][j], 0, 0, 0);
+            if (!SK || i < nb[AH])                                                                \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                    acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks].v, fa[i][ks], acc[AH][i][j], 0, 0, 0);
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     // one K tile out of buffer BUF (compile-time); t is the running K-tile index.  The M phases are BARE MFMA streams.
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-template <typename TO, bool NN, int EPI, int ACT = 0>
+template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
@@ -479,7 +492,7 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 #else
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
-    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT>;
+    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
                        ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
@@ -494,6 +507,14 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st) {
     const PPEpi ep{};
+    if (M <= 240) {          // one row of tiles with at least one dead 16-row block: the skinny instantiations
+        if (out_dtype == LRP_F32) {
+            if (nn) return launch_pp_t<float, true, 0, 0, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+            return launch_pp_t<float, false, 0, 0, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+        }
+        if (nn) return launch_pp_t<bf16_t, true, 0, 0, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+        return launch_pp_t<bf16_t, false, 0, 0, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
+    }
     if (out_dtype == LRP_F32) {
         if (nn) return launch_pp_t<float, true, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
         return launch_pp_t<float, false, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);

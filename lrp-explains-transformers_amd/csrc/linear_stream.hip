@@ -1,0 +1,248 @@
+// linear_stream.hip -- K1 (Linear forward z = x W^T + b, ref lxt/explicit/functional.py:345-351, rules.py:188-205) in its HBM-BOUND regime,
+// M <= 256 rows (bf16 arithmetic intensity ~2 M FLOP/B), as ONE launch: a narrow-N, FULL-K weight-streaming MFMA kernel.
+//
+// Why not the split-K ping-pong GEMM (lrp_gemm_skinny) here: it needs a second launch that sums fp32 slabs (5-9 us against a 15-us weight
+// stream) and its 256-row tile multiplies 240 rows of zeros at M = 16.  Here a workgroup (4 waves) owns 64 rows of W and the whole K range:
+//   * W is read ONCE, straight from HBM into registers in MFMA operand layout -- wave w owns W rows n0 + 16 w .. + 15, lane l holds 16 bytes
+//     of row (l & 15) at k = 64 t + 32 ks + 8 (l >> 4): no LDS hop for an operand nobody shares.  `buffer_load_dwordx4 ... nt` (streamed
+//     once, one CU), a register ring of LS_WD = 8 K tiles (16 loads = 16 KiB per wave, 64 KiB per workgroup in flight: the ~50 KB per CU
+//     that 25 GB/s per CU x ~2 us of loaded HBM latency asks for);
+//   * x (M rows, L2-resident, shared by the 4 waves) is staged per K tile through an LDS ring by buffer_load .. lds (8 rows x 128 B per
+//     wave instruction, chunk ^ (row & 7) swizzle on the source side: the A-operand image of gemm_pp.hip, conflict-free for the
+//     16-row ds_read_b128 fragments), XD tiles ahead, ring of XD + 2 tiles, ONE s_barrier per K tile;
+//   * every wait is a hand-counted s_waitcnt: loads retire in order, so "x(t) has landed" = "all but the XD (P + 2) younger VMEM operations
+//     have retired" -- which also covers W(t), issued 8 tiles earlier.  The last 8 tiles are peeled: nothing is fetched past K.
+//   * 16-row blocks past M are not multiplied (nb live blocks of the MBMAX the instantiation has accumulators for).
+// Grid: ceil(N / 64) workgroups; the host uses the kernel when that fills the chip (>= 192) and K is a multiple of 512.
+// D = mfma(Wfrag, xfrag): lane l holds z[m = 16 i + (l & 15)][n = n0 + 16 w + 4 (l >> 4) + e].
+#include "common.hpp"
+
+namespace {
+
+constexpr int LS_KT = 64;      // K elements per K tile
+constexpr int LS_WD = 8;       // K tiles of W in flight per wave (register ring)
+typedef __attribute__((address_space(3))) void* ls_lds_ptr_t;
+
+template <int MBMAX> struct LSCfg {
+    static constexpr int XD = (MBMAX >= 16) ? 2 : 3;               // x prefetch distance in K tiles
+    static constexpr int NBUF = XD + 2;                            // LDS ring: tile t + XD is written while tiles t - 1, t may still be read
+    static constexpr int P = MBMAX / 2;                            // 1-KiB staging pieces (8 rows x 128 B) per wave per K tile
+    static constexpr int XTILE = MBMAX * 16 * 128;                 // bytes of one x tile
+    static constexpr int BS = MBMAX < 4 ? MBMAX : 4;               // row blocks per LDS read batch
+    static constexpr int NBATCH = MBMAX / BS;
+    static constexpr int VMC = XD * (P + 2);                       // VMEM operations younger than x(t) at the wait of tile t (steady state)
+};
+// the same count inside the peeled last block (static s = position in the block; no W loads, x stages only while t + XD < nkt)
+template <int MBMAX> constexpr int ls_last_vmc(int s) {
+    constexpr int XD = LSCfg<MBMAX>::XD, P = LSCfg<MBMAX>::P;
+    int c = 0;
+    for (int j = s - XD + 1; j <= s; ++j) c += (j <= 7 - XD) ? P : 0;      // x stages issued at (relative) iterations s - XD + 1 .. s
+    for (int j = s - XD; j <= s - 1; ++j) c += (j < 0) ? 2 : 0;            // W loads issued at the end of iterations s - XD .. s - 1
+    return c;
+}
+
+template <int V> struct LSI { static constexpr int value = V; };
+template <int I, int N, typename F> LRP_DEVICE void ls_for(F&& f) {
+    if constexpr (I < N) {
+        f(LSI<I>{});
+        ls_for<I + 1, N>(static_cast<F&&>(f));
+    }
+}
+
+#define LS_LOADW(dst, voff, rs, soff) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
+#define LS_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <typename TO, int MBMAX>
+__global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, TO* __restrict__ z, const bf16_t* __restrict__ bias, int M, int N, int K,
+    int64_t ldx, int64_t ldw, int64_t ldz) {
+    using C = LSCfg<MBMAX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 64;
+    const int nkt = K / LS_KT;
+    int nb = (M + 15) >> 4;
+    nb = nb > MBMAX ? MBMAX : nb;
+
+    // ---- W: raw buffer over the whole weight (rows past N read as zero), per-lane offset relative to row n0
+    u32x4 rsW;
+    {
+        const uint64_t a = (uint64_t)(uintptr_t)W;
+        rsW[0] = (uint32_t)a;
+        rsW[1] = (uint32_t)(a >> 32) & 0xffffu;
+        rsW[2] = (uint32_t)(((int64_t)(N - 1) * ldw + K) * 2);
+        rsW[3] = 0x00020000u;
+    }
+    const uint32_t voW = (uint32_t)((int64_t)(16 * wave + (lane & 15)) * ldw * 2) + (uint32_t)((lane >> 4) << 4);
+    const uint32_t soW = (uint32_t)((int64_t)n0 * ldw * 2);
+
+    // ---- x: LDS-DMA pieces of 8 rows x 128 B; lane l -> row l >> 3, LDS slot l & 7, source chunk slot ^ (row & 7)
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int voX = (int)(prow * ldx * 2) + ((pslot ^ prow) << 4);
+    auto stage_x = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < C::P; ++p) {
+            const int q = wave * C::P + p;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ls_lds_ptr_t)(smem + buf * C::XTILE + q * 1024), 16, voX,
+                                                     (int)((int64_t)(8 * q) * ldx * 2) + kt * 128, 0, 0);
+        }
+    };
+    // fragment of row block i, k-step ks: row 16 i + (l & 15), chunk (4 ks + (l >> 4)) ^ (row & 7)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(ls_lds_ptr_t)smem;
+    uint32_t cX[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) cX[ks] = lds0 + (uint32_t)((lane & 15) * 128) + (uint32_t)((((4 * ks + (lane >> 4)) ^ (lane & 7))) << 4);
+
+    f32x4 acc[MBMAX];
+#pragma unroll
+    for (int i = 0; i < MBMAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 wf[LS_WD][2];
+
+    // (variables that appear ONLY as inline-asm operands of a nested generic lambda are not captured implicitly by this clang: name them once)
+    auto load_w = [&](auto sc, int kt) {
+        constexpr int s = decltype(sc)::value;
+        (void)&wf; (void)&voW; (void)&rsW;
+        const uint32_t so = soW + (uint32_t)kt * 128u;
+        LS_LOADW(wf[s][0], voW, rsW, so);
+        LS_LOADW(wf[s][1], voW, rsW, so + 64u);
+    };
+
+    // ---- prologue: W(0 .. WD - XD - 1), then [x(v), W(WD - XD + v)] for v = 0 .. XD - 1 (the order the steady state continues)
+    ls_for<0, LS_WD - C::XD>([&](auto sc) { load_w(sc, decltype(sc)::value); });
+    ls_for<0, C::XD>([&](auto vc) {
+        constexpr int v = decltype(vc)::value;
+        stage_x(v, v);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(LSI<LS_WD - C::XD + v>{}, LS_WD - C::XD + v);
+    });
+
+    // one K tile: LAST = inside the peeled final block (static s decides what is still fetched and how much may be outstanding)
+    auto tile = [&](auto sc, auto lastc, int t) {
+        constexpr int s = decltype(sc)::value;
+        constexpr bool LAST = decltype(lastc)::value != 0;
+        if constexpr (!LAST || (s + C::XD < 8)) stage_x(t + C::XD, (t + C::XD) % C::NBUF);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LAST) asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(wf[s][0]), "+v"(wf[s][1]) : [cnt] "n"(ls_last_vmc<MBMAX>(s)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(wf[s][0]), "+v"(wf[s][1]) : [cnt] "n"(C::VMC) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t xb = (uint32_t)((t % C::NBUF) * C::XTILE);
+        const uint32_t a0 = cX[0] + xb, a1 = cX[1] + xb;
+        const bf16x8 w0 = __builtin_bit_cast(bf16x8, wf[s][0]), w1 = __builtin_bit_cast(bf16x8, wf[s][1]);
+        // units u = (ks, batch): BS fragment reads each, read one unit ahead
+        u32x4 xf[2][C::BS];
+        constexpr int U = 2 * C::NBATCH;
+        auto issue = [&](auto uc) {
+            constexpr int u = decltype(uc)::value, ks = u / C::NBATCH, b = u % C::NBATCH;
+            (void)&xf; (void)&a0; (void)&a1;
+            ls_for<0, C::BS>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                (void)&xf; (void)&a0; (void)&a1;
+                if constexpr (ks == 0) LS_DSRD(xf[u & 1][i], a0, (b * C::BS + i) * 2048);
+                else LS_DSRD(xf[u & 1][i], a1, (b * C::BS + i) * 2048);
+            });
+        };
+        issue(LSI<0>{});
+        ls_for<0, U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, ks = u / C::NBATCH, b = u % C::NBATCH;
+            (void)&xf;
+            if constexpr (u + 1 < U) {
+                issue(LSI<u + 1>{});
+                if constexpr (C::BS == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xf[u & 1][0]), "+v"(xf[u & 1][1]), "+v"(xf[u & 1][2]), "+v"(xf[u & 1][3]));
+                else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xf[u & 1][0]), "+v"(xf[u & 1][1]));
+            } else {
+                if constexpr (C::BS == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[u & 1][0]), "+v"(xf[u & 1][1]), "+v"(xf[u & 1][2]), "+v"(xf[u & 1][3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[u & 1][0]), "+v"(xf[u & 1][1]));
+            }
+            ls_for<0, C::BS>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, blk = b * C::BS + i;
+                if (blk < nb)
+                    acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ks == 0 ? w0 : w1, __builtin_bit_cast(bf16x8, xf[u & 1][i]), acc[blk], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (!LAST) load_w(sc, t + LS_WD);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int t0 = 0;
+    for (; t0 + LS_WD < nkt; t0 += LS_WD)
+        ls_for<0, LS_WD>([&](auto sc) { tile(sc, LSI<0>{}, t0 + decltype(sc)::value); });
+    ls_for<0, LS_WD>([&](auto sc) { tile(sc, LSI<1>{}, t0 + decltype(sc)::value); });
+
+    // ---- epilogue: lane holds z[16 i + (l & 15)][n0 + 16 w + 4 (l >> 4) + e]
+    const int ncol = n0 + 16 * wave + 4 * (lane >> 4);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ncol + e < N) bv[e] = to_f32(bias[ncol + e]);
+    }
+    const bool vec = (ncol + 3 < N) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < MBMAX; ++i) {
+        const int m = 16 * i + (lane & 15);
+        if (i < nb && m < M) {
+            const f32x4 v = acc[i] + bv;
+            TO* dst = z + (int64_t)m * ldz + ncol;
+            if (vec) {
+                if constexpr (sizeof(TO) == 4) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ncol + e < N) dst[e] = from_f32<TO>(v[e]);
+            }
+        }
+    }
+}
+
+template <typename TO, int MBMAX>
+int launch_stream(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
+                  hipStream_t st) {
+    using C = LSCfg<MBMAX>;
+    const size_t lds = (size_t)C::NBUF * C::XTILE;
+    auto kern = linear_stream_fwd_kernel<TO, MBMAX>;
+    LRP_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((N + 63) / 64), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (TO*)z, (const bf16_t*)bias, M, N, K,
+                       ldx, ldw, ldz);
+    return lrp_check_launch();
+}
+
+template <typename TO>
+int launch_stream_m(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
+                    hipStream_t st) {
+    const int nb = (M + 15) / 16;
+    if (nb <= 2) return launch_stream<TO, 2>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+    if (nb <= 4) return launch_stream<TO, 4>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+    if (nb <= 8) return launch_stream<TO, 8>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+    return launch_stream<TO, 16>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+}
+
+}  // namespace
+
+// can lrp_linear_stream_fwd serve the problem, and is it the right kernel for it?  bf16, 1 <= M <= 256 rows, K a multiple of 512 (the
+// 8-tile register ring), operands below 2^31 bytes, and enough 64-row workgroups to put one on (nearly) every CU
+extern "C" int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ldw) {
+    if (M < 1 || M > 256 || N < 1 || K < 512 || (K % 512)) return 0;
+    if ((ldx % 8) || (ldw % 8) || ldx < K || ldw < K) return 0;
+    if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return 0;
+    return (N + 63) / 64 >= 192;
+}
+
+extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                     int64_t ldz, int dtype, int out_dtype, void* stream) {
+    if (!x || !W || !z || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (ldx % 8) || (ldw % 8)) return LRP_EALIGN;
+    if (M > 256 || K < 512 || (K % 512) || ldx < K || ldw < K || (int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return LRP_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == LRP_F32) return launch_stream_m<float>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+    return launch_stream_m<bf16_t>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+}

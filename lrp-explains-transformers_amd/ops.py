@@ -624,14 +624,42 @@ def linear_smallm_dgrad(g, W, z=None, x=None, eps=0.0, relevance_in=False, relev
     return out
 
 
+STREAM_FWD = True        # module attribute (A/B measurements): False sends every M <= 256 forward to the split-K skinny path
+
+
+def linear_stream_ok(x2, W):
+    """does the one-launch weight-streaming forward (lrp_linear_stream_fwd: narrow-N, full-K, no split-K slabs) serve z = x2 W^T?  bf16,
+    M <= 256 rows, K % 512 == 0, contiguous 16-byte aligned rows, and ceil(N / 64) workgroups that fill the chip"""
+    if not STREAM_FWD or x2.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or x2.dim() != 2 or W.dim() != 2:
+        return False
+    if x2.stride(1) != 1 or W.stride(1) != 1 or x2.data_ptr() % 16 or W.data_ptr() % 16:
+        return False
+    return bool(lib.lrp_linear_stream_ok(x2.shape[0], W.shape[0], x2.shape[1], x2.stride(0), W.stride(0)))
+
+
+def linear_stream_fwd(x2, W, bias=None, out=None, out_dtype=None):
+    """z[M,N] = x2[M,K] @ W[N,K]^T (+ bias), M <= 256, in ONE launch: every workgroup streams 64 rows of W over the whole K range"""
+    M, K = x2.shape
+    N = W.shape[0]
+    same(x2, W)
+    if out is None:
+        out = torch.empty(M, N, device=x2.device, dtype=out_dtype or x2.dtype)
+    check(lib.lrp_linear_stream_fwd(p(x2), p(W), p(aux(bias, x2, N)), p(out), M, N, K, x2.stride(0), W.stride(0), out.stride(0), dt(x2),
+                                    _DT[out.dtype], stream()), "lrp_linear_stream_fwd")
+    return out
+
+
 def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
     """z[M,N] = x2[M,K] @ W[N,K]^T (+ bias) on the kernel that fits M (ref: lxt/explicit/functional.py:351):
+       M <= 256 rows, bf16, K % 512 == 0, N >= 192 * 64 : one-launch weight-streaming kernel (narrow N, full K: no slabs, no second launch)
        M <= 256 rows, bf16, K % 64 == 0 : split-K skinny path of the ping-pong GEMM (W streamed once by all CUs)
        M <= 16 otherwise                : W-streaming small-M kernels (fp32, odd K)
        else                             : the MFMA GEMM (lrp_gemm_nt)"""
     M, K = x2.shape
     N = W.shape[0]
     odt = out_dtype or (out.dtype if out is not None else x2.dtype)
+    if M <= SKINNY_MAX and linear_stream_ok(x2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
+        return linear_stream_fwd(x2, W, bias, out=out, out_dtype=odt)
     if splitk_ok(M, N, K) and gemm_nn_ok(x2, W):
         if out is None:
             out = torch.empty(M, N, device=x2.device, dtype=odt)

@@ -112,6 +112,65 @@ def test_gemm_skinny_split_k(ops, M, nn):
         assert not torch.isnan(out).any() and nmax(out, ref) < tol, (M, nn, odt)
 
 
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 33, 64, 100, 128, 160, 256])
+def test_linear_stream_fwd(ops, M):
+    """lrp_linear_stream_fwd (round 4: the Linear forward in its HBM-bound regime as ONE launch -- narrow N, full K, W streamed HBM ->
+    registers once, x through an LDS ring, 16-row blocks past M not multiplied): every M bucket (2 / 4 / 8 / 16 row blocks), ragged N (not a
+    multiple of 64), K = 512 (prologue + peeled last block only) and 4096 (steady state), strided x, bias, bf16 and fp32 outputs; vs fp64 on
+    the same bf16 operands, and bit-identical row by row to the call with fewer rows (a row's result does not depend on its neighbours)"""
+    g = torch.Generator().manual_seed(100 + M)
+    for (N, K) in ((12352 + 24, 512), (14336, 4096), (12288 + 2, 1536)):
+        xs = torch.randn(M, K + 64, generator=g).bfloat16().cuda()
+        x = xs[:, :K]                                                        # row pitch K + 64
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        bias = torch.randn(N, generator=g).bfloat16().cuda() if (M + K // 512) % 2 else None
+        assert ops.linear_stream_ok(x, W)
+        ref = f64(x) @ f64(W).T + (f64(bias) if bias is not None else 0.0)
+        for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL[torch.bfloat16])):
+            out = torch.full((M, N), float("nan"), dtype=odt, device="cuda")
+            ops.linear_stream_fwd(x, W, bias, out=out)
+            assert not torch.isnan(out).any() and nmax(out, ref) < tol, (M, N, K, odt, nmax(out, ref))
+        # through the dispatcher, and row independence
+        z = ops.linear_fwd(x, W, bias)
+        assert torch.equal(z, out)
+        if M > 1:
+            z1 = ops.linear_stream_fwd(x[: M - 1], W, bias)
+            assert torch.equal(z1, z[: M - 1])
+    # shapes the kernel refuses go to the split-K path (K not a multiple of 512; too few 64-row workgroups)
+    assert not ops.linear_stream_ok(torch.empty(4, 4096 + 64, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096 + 64, dtype=torch.bfloat16, device="cuda"))
+    assert not ops.linear_stream_ok(torch.empty(4, 4096, dtype=torch.bfloat16, device="cuda"), torch.empty(4096, 4096, dtype=torch.bfloat16, device="cuda"))
+
+
+def test_gemm_big_m_row_chunks(ops):
+    """activations beyond 2^30 elements (32-bit buffer offsets of the ping-pong kernel): the library issues the launch in row chunks --
+    same kernel, same layout, no W^T fallback (B >= 19 prompts at S = 2048 on the gate/up dgrad operand).  NN form on a
+    [K = 28672 + pad] operand with 37632 rows (two chunks: 37120 + 512): equal to the two halves computed separately, spot-checked vs fp64"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, K, N = 37632, 28672, 1024
+    a_full = torch.randn(M, K + 64, generator=g, device="cuda", dtype=torch.float32).bfloat16()
+    a = a_full[:, :K]
+    assert M * a.stride(0) >= 2 ** 30
+    w = (torch.randn(K, N, generator=g, device="cuda") * K ** -0.5).bfloat16()
+    assert ops.gemm_nn_ok(a, w)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nn_2d(a, w, out)
+    assert not torch.isnan(out).any()
+    lo = torch.empty(18816, N, dtype=torch.bfloat16, device="cuda")
+    hi = torch.empty(M - 18816, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nn_2d(a[:18816], w, lo)
+    ops.gemm_nn_2d(a[18816:], w, hi)
+    assert torch.equal(out[:18816], lo) and torch.equal(out[18816:], hi)
+    rows = torch.tensor([0, 1, 37119, 37120, 37121, M - 1], device="cuda")
+    assert nmax(out[rows], f64(a[rows]) @ f64(w)) < TOL[torch.bfloat16]
+    # NT form through lrp_gemm_nt
+    wt = (torch.randn(512, K, generator=g, device="cuda") * K ** -0.5).bfloat16()
+    o2 = torch.full((M, 512), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt_2d(a, wt, o2)
+    assert not torch.isnan(o2).any() and nmax(o2[rows], f64(a[rows]) @ f64(wt).T) < TOL[torch.bfloat16]
+    del a_full, a, out, o2
+    torch.cuda.empty_cache()
+
+
 def test_gemm_skinny_single_split_and_big_n(ops):
     """tile counts that fill the chip alone (one split: the plain kernel writes the output, no slabs) and the many-tile split case"""
     g = torch.Generator().manual_seed(5)
