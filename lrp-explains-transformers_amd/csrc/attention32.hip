@@ -761,11 +761,607 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     store_rows(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, hi);
 }
 
+
+// =====================================================================================================================
+// head_dim 256 (Gemma-3: 8 query / 4 kv heads of d = 256, sliding window 1024 on 5 of 6 layers; ref lxt/efficient/models/gemma3.py:11-19,
+// lxt/efficient/patches.py:193-203) on the same 32x32x16 / transpose-read form -- round 4.  What changes against d = 128:
+//   * a tile row is 512 B (32 chunks of 16 B; the swizzle c ^ rot(r) acts on the low four chunk bits, so both read kinds stay
+//     conflict-free), a tile is 32 column-side rows (16 KiB as before), a staging piece (1 KiB) is 2 rows;
+//   * 16 contraction steps over the head dim and 8 head-dim blocks per out^T accumulator: 128 accumulator registers per output, so the
+//     kernels run ONE wave per SIMD (4-wave workgroups, up to 512 registers per lane) and hide LDS latency inside the wave: fragment reads
+//     run a 3-deep ring ahead of their MFMAs, transpose reads are issued one 8-read unit (4 head-dim blocks of one 16-row group) ahead;
+//   * addresses: ONE per-lane base per read kind, the step / head-dim block enters through an XOR (chunk bits) and an immediate.
+// No head-transposed copies in HBM for d = 256 any more (lrp_attn_needs_transposed(bf16, 256) = 0).
+// =====================================================================================================================
+namespace d256 {
+
+constexpr int D2 = 256, KP2 = 512, CT2 = 32, TILE2 = CT2 * KP2, NK2 = 16, ND2 = 8, NW2 = 4;
+
+// stage a [32 rows][512 B] tile: 16 pieces of 2 rows, 4 per wave (4-wave workgroups); rows >= S read as zero
+LRP_DEVICE void stage_tile2(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(S - 1) * ld + D2) * 2), 0x00020000);
+    const int rl = lane >> 5, slot = lane & 31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int grp = g * NW2 + wave;                               // piece: rows 2 grp, 2 grp + 1
+        const int rot = ((2 * (wave & 1) + rl) << 2) | ((2 * g + (wave >> 1)) & 3);      // rot4(2 grp + rl)
+        const int voff = (int)(rl * ld * 2) + ((slot ^ rot) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + grp * 1024), 16, voff, (int)((int64_t)(row0 + 2 * grp) * ld * 2), 0, 0);
+    }
+}
+// the same image for a wave-private 32-row block (all 16 pieces by one wave)
+LRP_DEVICE void stage_block2(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(S - 1) * ld + D2) * 2), 0x00020000);
+    const int rl = lane >> 5, slot = lane & 31;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int rot = ((2 * (g & 1) + rl) << 2) | ((g >> 1) & 3);
+        const int voff = (int)(rl * ld * 2) + ((slot ^ rot) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + g * 1024), 16, voff, (int)((int64_t)(row0 + 2 * g) * ld * 2), 0, 0);
+    }
+}
+// per-lane bases (relative to a tile): row fragment of step 0, transpose read of head-dim block 0 (two halves)
+LRP_DEVICE uint32_t rm_base(int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    return (uint32_t)(l31 * KP2 + ((hi ^ rot4(l31)) << 4));
+}
+LRP_DEVICE uint32_t tr_base(int lane, int half) {
+    const int l31 = lane & 31, hi = lane >> 5, i16 = lane & 15;
+    const int r = half * 8 + 4 * hi + (i16 >> 2);
+    const int chunk = ((l31 >> 4) << 1) + ((i16 & 3) >> 1);
+    return (uint32_t)(r * KP2 + ((chunk ^ rot4(r)) << 4) + 8 * (i16 & 1));
+}
+// step ks of the row fragment: chunk 2 ks + hi -> XOR ks << 5; head-dim block db of a transpose read: chunk 4 db + .. -> XOR db << 6
+template <int X> LRP_DEVICE uint32_t xor_addr(uint32_t a0) {
+    if constexpr (X == 0) return a0;
+    else {
+        uint32_t r;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(X), "v"(a0));
+        return r;
+    }
+}
+LRP_DEVICE void load_row_frags2(bf16x8* f, const bf16_t* base, int64_t ld, int row, int S, int hi) {
+    const bool ok = row < S;
+#pragma unroll
+    for (int ks = 0; ks < NK2; ++ks) {
+        if (ok) f[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)row * ld + ks * 16 + hi * 8);
+        else {
+            u32x4 z = {0, 0, 0, 0};
+            f[ks] = __builtin_bit_cast(bf16x8, z);
+        }
+    }
+}
+LRP_DEVICE void store_rows2(bf16_t* base, int64_t ld, int row, int S, const f32x16* acc, float mul, int hi) {
+    if (row >= S) return;
+#pragma unroll
+    for (int db = 0; db < ND2; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[db][4 * i + e] * mul);
+            *reinterpret_cast<bf16x4*>(base + (int64_t)row * ld + db * 32 + 8 * i + 4 * hi) = v;
+        }
+}
+// one unit = the 8 transpose reads (4 head-dim blocks x 2 halves) of 16-row group J, head-dim blocks 4 DBH .. 4 DBH + 3, tile byte offset OFF
+#define A2_UNIT(dst, a0, a1, J, DBH, OFF)                                                                            \
+    {                                                                                                                \
+        const uint32_t b0_ = xor_addr<((DBH) * 4 + 0) << 6>(a0), c0_ = xor_addr<((DBH) * 4 + 0) << 6>(a1);           \
+        const uint32_t b1_ = xor_addr<((DBH) * 4 + 1) << 6>(a0), c1_ = xor_addr<((DBH) * 4 + 1) << 6>(a1);           \
+        const uint32_t b2_ = xor_addr<((DBH) * 4 + 2) << 6>(a0), c2_ = xor_addr<((DBH) * 4 + 2) << 6>(a1);           \
+        const uint32_t b3_ = xor_addr<((DBH) * 4 + 3) << 6>(a0), c3_ = xor_addr<((DBH) * 4 + 3) << 6>(a1);           \
+        A32_RDTR(dst[0][0], b0_, (OFF) + (J) * 16 * KP2); A32_RDTR(dst[0][1], c0_, (OFF) + (J) * 16 * KP2);          \
+        A32_RDTR(dst[1][0], b1_, (OFF) + (J) * 16 * KP2); A32_RDTR(dst[1][1], c1_, (OFF) + (J) * 16 * KP2);          \
+        A32_RDTR(dst[2][0], b2_, (OFF) + (J) * 16 * KP2); A32_RDTR(dst[2][1], c2_, (OFF) + (J) * 16 * KP2);          \
+        A32_RDTR(dst[3][0], b3_, (OFF) + (J) * 16 * KP2); A32_RDTR(dst[3][1], c3_, (OFF) + (J) * 16 * KP2);          \
+    }
+#define A2_UNITV(t) "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1])
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, d = 256: row side = 32 queries per wave, 32-key K / V tiles stream
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+    float* __restrict__ lse, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+    int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BQ = NW2 * 32, STAGE = 2 * TILE2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;
+    const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
+    if (q0 + BQ <= q_begin) return;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D2;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D2;
+
+    bf16x8 qf[NK2];
+    load_row_frags2(qf, q + (int64_t)b * S * ldq + (int64_t)h * D2, ldq, qi, S, hi);
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+    f32x16 oacc[ND2];
+#pragma unroll
+    for (int db = 0; db < ND2; ++db) oacc[db] = zero16();
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c1 = scale * LRP_LOG2E;
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT2) * CT2; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile2(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile2(vb_, ldv, kt0, S, sb + TILE2, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t arm = lds_addr(smem) + rm_base(lane), at0 = lds_addr(smem) + tr_base(lane, 0), at1 = lds_addr(smem) + tr_base(lane, 1);
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT2) {
+        if (kt0 + CT2 < kend) stage(kt0 + CT2, cur ^ 1);
+        const bool dead = (causal && kt0 > qw + 31) || (window > 0 && kt0 + CT2 - 1 <= qw - window);
+        if (!dead) {
+            // ---- S^T of the 32 keys: 16 steps, fragments read two steps ahead
+            f32x16 st = zero16();
+            bf16x8 fk[3];
+            A32_RD128(fk[0], arm, 0);
+            { const uint32_t a_ = xor_addr<1 << 5>(arm); A32_RD128(fk[1], a_, 0); }
+            sfor<0, NK2>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                (void)&fk; (void)&arm;
+                if constexpr (ks + 2 < NK2) {
+                    { const uint32_t a_ = xor_addr<(ks + 2) << 5>(arm); A32_RD128(fk[nx], a_, 0); }
+                    A32_WAIT(2, "+v"(fk[cu]));
+                } else if constexpr (ks + 1 < NK2) {
+                    A32_WAIT(1, "+v"(fk[cu]));
+                } else {
+                    A32_WAIT(0, "+v"(fk[cu]));
+                }
+                st = mfma32(fk[cu], qf[ks], st);
+                A32_FENCE();
+            });
+            // ---- first V^T unit in flight under the softmax
+            u32x2 tv[2][4][2];
+            A2_UNIT(tv[0], at0, at1, 0, 0, TILE2);
+            A32_FENCE();
+            const bool need_mask = (kt0 + CT2 > S) || (causal && kt0 + CT2 - 1 > qw) || (window > 0) || (row_lo != nullptr);
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[r] = visible(qi, kt0 + crow(r, hi), S, causal, window, ivlo, ivhi) ? st[r] : -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = half_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float nm2 = -m_use * c1;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(__builtin_fmaf(st[r], c1, nm2));
+                st[r] = p;
+                rs += p;
+            }
+            rs = half_sum(rs);
+            if (__any(m_new != m_run)) {
+                const float alpha = fast_exp2((m_run - m_use) * c1);
+                l_run = l_run * alpha + rs;
+#pragma unroll
+                for (int db = 0; db < ND2; ++db) oacc[db] *= alpha;
+            } else l_run += rs;
+            m_run = m_new;
+            const bf16x8 p0 = pack8(st, 0), p1 = pack8(st, 1);
+            A32_FENCE();
+            // ---- O^T += V^T P^T: units (j, dbh) = (0,0) (0,1) (1,0) (1,1), next unit's reads issued before this unit's MFMAs
+            A2_UNIT(tv[1], at0, at1, 0, 1, TILE2);
+            A32_WAIT(8, A2_UNITV(tv[0]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) oacc[d4] = mfma32(join_tr(tv[0][d4][0], tv[0][d4][1]), p0, oacc[d4]);
+            A32_FENCE();
+            A2_UNIT(tv[0], at0, at1, 1, 0, TILE2);
+            A32_WAIT(8, A2_UNITV(tv[1]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) oacc[4 + d4] = mfma32(join_tr(tv[1][d4][0], tv[1][d4][1]), p0, oacc[4 + d4]);
+            A32_FENCE();
+            A2_UNIT(tv[1], at0, at1, 1, 1, TILE2);
+            A32_WAIT(8, A2_UNITV(tv[0]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) oacc[d4] = mfma32(join_tr(tv[0][d4][0], tv[0][d4][1]), p1, oacc[d4]);
+            A32_FENCE();
+            A32_WAIT(0, A2_UNITV(tv[1]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) oacc[4 + d4] = mfma32(join_tr(tv[1][d4][0], tv[1][d4][1]), p1, oacc[4 + d4]);
+            A32_FENCE();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+            arm += delta; at0 += delta; at1 += delta;
+        }
+        cur ^= 1;
+    }
+    const float inv = (l_run > 0.f) ? 1.f / l_run : 0.f;
+    store_rows2(o + (int64_t)b * S * ldo + (int64_t)h * D2, ldo, qi, S, oacc, inv, hi);
+    if (hi == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run * scale + __logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ, d = 256: row side = 32 queries per wave; 32-key K / V tiles stream
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool EXPL>
+__global__ __launch_bounds__(NW2 * 64, 1) void dq256_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
+    const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
+    int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
+    int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BQ = NW2 * 32, STAGE = 2 * TILE2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rep = Hq / Hkv, nqb = (S + BQ - 1) / BQ;
+    int bhk, item;
+    if (!xcd_group_decode(blockIdx.x, B * Hkv, rep * nqb, bhk, item)) return;
+    const int b = bhk / Hkv, hk = bhk % Hkv, h = hk * rep + item % rep;
+    const int qblk = nqb - 1 - item / rep;
+    const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
+    if (q0 + BQ <= q_begin) return;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D2;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D2;
+
+    bf16x8 qf[NK2], gf[NK2];
+    load_row_frags2(qf, q + (int64_t)b * S * ldq + (int64_t)h * D2, ldq, qi, S, hi);
+    load_row_frags2(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D2, ldg, qi, S, hi);
+    const float lse2 = ((qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f) * LRP_LOG2E;
+    const float Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    int ivlo = 0, ivhi = S;
+    if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
+    f32x16 acc[ND2];
+#pragma unroll
+    for (int db = 0; db < ND2; ++db) acc[db] = zero16();
+    const float c1 = scale * LRP_LOG2E;
+    int kend = S;
+    if (causal) kend = min(S, q0 + BQ);
+    int kbeg = 0;
+    if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT2) * CT2; }
+
+    auto stage = [&](int kt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile2(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile2(vb_, ldv, kt0, S, sb + TILE2, wave, lane);
+    };
+    if (kbeg < kend) stage(kbeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t arm = lds_addr(smem) + rm_base(lane), at0 = lds_addr(smem) + tr_base(lane, 0), at1 = lds_addr(smem) + tr_base(lane, 1);
+    int cur = 0;
+    for (int kt0 = kbeg; kt0 < kend; kt0 += CT2) {
+        if (kt0 + CT2 < kend) stage(kt0 + CT2, cur ^ 1);
+        const bool dead = (causal && kt0 > qw + 31) || kt0 >= S || (window > 0 && kt0 + CT2 - 1 <= qw - window);
+        if (!dead) {
+            // ---- S^T and dP^T: 16 steps x {K fragment, V fragment}, read two steps ahead
+            f32x16 st = zero16(), dp = zero16();
+            bf16x8 fk[3], fv[3];
+            A32_RD128(fk[0], arm, 0); A32_RD128(fv[0], arm, TILE2);
+            { const uint32_t a_ = xor_addr<1 << 5>(arm); A32_RD128(fk[1], a_, 0); A32_RD128(fv[1], a_, TILE2); }
+            sfor<0, NK2>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                (void)&fk; (void)&fv; (void)&arm;
+                if constexpr (ks + 2 < NK2) {
+                    { const uint32_t a_ = xor_addr<(ks + 2) << 5>(arm); A32_RD128(fk[nx], a_, 0); A32_RD128(fv[nx], a_, TILE2); }
+                    A32_WAIT(4, "+v"(fk[cu]), "+v"(fv[cu]));
+                } else if constexpr (ks + 1 < NK2) {
+                    A32_WAIT(2, "+v"(fk[cu]), "+v"(fv[cu]));
+                } else {
+                    A32_WAIT(0, "+v"(fk[cu]), "+v"(fv[cu]));
+                }
+                st = mfma32(fk[cu], qf[ks], st);
+                dp = mfma32(fv[cu], gf[ks], dp);
+                A32_FENCE();
+            });
+            // ---- first K^T unit in flight under the element-wise work
+            u32x2 tk[2][4][2];
+            A2_UNIT(tk[0], at0, at1, 0, 0, 0);
+            A32_FENCE();
+            const bool masked = (kt0 + 32 > S) || (causal && kt0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s_raw = st[r];
+                    float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2));
+                    if (!visible(qi, kt0 + crow(r, hi), S, causal, window, ivlo, ivhi)) p = 0.f;
+                    st[r] = lrp_ds<EXPL>(s_raw, p, dp[r], Dq, scale, eps_mask, eps_qk);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s_raw = st[r];
+                    const float p = fast_exp2(__builtin_fmaf(s_raw, c1, -lse2));
+                    st[r] = lrp_ds<EXPL>(s_raw, p, dp[r], Dq, scale, eps_mask, eps_qk);
+                }
+            }
+            const bf16x8 df0 = pack8(st, 0), df1 = pack8(st, 1);
+            A32_FENCE();
+            // ---- dQ^T += K^T dS^T
+            A2_UNIT(tk[1], at0, at1, 0, 1, 0);
+            A32_WAIT(8, A2_UNITV(tk[0]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) acc[d4] = mfma32(join_tr(tk[0][d4][0], tk[0][d4][1]), df0, acc[d4]);
+            A32_FENCE();
+            A2_UNIT(tk[0], at0, at1, 1, 0, 0);
+            A32_WAIT(8, A2_UNITV(tk[1]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) acc[4 + d4] = mfma32(join_tr(tk[1][d4][0], tk[1][d4][1]), df0, acc[4 + d4]);
+            A32_FENCE();
+            A2_UNIT(tk[1], at0, at1, 1, 1, 0);
+            A32_WAIT(8, A2_UNITV(tk[0]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) acc[d4] = mfma32(join_tr(tk[0][d4][0], tk[0][d4][1]), df1, acc[d4]);
+            A32_FENCE();
+            A32_WAIT(0, A2_UNITV(tk[1]));
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) acc[4 + d4] = mfma32(join_tr(tk[1][d4][0], tk[1][d4][1]), df1, acc[4 + d4]);
+            A32_FENCE();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+            arm += delta; at0 += delta; at1 += delta;
+        }
+        cur ^= 1;
+    }
+    store_rows2(dq + (int64_t)b * S * lddq + (int64_t)h * D2, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dK / dV per query head, d = 256: row side = 32 keys per wave (128 keys per workgroup); 32-query Q / Gho tiles (+ lse, D) stream.
+// TWO PASSES over the query tiles with ONE 128-register out^T accumulator: pass 0  dV^T += Gho^T P^T  (S^T, P),  pass 1  dK^T += Q^T dS^T
+// (S^T, dP^T, dS).  dK^T and dV^T together are 256 accumulator registers -- all of the accumulator file -- and S^T / dP^T need 32 more: the
+// fused form made the compiler shuttle accumulators between the two register classes every tile (~500 v_accvgpr moves against 64 MFMAs) and
+// keep the K fragments in scratch.  The second S^T costs 16 of 80 MFMAs per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool EXPL>
+__global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
+    const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int Hq,
+    int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask,
+    float eps_qk, int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    constexpr int BK = NW2 * 32, STAGE = 2 * TILE2 + 512, VROWS = 32 * KP2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bh, kblk;
+    if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+    const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
+    const int k0 = kblk * BK, kw = k0 + wave * 32, ki = kw + l31;
+    const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * D2;
+    const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * D2;
+    const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
+    const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
+    const int* rlo_b = row_lo ? row_lo + (int64_t)b * S : nullptr;
+    const int* rhi_b = row_lo ? row_hi + (int64_t)b * S : nullptr;
+
+    // K fragments of the wave's 32 keys in registers, its V rows in a wave-private LDS block in the tile layout (read in pass 1)
+    bf16x8 kf[NK2];
+    load_row_frags2(kf, k + (int64_t)b * S * ldk + (int64_t)hk * D2, ldk, ki, S, hi);
+    char* sVw = smem + 2 * STAGE + wave * VROWS;
+    stage_block2(v + (int64_t)b * S * ldv + (int64_t)hk * D2, ldv, kw, S, sVw, lane);
+    const float c1 = scale * LRP_LOG2E;
+    int qbeg = 0, qend = S;
+    if (causal) qbeg = (k0 / CT2) * CT2;
+    if (window > 0) qend = min(S, k0 + BK - 1 + window);
+    if (q_begin > qbeg) qbeg = (q_begin / CT2) * CT2;
+
+    auto stage = [&](int qt0, int buf) {
+        char* sb = smem + buf * STAGE;
+        stage_tile2(qb_, ldq, qt0, S, sb, wave, lane);
+        stage_tile2(gb_, ldg, qt0, S, sb + TILE2, wave, lane);
+        if (wave == 0) stage_stats(lse_b, qt0, S, sb + 2 * TILE2, lane);
+        if (wave == 1) stage_stats(D_b, qt0, S, sb + 2 * TILE2 + 256, lane);
+    };
+    const uint32_t avw = lds_addr(sVw) + rm_base(lane);              // the wave's V block (fixed)
+
+    sfor<0, 2>([&](auto passc) {
+        constexpr int PASS = decltype(passc)::value;                   // 0: dV, 1: dK
+        f32x16 acc[ND2];
+#pragma unroll
+        for (int db = 0; db < ND2; ++db) acc[db] = zero16();
+        if (qbeg < qend) stage(qbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t arm = lds_addr(smem) + rm_base(lane), at0 = lds_addr(smem) + tr_base(lane, 0), at1 = lds_addr(smem) + tr_base(lane, 1);
+        uint32_t ast = lds_addr(smem) + 2 * TILE2 + hi * 16;
+        int cur = 0;
+        for (int qt0 = qbeg; qt0 < qend; qt0 += CT2) {
+            if (qt0 + CT2 < qend) stage(qt0 + CT2, cur ^ 1);
+            const bool dead = (causal && qt0 + 31 < kw) || qt0 >= S || (window > 0 && qt0 - window >= kw + 31);
+            if (!dead) {
+                // ---- S^T (16 steps x Q fragment); pass 1: dP^T as well (16 steps x {Gho fragment, V fragment})
+                f32x16 st = zero16(), dp = zero16();
+                bf16x8 fq[3];
+                A32_RD128(fq[0], arm, 0);
+                { const uint32_t a_ = xor_addr<1 << 5>(arm); A32_RD128(fq[1], a_, 0); }
+                sfor<0, NK2>([&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                    (void)&fq; (void)&arm;
+                    if constexpr (ks + 2 < NK2) {
+                        { const uint32_t a_ = xor_addr<(ks + 2) << 5>(arm); A32_RD128(fq[nx], a_, 0); }
+                        A32_WAIT(2, "+v"(fq[cu]));
+                    } else if constexpr (ks + 1 < NK2) {
+                        A32_WAIT(1, "+v"(fq[cu]));
+                    } else {
+                        A32_WAIT(0, "+v"(fq[cu]));
+                    }
+                    st = mfma32(fq[cu], kf[ks], st);
+                    A32_FENCE();
+                });
+                if constexpr (PASS == 1) {
+                    bf16x8 fg[3], fv[3];
+                    A32_RD128(fg[0], arm, TILE2); A32_RD128(fv[0], avw, 0);
+                    { const uint32_t a_ = xor_addr<1 << 5>(arm), b_ = xor_addr<1 << 5>(avw); A32_RD128(fg[1], a_, TILE2); A32_RD128(fv[1], b_, 0); }
+                    sfor<0, NK2>([&](auto ksc) {
+                        constexpr int ks = decltype(ksc)::value, cu = ks % 3, nx = (ks + 2) % 3;
+                        (void)&fg; (void)&fv; (void)&arm; (void)&avw;
+                        if constexpr (ks + 2 < NK2) {
+                            { const uint32_t a_ = xor_addr<(ks + 2) << 5>(arm), b_ = xor_addr<(ks + 2) << 5>(avw); A32_RD128(fg[nx], a_, TILE2); A32_RD128(fv[nx], b_, 0); }
+                            A32_WAIT(4, "+v"(fg[cu]), "+v"(fv[cu]));
+                        } else if constexpr (ks + 1 < NK2) {
+                            A32_WAIT(2, "+v"(fg[cu]), "+v"(fv[cu]));
+                        } else {
+                            A32_WAIT(0, "+v"(fg[cu]), "+v"(fv[cu]));
+                        }
+                        dp = mfma32(fg[cu], fv[cu], dp);
+                        A32_FENCE();
+                    });
+                }
+                // ---- first transpose-read unit (pass 0: Gho tile, pass 1: Q tile) in flight under the element-wise work
+                constexpr int TOFF = (PASS == 0) ? TILE2 : 0;
+                u32x2 tt[2][4][2];
+                A2_UNIT(tt[0], at0, at1, 0, 0, TOFF);
+                A32_FENCE();
+                const bool masked = (qt0 + 32 > S) || (causal && qt0 < kw + 31) || (window > 0) || (row_lo != nullptr);
+                bf16x8 xf[2];                                             // pass 0: P, pass 1: dS (per 16-query group)
+                f32x4 sl[2], sd[2];
+                sfor<0, 2>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    (void)&sl; (void)&sd; (void)&ast;
+                    A32_RD128(sl[0], ast, 64 * j); A32_RD128(sl[1], ast, 64 * j + 32);
+                    if constexpr (PASS == 1) {
+                        A32_RD128(sd[0], ast, 64 * j + 256); A32_RD128(sd[1], ast, 64 * j + 32 + 256);
+                        A32_WAIT(0, "+v"(sl[0]), "+v"(sl[1]), "+v"(sd[0]), "+v"(sd[1]));
+                    } else {
+                        A32_WAIT(0, "+v"(sl[0]), "+v"(sl[1]));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 2 * j + ii, r = 4 * i + e;
+                            const float s_raw = st[r];
+                            float p = fast_exp2(__builtin_fmaf(s_raw, c1, -(sl[ii][e] * LRP_LOG2E)));
+                            if (masked) {
+                                const int qi = qt0 + 8 * i + 4 * hi + e;
+                                int ivlo = 0, ivhi = S;
+                                if (rlo_b != nullptr && qi < S) { ivlo = rlo_b[qi]; ivhi = rhi_b[qi]; }
+                                p = ((qi < S) & visible(qi, ki, S, causal, window, ivlo, ivhi)) ? p : 0.f;
+                            }
+                            if constexpr (PASS == 0) xf[j][4 * ii + e] = (bf16_t)p;
+                            else xf[j][4 * ii + e] = (bf16_t)lrp_ds<EXPL>(s_raw, p, dp[r], sd[ii][e], scale, eps_mask, eps_qk);
+                        }
+                    A32_FENCE();
+                });
+                // ---- out^T += (Gho | Q)^T x^T: units (j, dbh) = (0,0) (0,1) (1,0) (1,1), next unit's reads issued before this unit's MFMAs
+                A2_UNIT(tt[1], at0, at1, 0, 1, TOFF);
+                A32_WAIT(8, A2_UNITV(tt[0]));
+#pragma unroll
+                for (int d4 = 0; d4 < 4; ++d4) acc[d4] = mfma32(join_tr(tt[0][d4][0], tt[0][d4][1]), xf[0], acc[d4]);
+                A32_FENCE();
+                A2_UNIT(tt[0], at0, at1, 1, 0, TOFF);
+                A32_WAIT(8, A2_UNITV(tt[1]));
+#pragma unroll
+                for (int d4 = 0; d4 < 4; ++d4) acc[4 + d4] = mfma32(join_tr(tt[1][d4][0], tt[1][d4][1]), xf[0], acc[4 + d4]);
+                A32_FENCE();
+                A2_UNIT(tt[1], at0, at1, 1, 1, TOFF);
+                A32_WAIT(8, A2_UNITV(tt[0]));
+#pragma unroll
+                for (int d4 = 0; d4 < 4; ++d4) acc[d4] = mfma32(join_tr(tt[0][d4][0], tt[0][d4][1]), xf[1], acc[d4]);
+                A32_FENCE();
+                A32_WAIT(0, A2_UNITV(tt[1]));
+#pragma unroll
+                for (int d4 = 0; d4 < 4; ++d4) acc[4 + d4] = mfma32(join_tr(tt[1][d4][0], tt[1][d4][1]), xf[1], acc[4 + d4]);
+                A32_FENCE();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
+                arm += delta; at0 += delta; at1 += delta; ast += delta;
+            }
+            cur ^= 1;
+        }
+        if constexpr (PASS == 0) store_rows2(dv + (int64_t)b * S * lddv + (int64_t)h * D2, lddv, ki, S, acc, 1.f, hi);
+        else store_rows2(dk + (int64_t)b * S * lddk + (int64_t)h * D2, lddk, ki, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+    });
+}
+
+}  // namespace d256
+
 template <typename K> void set_lds(K kern, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace attn32
+
+// ---- entry points used by the dispatchers of attention.hip (bf16, d == 256) ------------------------------------------
+int lrp_attn32_fwd_d256(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
+                        int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
+                        const int* row_hi, hipStream_t st) {
+    using namespace attn32;
+    using namespace attn32::d256;
+    const size_t lds = 2 * (2 * (size_t)TILE2);
+    auto kern = fwd256_kernel;
+    LRP_SET_MAX_LDS(kern, lds);
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NW2 * 32 - 1) / (NW2 * 32))));
+    hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
+                       Hkv, ldq, ldk, ldv, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
+    return lrp_check_launch();
+}
+
+int lrp_attn32_dq_d256(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
+                       int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
+                       float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
+                       hipStream_t st) {
+    using namespace attn32;
+    using namespace attn32::d256;
+    const size_t lds = 2 * (2 * (size_t)TILE2);
+    dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NW2 * 32 - 1) / (NW2 * 32))));
+    if (eps_mask != 0.f || eps_qk != 0.f) {
+        auto kern = dq256_kernel<true>;
+        LRP_SET_MAX_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
+                           q_begin, row_lo, row_hi);
+    } else {
+        auto kern = dq256_kernel<false>;
+        LRP_SET_MAX_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
+                           q_begin, row_lo, row_hi);
+    }
+    return lrp_check_launch();
+}
+
+int lrp_attn32_dkv_d256(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
+                        void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
+                        int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
+                        const int* row_lo, const int* row_hi, hipStream_t st) {
+    using namespace attn32;
+    using namespace attn32::d256;
+    const size_t lds = 2 * (2 * (size_t)TILE2 + 512) + (size_t)NW2 * 32 * KP2;
+    dim3 grid(xcd_group_grid(B * Hq, (S + NW2 * 32 - 1) / (NW2 * 32)));
+    if (eps_mask != 0.f || eps_qk != 0.f) {
+        auto kern = dkv256_kernel<true>;
+        LRP_SET_MAX_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
+                           causal, window, B, q_begin, row_lo, row_hi);
+    } else {
+        auto kern = dkv256_kernel<false>;
+        LRP_SET_MAX_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
+                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
+                           causal, window, B, q_begin, row_lo, row_hi);
+    }
+    return lrp_check_launch();
+}
 
 // ---- entry points used by the dispatchers of attention.hip (bf16, d == 128) ------------------------------------------
 int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
