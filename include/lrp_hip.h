@@ -73,9 +73,9 @@ int lrp_gemm_nt(const void* A, const void* B, void* C, const void* bias,
 int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int dtype, int out_dtype, void* stream);
 
-/* lrp_linear_stream_fwd: z[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) for 1 <= M <= 256 rows in ONE launch -- the Linear forward in its
+/* lrp_linear_stream_fwd: z[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) for 1 <= M <= 128 rows in ONE launch -- the Linear forward in its
  * HBM-bound regime as a narrow-N, full-K weight-streaming MFMA kernel (csrc/linear_stream.hip): a workgroup owns 64 rows of W and the
- * whole K range, W goes HBM -> registers exactly once (no split-K, no fp32 slabs, no second launch), x is staged through LDS, 16-row
+ * whole K range, W is read from HBM exactly once (no split-K, no fp32 slabs, no second launch), x is staged through LDS, 16-row
  * blocks past M are not multiplied.  bf16 operands, out bf16 / fp32, K a multiple of 512, ldx / ldw multiples of 8 elements, operands
  * below 2^30 elements; anything else returns LRP_ESHAPE / LRP_EALIGN.  lrp_linear_stream_ok(M, N, K, ldx, ldw) = 1 when the kernel
  * applies AND its ceil(N / 64) workgroups fill the chip (>= 192); otherwise the caller uses lrp_gemm_skinny.

@@ -3,15 +3,17 @@
 //
 // Why not the split-K ping-pong GEMM (lrp_gemm_skinny) here: it needs a second launch that sums fp32 slabs (5-9 us against a 15-us weight
 // stream) and its 256-row tile multiplies 240 rows of zeros at M = 16.  Here a workgroup (4 waves) owns 64 rows of W and the whole K range:
-//   * W is read ONCE, straight from HBM into registers in MFMA operand layout -- wave w owns W rows n0 + 16 w .. + 15, lane l holds 16 bytes
-//     of row (l & 15) at k = 64 t + 32 ks + 8 (l >> 4): no LDS hop for an operand nobody shares.  `buffer_load_dwordx4 ... nt` (streamed
-//     once, one CU), a register ring of LS_WD = 8 K tiles (16 loads = 16 KiB per wave, 64 KiB per workgroup in flight: the ~50 KB per CU
-//     that 25 GB/s per CU x ~2 us of loaded HBM latency asks for);
+//   * W is read ONCE: wave w owns W rows n0 + 16 w .. + 15 and stages them itself, K tile by K tile, into a WAVE-PRIVATE LDS ring of
+//     LS_WD = 8 tiles with buffer_load_dwordx4 .. lds nt -- 2 pieces of 8 rows x 128 B per tile, i.e. FULL 128-byte lines per row visit
+//     (version 1 of this kernel loaded the MFMA operand layout straight into registers: 16 rows x 64 B per wave instruction, half
+//     lines -- 5.2 TB/s on the 1-GB LM head where the full-line staging of the split-K path reaches 6.05; profiles/r04_call2_*.txt).
+//     16 KiB per wave = 64 KiB per workgroup in flight: the ~50 KB per CU that 25 GB/s per CU x ~2 us of loaded HBM latency asks for.
+//     No barrier guards W: only the staging wave reads its pieces, its own vmcnt covers them;
 //   * x (M rows, L2-resident, shared by the 4 waves) is staged per K tile through an LDS ring by buffer_load .. lds (8 rows x 128 B per
 //     wave instruction, chunk ^ (row & 7) swizzle on the source side: the A-operand image of gemm_pp.hip, conflict-free for the
 //     16-row ds_read_b128 fragments), XD tiles ahead, ring of XD + 2 tiles, ONE s_barrier per K tile;
 //   * every wait is a hand-counted s_waitcnt: loads retire in order, so "x(t) has landed" = "all but the XD (P + 2) younger VMEM operations
-//     have retired" -- which also covers W(t), issued 8 tiles earlier.  The last 8 tiles are peeled: nothing is fetched past K.
+//     have retired" -- which also covers W(t), issued 8 tiles earlier (2 W pieces + P x pieces per wave and K tile).  The last 8 tiles are peeled: nothing is fetched past K.
 //   * 16-row blocks past M are not multiplied (nb live blocks of the MBMAX the instantiation has accumulators for).
 // Grid: ceil(N / 64) workgroups; the host uses the kernel when that fills the chip (>= 192) and K is a multiple of 512.
 // D = mfma(Wfrag, xfrag): lane l holds z[m = 16 i + (l & 15)][n = n0 + 16 w + 4 (l >> 4) + e].
@@ -24,7 +26,7 @@ constexpr int LS_WD = 8;       // K tiles of W in flight per wave (register ring
 typedef __attribute__((address_space(3))) void* ls_lds_ptr_t;
 
 template <int MBMAX> struct LSCfg {
-    static constexpr int XD = (MBMAX >= 16) ? 2 : 3;               // x prefetch distance in K tiles
+    static constexpr int XD = 3;                                   // x prefetch distance in K tiles
     static constexpr int NBUF = XD + 2;                            // LDS ring: tile t + XD is written while tiles t - 1, t may still be read
     static constexpr int P = MBMAX / 2;                            // 1-KiB staging pieces (8 rows x 128 B) per wave per K tile
     static constexpr int XTILE = MBMAX * 16 * 128;                 // bytes of one x tile
@@ -49,7 +51,6 @@ template <int I, int N, typename F> LRP_DEVICE void ls_for(F&& f) {
     }
 }
 
-#define LS_LOADW(dst, voff, rs, soff) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory")
 #define LS_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 template <typename TO, int MBMAX>
@@ -65,21 +66,14 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
     int nb = (M + 15) >> 4;
     nb = nb > MBMAX ? MBMAX : nb;
 
-    // ---- W: raw buffer over the whole weight (rows past N read as zero), per-lane offset relative to row n0
-    u32x4 rsW;
-    {
-        const uint64_t a = (uint64_t)(uintptr_t)W;
-        rsW[0] = (uint32_t)a;
-        rsW[1] = (uint32_t)(a >> 32) & 0xffffu;
-        rsW[2] = (uint32_t)(((int64_t)(N - 1) * ldw + K) * 2);
-        rsW[3] = 0x00020000u;
-    }
-    const uint32_t voW = (uint32_t)((int64_t)(16 * wave + (lane & 15)) * ldw * 2) + (uint32_t)((lane >> 4) << 4);
-    const uint32_t soW = (uint32_t)((int64_t)n0 * ldw * 2);
-
+    // ---- W: raw buffer over the whole weight (rows past N read as zero); this wave's rows n0 + 16 w .. + 15 as two 8-row pieces per K tile
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(((int64_t)(N - 1) * ldw + K) * 2), 0x00020000);
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int voW = (int)(prow * ldw * 2) + ((pslot ^ prow) << 4);
+    const int soW = (int)((int64_t)(n0 + 16 * wave) * ldw * 2);
+    char* const wring = smem + C::NBUF * C::XTILE + wave * (LS_WD * 2048);       // [LS_WD tiles][16 rows][128 B], wave-private
     // ---- x: LDS-DMA pieces of 8 rows x 128 B; lane l -> row l >> 3, LDS slot l & 7, source chunk slot ^ (row & 7)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
-    const int prow = lane >> 3, pslot = lane & 7;
     const int voX = (int)(prow * ldx * 2) + ((pslot ^ prow) << 4);
     auto stage_x = [&](int kt, int buf) {
 #pragma unroll
@@ -95,18 +89,21 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) cX[ks] = lds0 + (uint32_t)((lane & 15) * 128) + (uint32_t)((((4 * ks + (lane >> 4)) ^ (lane & 7))) << 4);
 
+    // W fragment of ring slot s, k-step ks: same image as x (row l & 15 of the wave's 16 rows)
+    uint32_t cW[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) cW[ks] = cX[ks] + (uint32_t)(C::NBUF * C::XTILE + wave * (LS_WD * 2048));
     f32x4 acc[MBMAX];
 #pragma unroll
     for (int i = 0; i < MBMAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 wf[LS_WD][2];
 
-    // (variables that appear ONLY as inline-asm operands of a nested generic lambda are not captured implicitly by this clang: name them once)
+    // stage W(kt) into ring slot s: two pieces (rows 0..7, 8..15 of the wave's block); nt: streamed once, by one CU
     auto load_w = [&](auto sc, int kt) {
         constexpr int s = decltype(sc)::value;
-        (void)&wf; (void)&voW; (void)&rsW;
-        const uint32_t so = soW + (uint32_t)kt * 128u;
-        LS_LOADW(wf[s][0], voW, rsW, so);
-        LS_LOADW(wf[s][1], voW, rsW, so + 64u);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ls_lds_ptr_t)(wring + s * 2048 + p * 1024), 16, voW,
+                                                     soW + (int)((int64_t)(8 * p) * ldw * 2) + kt * 128, 0, 2);
     };
 
     // ---- prologue: W(0 .. WD - XD - 1), then [x(v), W(WD - XD + v)] for v = 0 .. XD - 1 (the order the steady state continues)
@@ -124,13 +121,16 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
         constexpr bool LAST = decltype(lastc)::value != 0;
         if constexpr (!LAST || (s + C::XD < 8)) stage_x(t + C::XD, (t + C::XD) % C::NBUF);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LAST) asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(wf[s][0]), "+v"(wf[s][1]) : [cnt] "n"(ls_last_vmc<MBMAX>(s)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(wf[s][0]), "+v"(wf[s][1]) : [cnt] "n"(C::VMC) : "memory");
+        if constexpr (LAST) asm volatile("s_waitcnt vmcnt(%[cnt])" :: [cnt] "n"(ls_last_vmc<MBMAX>(s)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%[cnt])" :: [cnt] "n"(C::VMC) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t xb = (uint32_t)((t % C::NBUF) * C::XTILE);
         const uint32_t a0 = cX[0] + xb, a1 = cX[1] + xb;
-        const bf16x8 w0 = __builtin_bit_cast(bf16x8, wf[s][0]), w1 = __builtin_bit_cast(bf16x8, wf[s][1]);
+        // this wave's W fragments of the tile (ring slot s): two reads, first in the LDS queue
+        u32x4 wq0, wq1;
+        LS_DSRD(wq0, cW[0], s * 2048);
+        LS_DSRD(wq1, cW[1], s * 2048);
         // units u = (ks, batch): BS fragment reads each, read one unit ahead
         u32x4 xf[2][C::BS];
         constexpr int U = 2 * C::NBATCH;
@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
             });
         };
         issue(LSI<0>{});
+        if constexpr (C::BS == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wq0), "+v"(wq1));
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq0), "+v"(wq1));
+        const bf16x8 w0 = __builtin_bit_cast(bf16x8, wq0), w1 = __builtin_bit_cast(bf16x8, wq1);
         ls_for<0, U>([&](auto uc) {
             constexpr int u = decltype(uc)::value, ks = u / C::NBATCH, b = u % C::NBATCH;
             (void)&xf;
@@ -206,7 +209,7 @@ template <typename TO, int MBMAX>
 int launch_stream(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
                   hipStream_t st) {
     using C = LSCfg<MBMAX>;
-    const size_t lds = (size_t)C::NBUF * C::XTILE;
+    const size_t lds = (size_t)C::NBUF * C::XTILE + 4 * (size_t)LS_WD * 2048;        // x ring + four wave-private W rings
     auto kern = linear_stream_fwd_kernel<TO, MBMAX>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((N + 63) / 64), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (TO*)z, (const bf16_t*)bias, M, N, K,
@@ -220,16 +223,16 @@ int launch_stream_m(const void* x, const void* W, const void* bias, void* z, int
     const int nb = (M + 15) / 16;
     if (nb <= 2) return launch_stream<TO, 2>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
     if (nb <= 4) return launch_stream<TO, 4>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
-    if (nb <= 8) return launch_stream<TO, 8>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
-    return launch_stream<TO, 16>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+    return launch_stream<TO, 8>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
 }
 
 }  // namespace
 
-// can lrp_linear_stream_fwd serve the problem, and is it the right kernel for it?  bf16, 1 <= M <= 256 rows, K a multiple of 512 (the
-// 8-tile register ring), operands below 2^31 bytes, and enough 64-row workgroups to put one on (nearly) every CU
+// can lrp_linear_stream_fwd serve the problem, and is it the right kernel for it?  bf16, 1 <= M <= 128 rows (every workgroup re-reads x from
+// L2: beyond that the x traffic outgrows the weight's), K a multiple of 512 (the 8-tile ring), operands below 2^31 bytes, and enough 64-row
+// workgroups to put one on (nearly) every CU
 extern "C" int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ldw) {
-    if (M < 1 || M > 256 || N < 1 || K < 512 || (K % 512)) return 0;
+    if (M < 1 || M > 128 || N < 1 || K < 512 || (K % 512)) return 0;
     if ((ldx % 8) || (ldw % 8) || ldx < K || ldw < K) return 0;
     if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return 0;
     return (N + 63) / 64 >= 192;
@@ -241,7 +244,7 @@ extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* b
     if (M == 0 || N == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (ldx % 8) || (ldw % 8)) return LRP_EALIGN;
-    if (M > 256 || K < 512 || (K % 512) || ldx < K || ldw < K || (int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return LRP_ESHAPE;
+    if (M > 128 || K < 512 || (K % 512) || ldx < K || ldw < K || (int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (out_dtype == LRP_F32) return launch_stream_m<float>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
     return launch_stream_m<bf16_t>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
