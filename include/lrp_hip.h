@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -163,6 +163,11 @@ int lrp_layernorm_fwd(const void* x, const void* w, const void* b, void* y, floa
                       float* rstd, int M, int H, float eps, int dtype, void* stream);
 int lrp_layernorm_bwd(const void* Gy, const void* y, const void* w, const float* rstd,
                       void* Gx, int M, int H, float eps_y, int dtype, void* stream);
+/* full LayerNorm VJP, NO rule (mean and 1/std both differentiated): u = Gy (*) w, xh = (x - mean) rstd,
+ * Gx = rstd (u - mean_row(u) - xh mean_row(u (*) xh)); x / mean / rstd as lrp_layernorm_fwd took / wrote them (image tower, see lrp_act_grad) */
+int lrp_layernorm_bwd_plain(const void* Gy, const void* x, const void* w, const float* mean, const float* rstd, void* Gx,
+                            int M, int H, int dtype, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * K3/K8  gated MLP element-wise rules.
@@ -205,6 +210,10 @@ int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* A
 int lrp_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
 int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, float eps_g, int act,
                 int dtype, void* stream);
+/* plain derivative, NO rule: Gx = Gy * act'(x).  The reference's gemma3 map patches nothing in modeling_siglip, so the SigLIP tower of
+ * Gemma-3 keeps ordinary gradients through its GELU / LayerNorm (ref: lxt/efficient/models/gemma3.py:14-19). */
+int lrp_act_grad(const void* Gy, const void* x, void* Gx, int64_t n, int act, int dtype, void* stream);
+
 /* forward sums of the encoder families: out[m,:] = x[m,:] + y[m % period,:]  (period 1: a bias / token-type row, period S: position
  * embeddings, period M: a residual sum; the summands of lf.add2, ref: lxt/explicit/models/bert.py:249-253,:396).  x, y, out [.,H]
  * contiguous; out may alias x.                                                                                                    */

@@ -149,6 +149,37 @@ __global__ void act_bwd_kernel(const T* Gy, const T* x, T* Gx, int64_t n, float 
     }
 }
 
+// plain derivative of the activation (NO rule): Gx = Gy act'(x) -- the reference's gemma3 map patches nothing in modeling_siglip, so the
+// image tower's GELU keeps its ordinary gradient (ref: lxt/efficient/models/gemma3.py:14-19)
+LRP_DEVICE float act_deriv(float x, int act) {
+    if (act == LRP_ACT_SILU) {
+        const float sg = 1.f / (1.f + __expf(-x));
+        return sg * (1.f + x * (1.f - sg));
+    }
+    if (act == LRP_ACT_GELU_TANH) {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        const float t = tanhf(k0 * (x + k1 * x * x * x));
+        return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x * x);
+    }
+    if (act == LRP_ACT_TANH) {
+        const float t = tanhf(x);
+        return 1.f - t * t;
+    }
+    return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+template <typename T, int W>
+__global__ void act_grad_kernel(const T* Gy, const T* x, T* Gx, int64_t n, int act) {
+    const int64_t nchunk = n / W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        Chunk<T, W> g, a, o;
+        g.load(Gy + i * W);
+        a.load(x + i * W);
+#pragma unroll
+        for (int k = 0; k < W; ++k) o.v[k] = g.v[k] * act_deriv(a.v[k], act);
+        o.store(Gx + i * W);
+    }
+}
+
 // 2-D strided gated-MLP kernels: one chunk of W columns per thread-iteration
 template <typename T, int W>
 __global__ void gated_fwd_kernel(const T* g, const T* u, T* m, int M, int I, int64_t ldg, int64_t ldu, int64_t ldm, int act, int il) {
@@ -441,6 +472,24 @@ extern "C" int lrp_act_bwd(const void* Gy, const void* x, void* Gx, int64_t n, f
             if (n > nb) hipLaunchKernelGGL((act_bwd_kernel<T, 1>), dim3(1), dim3(64), 0, st, pg + nb, px + nb, po + nb, n - nb, eps_g, act);
         } else {
             hipLaunchKernelGGL((act_bwd_kernel<T, 1>), dim3(grid_for(n)), dim3(ENT), 0, st, pg, px, po, n, eps_g, act);
+        }
+    })
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_act_grad(const void* Gy, const void* x, void* Gx, int64_t n, int act, int dtype, void* stream) {
+    if (!Gy || !x || !Gx || n < 0 || act < 0 || act > 3) return LRP_EINVAL;
+    if (n == 0) return LRP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        const T *pg = (const T*)Gy, *px = (const T*)x; T* po = (T*)Gx;
+        if (al16(Gy) && al16(x) && al16(Gx)) {
+            const int64_t nb = (n / EPC) * EPC;
+            if (nb) hipLaunchKernelGGL((act_grad_kernel<T, EPC>), dim3(grid_for(nb / EPC)), dim3(ENT), 0, st, pg, px, po, nb, act);
+            if (n > nb) hipLaunchKernelGGL((act_grad_kernel<T, 1>), dim3(1), dim3(64), 0, st, pg + nb, px + nb, po + nb, n - nb, act);
+        } else {
+            hipLaunchKernelGGL((act_grad_kernel<T, 1>), dim3(grid_for(n)), dim3(ENT), 0, st, pg, px, po, n, act);
         }
     })
     return lrp_check_launch();

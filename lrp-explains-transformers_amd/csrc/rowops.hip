@@ -181,6 +181,44 @@ __global__ void layernorm_bwd_kernel(const T* Gy, const T* y, const T* w, const 
     }
 }
 
+// full LayerNorm VJP (NO rule: mean and 1/std both differentiated): u = Gy (*) w, xh = (x - mean) rstd,
+// Gx = rstd (u - mean_row(u) - xh mean_row(u (*) xh)) -- the image tower of Gemma-3 under the reference's gemma3 map (nothing patched in
+// modeling_siglip: ref lxt/efficient/models/gemma3.py:14-19)
+template <typename T, int W>
+__global__ void layernorm_bwd_plain_kernel(const T* Gy, const T* x, const T* w, const float* mean, const float* rstd, T* Gx, int H) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const float rs = rstd[row], mu = mean[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x * W; c < H; c += blockDim.x * W) {
+        RChunk<T, W> g, xx, ww;
+        g.load(Gy + row * H + c);
+        xx.load(x + row * H + c);
+        if (w) ww.load(w + c);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float u = w ? g.v[k] * ww.v[k] : g.v[k];
+            s1 += u;
+            s2 += u * ((xx.v[k] - mu) * rs);
+        }
+    }
+    const float m1 = block_sum(s1, red) / (float)H;
+    __syncthreads();
+    const float m2 = block_sum(s2, red) / (float)H;
+    for (int c = threadIdx.x * W; c < H; c += blockDim.x * W) {
+        RChunk<T, W> g, xx, ww, o;
+        g.load(Gy + row * H + c);
+        xx.load(x + row * H + c);
+        if (w) ww.load(w + c);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float u = w ? g.v[k] * ww.v[k] : g.v[k];
+            o.v[k] = rs * (u - m1 - (xx.v[k] - mu) * rs * m2);
+        }
+        o.store(Gx + row * H + c);
+    }
+}
+
 // ---- explicit softmax rule on materialised rows --------------------------------------------------------
 template <typename T>
 __global__ void softmax_fwd_kernel(const T* x, T* p, int n, float inv_t) {
@@ -430,6 +468,20 @@ extern "C" int lrp_layernorm_bwd(const void* Gy, const void* y, const void* w, c
         const bool v = (H % EPC == 0) && al16(Gy) && al16(y) && al16(w) && al16(Gx);
         if (v) hipLaunchKernelGGL((layernorm_bwd_kernel<T, EPC>), dim3(M), dim3(row_threads(H, EPC)), 0, st, (const T*)Gy, (const T*)y, (const T*)w, rstd, (T*)Gx, H, eps_y);
         else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(M), dim3(row_threads(H, 1)), 0, st, (const T*)Gy, (const T*)y, (const T*)w, rstd, (T*)Gx, H, eps_y);
+    })
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_layernorm_bwd_plain(const void* Gy, const void* x, const void* w, const float* mean, const float* rstd, void* Gx,
+                                       int M, int H, int dtype, void* stream) {
+    if (!Gy || !x || !mean || !rstd || !Gx || M < 0 || H < 1) return LRP_EINVAL;
+    if (M == 0) return LRP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        constexpr int EPC = 16 / sizeof(T);
+        const bool v = (H % EPC == 0) && al16(Gy) && al16(x) && al16(w) && al16(Gx);
+        if (v) hipLaunchKernelGGL((layernorm_bwd_plain_kernel<T, EPC>), dim3(M), dim3(row_threads(H, EPC)), 0, st, (const T*)Gy, (const T*)x, (const T*)w, mean, rstd, (T*)Gx, H);
+        else hipLaunchKernelGGL((layernorm_bwd_plain_kernel<T, 1>), dim3(M), dim3(row_threads(H, 1)), 0, st, (const T*)Gy, (const T*)x, (const T*)w, mean, rstd, (T*)Gx, H);
     })
     return lrp_check_launch();
 }

@@ -153,6 +153,15 @@ class Gemma3LRP:
     def _window(self, li):
         return self.cfg["window"] if self.cfg["layer_types"][li] == "sliding_attention" else 0
 
+    def _attn_mask(self, li, row_iv):
+        """-> (causal, window, row intervals) of layer li.  row_iv is None / a (lo, hi) pair (left-padded text batches: causal + window stay
+        structural) or a dict {"global": (lo, hi), "local": (lo, hi)} of COMPLETE per-row key intervals (image + text prompts: tokens of one
+        image attend to each other in both directions, HF `create_masks_for_vision_model`; the intervals then carry causality and the
+        sliding window themselves, see engine_gemma3_mm.mm_row_intervals)"""
+        if isinstance(row_iv, dict):
+            return False, 0, row_iv["local" if self.cfg["layer_types"][li] == "sliding_attention" else "global"]
+        return True, self._window(li), row_iv
+
     # ---------------------------------------------------------------------------------------------
     def forward(self, emb, B, S, row_iv=None):
         c = self.cfg
@@ -190,7 +199,8 @@ class Gemma3LRP:
             v = qkv[:, nqd + nkd:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o, lse = new(("o", li), M, nqd), f32(("lse", li), B, nq, S)
-            ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], True, self._window(li), row_iv=row_iv)
+            causal, win, iv = self._attn_mask(li, row_iv)
+            ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], causal, win, row_iv=iv)
             a = ops.linear_fwd(o, Lw["wo"], out=new("a", M, H))
             # post-attention norm, residual add, pre-feed-forward norm
             pa, st["rstd_pa"] = new("pa", M, H), f32(("rstd_pa", li), M)
@@ -229,7 +239,7 @@ class Gemma3LRP:
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
             cos, sin = self.rope[c["layer_types"][li]]
-            win = self._window(li)
+            causal, win, iv = self._attn_mask(li, fw["row_iv"])
             # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
             Gdn = new("Gdn", M, H)
             ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
@@ -250,9 +260,9 @@ class Gemma3LRP:
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dq, dk_h, dv_h = new("dq", M, nqd), new("dk_h", M, nqd), new("dv_h", M, nqd)
-            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win, row_iv=fw["row_iv"])
-            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], True, win,
-                             row_iv=fw["row_iv"])
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win, row_iv=iv)
+            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win,
+                             row_iv=iv)
             dk = ops.gqa_reduce(dk_h, new("dk", M, nkd), M, nk, rep, d)
             Aqkv = new("Aqkv", M, nqkv)
             ops.gqa_reduce(dv_h, Aqkv[:, nqd + nkd:], M, nk, rep, d)

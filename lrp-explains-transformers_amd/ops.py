@@ -336,6 +336,15 @@ def act_bwd(Gy, x, act="silu", eps_g=1e-10):
     return Gx
 
 
+def act_grad(Gy, x, act="gelu_tanh", out=None):
+    """plain derivative Gy * act'(x) (no rule): the SigLIP tower under the reference's gemma3 map"""
+    Gy, x = _c(Gy), _c(x)
+    out = torch.empty_like(x) if out is None else out
+    same(x, Gy, out)
+    check(lib.lrp_act_grad(p(Gy), p(x), p(out), x.numel(), ACT[act], dt(x), stream()), "lrp_act_grad")
+    return out
+
+
 def gated_act_fwd(g, u, out=None, act="silu"):
     M, I = g.shape
     out = torch.empty(M, I, device=g.device, dtype=g.dtype) if out is None else out
@@ -526,6 +535,19 @@ def layernorm_bwd(Gy, y, w, rstd, eps_y=0.0):
     w = aux(w, Gy, H)
     check(lib.lrp_layernorm_bwd(p(Gy), p(y), p(w), p(rstd), p(Gx), M, H, eps_y, dt(Gy), stream()), "lrp_layernorm_bwd")
     return Gx
+
+
+def layernorm_bwd_plain(Gy, x, w, mean, rstd, out=None):
+    """full LayerNorm VJP (no rule; mean and 1/std differentiated) from the forward's x / mean / rstd"""
+    Gy, x = _c(Gy), _c(x)
+    H = Gy.shape[-1]
+    M = Gy.numel() // H
+    out = torch.empty_like(Gy) if out is None else out
+    same(Gy, x, out)
+    f32(mean, rstd)
+    w = aux(w, Gy, H)
+    check(lib.lrp_layernorm_bwd_plain(p(Gy), p(x), p(w), p(mean), p(rstd), p(out), M, H, dt(Gy), stream()), "lrp_layernorm_bwd_plain")
+    return out
 
 
 def softmax_fwd(x, inv_temp=1.0):

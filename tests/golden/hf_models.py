@@ -63,6 +63,41 @@ def build_gemma3_mm(seed=11, attn="eager"):
     return m
 
 
+def build_gemma3_mm_fulldims(vision_layers=2, text_layers=2, seed=13, attn="sdpa"):
+    """Gemma3ForConditionalGeneration at the released Gemma-3-4B-it dimensions (BASELINE config 4, image + text): SigLIP-So400m tower
+    (H 1152, 16 heads of d = 72, I 4304, 896 x 896 images, patch 14 -> 4096 patches, 256 image tokens) with `vision_layers` encoder layers,
+    text tower (H 2560, 8 / 4 heads of d = 256, I 10240, window 1024) with `text_layers` layers, small vocabulary; seeded, non-trivial norms"""
+    from transformers import Gemma3Config, Gemma3ForConditionalGeneration
+    torch.manual_seed(seed)
+    text = dict(vocab_size=4096, hidden_size=2560, intermediate_size=10240, num_hidden_layers=text_layers, num_attention_heads=8,
+                num_key_value_heads=4, head_dim=256, sliding_window=1024, max_position_embeddings=4096, query_pre_attn_scalar=256,
+                layer_types=["sliding_attention", "full_attention"][:text_layers])
+    vision = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=vision_layers, num_attention_heads=16, image_size=896,
+                  patch_size=14, num_channels=3)
+    cfg = Gemma3Config(text_config=text, vision_config=vision, mm_tokens_per_image=256, image_token_id=4095, boi_token_id=4093,
+                       eoi_token_id=4094, attn_implementation=attn)
+    m = Gemma3ForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 1)
+        w = m.model.multi_modal_projector.mm_input_projection_weight
+        w.copy_(torch.randn(w.shape, generator=g) * 0.03)
+        for n_, p_ in m.named_parameters():
+            if "norm" in n_ and "layer_norm" not in n_ and "layernorm" not in n_ and p_.dim() == 1:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+    return m
+
+
+def gemma3_mm_fulldims_inputs(S=384):
+    """one image inside a text prompt: text, <boi>, 256 image tokens, <eoi>, text; token_type_ids; pixel values"""
+    ids = torch.randint(0, 4000, (1, S), generator=torch.Generator().manual_seed(5))
+    ids[0, 20] = 4093
+    ids[0, 21: 21 + 256] = 4095
+    ids[0, 21 + 256] = 4094
+    tt = (ids == 4095).long()
+    pv = torch.randn(1, 3, 896, 896, generator=torch.Generator().manual_seed(6))
+    return ids, tt, pv
+
+
 def gemma3_mm_inputs():
     """ids with one image (boi, 4 image tokens, eoi) inside a 48-token prompt, token_type_ids, pixel values"""
     S = 48
