@@ -230,7 +230,7 @@ def mode_batch_probes(eng, ops, cfg, dev, peak, S, steps=3):
     return out
 
 
-def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048):
+def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048, image=True):
     """BASELINE config 4's text tower through the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP), AFTER and OUTSIDE the headline
     timed region: Gemma-3-4B shape (34 layers, H 2560, 8 / 4 heads of d = 256, I 10240, sliding window 1024 on 5 of 6 layers, tied
     262208-token head), random init on the device, seq = 2048, 4 prompts per step."""
@@ -262,11 +262,56 @@ def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048):
     ops.GEMM_TIMER = None
     n_launch, flops, secs = timer.summary()
     assert torch.isfinite(R).all()
-    eng.release()
-    return {"workload": f"Gemma-3-4B text tower shape, lxt.efficient rule placement, seq={S4}, {B4} prompts per step, {steps} steps after the "
+    text = {"workload": f"Gemma-3-4B text tower shape, lxt.efficient rule placement, seq={S4}, {B4} prompts per step, {steps} steps after the "
                         "headline region (fused driver engine_gemma3.Gemma3LRP)",
             "value": B4 * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3,
             "gemm_TFLOPs": flops / secs / 1e12, "gemm_frac_of_peak": flops / secs / 1e12 / peak, "gemm_time_frac_of_step": secs / el}
+    mm = None
+    if image:
+        mm = config4_image_probe(eng, ops, dev, dtype, peak, g, steps=steps, B4=B4, S4=S4)
+    eng.release()
+    return text, mm
+
+
+def config4_image_probe(text_eng, ops, dev, dtype, peak, g, steps=3, B4=4, S4=2048):
+    """BASELINE config 4 as named: Gemma-3-4B-it IMAGE + TEXT.  One 896 x 896 image per prompt (SigLIP-So400m shape: 27 layers, H 1152, 16
+    heads of d = 72, I 4304, 4096 patches -> 256 image tokens through the projector) inside a seq = 2048 prompt, relevance of the text tokens
+    and of the 4096 ViT patches, through the fused driver engine_gemma3_mm.Gemma3MMLRP; random init on the device."""
+    from lxt_amd.engine_gemma3_mm import Gemma3MMLRP, SiglipLRP
+    Lv, Hv, Iv, nh, img, pt, T = 27, 1152, 4304, 16, 896, 14, 256
+    Ht, V = text_eng.cfg["hidden"], text_eng.cfg["vocab"]
+    rn = lambda sd, *s: (torch.randn(*s, generator=g, device=dev) * sd).to(dtype)  # noqa: E731
+    P = (img // pt) ** 2
+    W = dict(patch_w=rn(0.02, Hv, 3, pt, pt), patch_b=rn(0.02, Hv), pos=rn(0.02, P, Hv), post_w=1 + rn(0.1, Hv), post_b=rn(0.1, Hv),
+             proj_norm=rn(0.1, Hv), proj_w=rn(0.03, Hv, Ht), layers=[
+        dict(ln1_w=1 + rn(0.1, Hv), ln1_b=rn(0.1, Hv), ln2_w=1 + rn(0.1, Hv), ln2_b=rn(0.1, Hv), wq=rn(0.02, Hv, Hv), bq=rn(0.02, Hv),
+             wk=rn(0.02, Hv, Hv), bk=rn(0.02, Hv), wv=rn(0.02, Hv, Hv), bv=rn(0.02, Hv), wo=rn(0.02, Hv, Hv), bo=rn(0.02, Hv),
+             w1=rn(0.02, Iv, Hv), b1=rn(0.02, Iv), w2=rn(0.02, Hv, Iv), b2=rn(0.02, Hv)) for _ in range(Lv)])
+    vcfg = dict(hidden=Hv, inter=Iv, n_layers=Lv, n_heads=nh, image=img, patch=pt, channels=3, ln_eps=1e-6, act="gelu_tanh",
+                tokens_per_image=T, text_hidden=Ht, image_token_id=V - 1)
+    vis = SiglipLRP(vcfg, W, dtype=dtype, device=dev, vision_attn_rule=True)
+    del W
+    eng = Gemma3MMLRP(text_eng, vis)
+    ids = torch.randint(0, V - 8, (B4 * (steps + 1), S4), generator=torch.Generator().manual_seed(98))
+    ids[:, 64: 64 + T] = V - 1                                                 # the image's 256 tokens inside the prompt
+    pix = torch.randn(B4 * (steps + 1), 3, img, img, generator=g, device=dev).to(dtype)
+    r = eng.explain(ids[:B4], pix[:B4])
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.GEMM_TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r = eng.explain(ids[(i + 1) * B4: (i + 2) * B4], pix[(i + 1) * B4: (i + 2) * B4])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    n_launch, flops, secs = timer.summary()
+    assert torch.isfinite(r["R_tok"]).all() and torch.isfinite(r["R_patch"]).all()
+    return {"workload": f"Gemma-3-4B-it shape, image + text: one 896x896 image (SigLIP tower 27 layers, 4096 patches -> 256 image tokens) inside a "
+                        f"seq={S4} prompt, {B4} prompts per step, {steps} steps; relevance of text tokens and ViT patches (fused driver "
+                        "engine_gemma3_mm.Gemma3MMLRP, lxt.efficient placement, tower attention under the AttnLRP rule = the reference with sdpa)",
+            "value": B4 * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3,
+            "gemm_TFLOPs_timed_launches": flops / max(secs, 1e-9) / 1e12, "gemm_time_frac_of_step": secs / el}
 
 
 def dry_run(args):
@@ -330,6 +375,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
     ap.add_argument("--no-config4", action="store_true", help="skip the Gemma-3-4B text-tower probe that follows the headline region")
+    ap.add_argument("--no-config4-image", action="store_true", help="skip the image + text part of the Gemma-3-4B probe")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the explicit-mode and one-prompt-per-step probes that follow the headline region")
     ap.add_argument("--no-smallm", action="store_true", help="skip the small-M Linear tables that follow the headline region (profiling: their "
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
@@ -483,7 +529,9 @@ def main():
             line.update(mode_batch_probes(eng, ops, cfg, dev, peak, S))
         if not args.no_config4 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
             eng.release()
-            line["config4_gemma3_4b_text"] = config4_probe(ops, dev, dtype, peak)
+            line["config4_gemma3_4b_text"], mm_line = config4_probe(ops, dev, dtype, peak, image=not args.no_config4_image)
+            if mm_line is not None:
+                line["config4_gemma3_4b_image_text"] = mm_line
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)

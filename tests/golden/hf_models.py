@@ -82,8 +82,8 @@ def build_gemma3_mm_fulldims(vision_layers=2, text_layers=2, seed=13, attn="sdpa
         w = m.model.multi_modal_projector.mm_input_projection_weight
         w.copy_(torch.randn(w.shape, generator=g) * 0.03)
         for n_, p_ in m.named_parameters():
-            if "norm" in n_ and "layer_norm" not in n_ and "layernorm" not in n_ and p_.dim() == 1:
-                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+            if "norm" in n_ and p_.dim() == 1:               # Gemma (1 + w) weights and LayerNorm biases start at 0, LayerNorm weights at 1
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.1)
     return m
 
 
