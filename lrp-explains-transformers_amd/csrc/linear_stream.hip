@@ -235,7 +235,10 @@ extern "C" int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ld
     if (M < 1 || M > 128 || N < 1 || K < 512 || (K % 512)) return 0;
     if ((ldx % 8) || (ldw % 8) || ldx < K || ldw < K) return 0;
     if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return 0;
-    return (N + 63) / 64 >= 192;
+    // enough 64-row workgroups to put one on (nearly) every CU; for very many (the 128256-row LM head: 2004) the split-K path with its
+    // 256 x 256 tiles streams ~4 % faster (6.1 vs 5.8 TB/s, profiles/r04_call3_*.txt) and its second launch no longer matters
+    const int wgs = (N + 63) / 64;
+    return wgs >= 192 && wgs <= 1024;
 }
 
 extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,

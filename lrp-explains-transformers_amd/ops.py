@@ -700,7 +700,7 @@ def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
 def linear_dgrad(s2, W, out=None, out_dtype=None):
     """c[M,K] = s2[M,N] @ W[N,K]: the redistribution half of the Linear eps-rule (ref: lxt/explicit/functional.py:355-364) from the
     STORED weight layout:
-       M <= 4, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
+       M <= 2, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
        M <= 256, bf16, N % 64 == 0                           : split-K skinny path, NN form
        bf16 problems of >= 190 tiles of 256 x 256            : lrp_gemm_nn (no W^T copy)
        everything else (fp32 parity path, odd shapes)        : lrp_gemm_nt on a W^T copy cached on the weight (ops.weight_t)"""
@@ -708,7 +708,7 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     K = W.shape[1]
     odt = out_dtype or (out.dtype if out is not None else W.dtype)
     nn = gemm_nn_ok(s2, W)
-    if (M <= 4 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
+    if (M <= 2 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
         return linear_smallm_dgrad(s2, W, out=out, out_dtype=odt)
     if nn:
         split = splitk_ok(M, K, N)
