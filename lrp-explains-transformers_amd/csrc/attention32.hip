@@ -929,7 +929,8 @@ __global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
             u32x2 tv[2][4][2];
             A2_UNIT(tv[0], at0, at1, 0, 0, TILE2);
             A32_FENCE();
-            const bool need_mask = (kt0 + CT2 > S) || (causal && kt0 + CT2 - 1 > qw) || (window > 0) || (row_lo != nullptr);
+            // (a sliding window only needs per-element masks where the tile crosses the window's lower edge for some row of the wave)
+            const bool need_mask = (kt0 + CT2 > S) || (causal && kt0 + CT2 - 1 > qw) || (window > 0 && kt0 <= qw + 31 - window) || (row_lo != nullptr);
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -939,7 +940,14 @@ __global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
             mx = half_max(mx);
-            const float m_new = fmaxf(m_run, mx);
+            // LAZY running maximum: the reference point m_run only moves when some row's maximum grew by more than 2^LAZY (in the exponent's
+            // units) -- rescaling 128 accumulator registers through the accumulator file costs ~320 VALU operations, more than the tile's 32
+            // MFMAs, and with 32 rows per wave "some row's maximum moved" is true on most tiles.  Between moves p = exp2((s - m_run) c1) may
+            // exceed 1 (by at most 2^LAZY = 256: exact in fp32, same relative rounding in bf16); l_run uses the same reference, so o = acc / l
+            // and lse = m_run scale + log l are unchanged up to rounding.
+            constexpr float LAZY = 8.f;
+            float m_new = m_run;
+            if (__any((mx - m_run) * c1 > LAZY || (m_run == -INFINITY && mx != -INFINITY))) m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float nm2 = -m_use * c1;
             float rs = 0.f;
@@ -1070,7 +1078,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dq256_kernel(
             u32x2 tk[2][4][2];
             A2_UNIT(tk[0], at0, at1, 0, 0, 0);
             A32_FENCE();
-            const bool masked = (kt0 + 32 > S) || (causal && kt0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
+            const bool masked = (kt0 + 32 > S) || (causal && kt0 + 31 > qw) || (window > 0 && kt0 <= qw + 31 - window) || (row_lo != nullptr);
             if (masked) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
                 u32x2 tt[2][4][2];
                 A2_UNIT(tt[0], at0, at1, 0, 0, TOFF);
                 A32_FENCE();
-                const bool masked = (qt0 + 32 > S) || (causal && qt0 < kw + 31) || (window > 0) || (row_lo != nullptr);
+                const bool masked = (qt0 + 32 > S) || (causal && qt0 < kw + 31) || (window > 0 && qt0 + 31 - window >= kw) || (row_lo != nullptr);
                 bf16x8 xf[2];                                             // pass 0: P, pass 1: dS (per 16-query group)
                 f32x4 sl[2], sd[2];
                 sfor<0, 2>([&](auto jc) {
