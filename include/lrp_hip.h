@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -83,6 +83,18 @@ int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M,
 int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ldw);
 int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
                           int64_t ldz, int dtype, int out_dtype, void* stream);
+
+/* lrp_linear_stream_dgrad: c[M,Kout] = s[M,N] . W[N,Kout] (the eps-rule's redistribution from the STORED weight: contraction over W's rows) for
+ * 1 <= M <= 64 rows -- the dgrad counterpart of lrp_linear_stream_fwd: a workgroup owns 64 output columns (128-byte segments of every W row)
+ * and one of `splits` ranges of contraction rows, operands go through wave-private LDS rings (no barrier in the contraction loop), the
+ * MFMA's W operand is gathered by ds_read_b64_tr_b16.  splits > 1 (few column blocks, e.g. Kout = 4096) writes fp32 slabs into `ws`
+ * (lrp_linear_stream_dgrad_ws BYTES, caller-allocated) that a second small kernel sums in slab order; otherwise the result is written directly.
+ * bf16 operands, out bf16 / fp32, N a multiple of 128, Kout of 64; lrp_linear_stream_dgrad_ok = 1 when the kernel applies and fills the chip.
+ * ref: lxt/explicit/functional.py:355-364 (`relevance_norm @ weight`), lxt/explicit/rules.py:206-222. */
+int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds, int64_t ldw);
+int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout);
+int lrp_linear_stream_dgrad(const void* s, const void* W, void* c, int M, int N, int Kout, int64_t lds, int64_t ldw, int64_t ldc,
+                            int dtype, int out_dtype, void* ws, void* stream);
 
 /* lrp_gemm_skinny: the same two products with SPLIT-K, for problems whose 256 x 256 tile count alone leaves CUs idle: 1 <= M <= 256 rows
  * (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic

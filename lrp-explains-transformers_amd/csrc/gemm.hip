@@ -476,6 +476,18 @@ int skinny_splits(int M, int N, int K) {
 
 }  // namespace
 
+// the slab reduction alone (linear_stream.hip's dgrad splits its contraction range the same way)
+int lrp_launch_splitk_reduce(const float* ws, void* out, int M, int N, int64_t ldw, int64_t ldo, int splits, int64_t slab, int out_dtype,
+                             hipStream_t st) {
+    const int64_t nq = (int64_t)M * ((N + 3) / 4);
+    dim3 grid((unsigned)((nq + 255) / 256)), block(256);
+    if (out_dtype == LRP_F32)
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), grid, block, 0, st, ws, (const bf16_t*)nullptr, (float*)out, M, N, ldw, ldo, splits, slab);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), grid, block, 0, st, ws, (const bf16_t*)nullptr, (bf16_t*)out, M, N, ldw, ldo, splits, slab);
+    return lrp_check_launch();
+}
+
 extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                            int64_t ldc, int dtype, int out_dtype, void* stream) {
     if (!A || !Bt || !C || M < 0 || N < 0 || K < 0) return LRP_EINVAL;

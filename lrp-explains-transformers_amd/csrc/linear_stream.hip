@@ -205,6 +205,160 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
     }
 }
 
+// =====================================================================================================================
+// Redistribution half of the eps-rule in the same regime: c[M, Kout] = s[M, N] . W[N, Kout] from the STORED weight (contraction over W's
+// rows; ref lxt/explicit/functional.py:355-364, rules.py:206-222), M <= 64 rows.
+//   * a workgroup owns 64 OUTPUT columns (128-byte segments of every W row it visits: full lines) and one of `splits` contiguous ranges of
+//     contraction rows; tiles of 128 rows, wave w takes rows 32 w .. + 31 of a tile = ONE 32-deep MFMA step for all 64 columns and all row
+//     blocks of s.  Its operands -- 4 W pieces of 8 rows x 128 B, MBMAX pieces of s (16 rows x 64 B) -- go through WAVE-PRIVATE LDS rings
+//     (D = 4 tiles, 16 KiB of W in flight per wave): no barrier inside the contraction loop, only the wave's own counted s_waitcnt.
+//   * the MFMA's W operand (8 consecutive contraction rows of one output column) is gathered from the row-major image by two
+//     ds_read_b64_tr_b16 (image [32 rows][128 B], 16-byte chunk c of row r at c ^ 2 (((r >> 1) & 1) + 2 ((r >> 3) & 1)): conflict-free for
+//     the 32-lane transpose-read groups); s fragments are plain ds_read_b128 (image [16 rows][64 B], chunk c of row r at c ^ (-(r >> 2) & 3)).
+//   * the four waves' partial sums meet in LDS once, at the end; splits > 1 (Kout = 4096: 64 column blocks x 4) writes fp32 slabs that
+//     the split-K reduce kernel of gemm.hip sums in slab order (deterministic), splits = 1 (Kout >= 14336) writes the result directly.
+// =====================================================================================================================
+constexpr int LD_D = 4;        // tiles in flight per wave
+
+#define LS_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <typename TO, int MBMAX>
+__global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
+    const bf16_t* __restrict__ sm, const bf16_t* __restrict__ W, TO* __restrict__ c, int M, int N, int Kout, int64_t lds_, int64_t ldw,
+    int64_t ldc, int tiles_per_split, int64_t slab_stride) {
+    constexpr int OPS = 4 + MBMAX;                       // VMEM operations per tile and wave
+    constexpr int WSLOT = 4096, SSLOT = MBMAX * 1024, SLOT = WSLOT + SSLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.x, sp = blockIdx.y;
+    const int n_beg = sp * tiles_per_split * 128;
+    const int nt = tiles_per_split;
+    c += (int64_t)sp * slab_stride;
+    int nb = (M + 15) >> 4;
+    nb = nb > MBMAX ? MBMAX : nb;
+    char* const ring = smem + wave * (LD_D * SLOT);
+
+    // ---- staging.  W piece p: rows 8 p + (l >> 3) of the wave's 32, LDS slot l & 7, source chunk slot ^ g(row)
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(((int64_t)(N - 1) * ldw + Kout) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sm, 0, (int)(((int64_t)(M - 1) * lds_ + N) * 2), 0x00020000);
+    int voW[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) voW[pp] = (int)((lane >> 3) * ldw * 2) + (((lane & 7) ^ (2 * (((lane >> 4) & 1) + 2 * pp))) << 4);
+    // s piece i: rows 16 i + (l >> 2), LDS slot l & 3, source chunk slot ^ f(row), f(r) = (-(r >> 2)) & 3
+    const int voS = (int)((lane >> 2) * lds_ * 2) + (((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
+    auto issue = [&](int t, int slot) {
+        const int r0 = n_beg + t * 128 + wave * 32;
+        char* dst = ring + slot * SLOT;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ls_lds_ptr_t)(dst + p * 1024), 16, voW[p & 1],
+                                                     (int)((int64_t)(r0 + 8 * p) * ldw * 2) + cb * 128, 0, 2);
+#pragma unroll
+        for (int i = 0; i < MBMAX; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (ls_lds_ptr_t)(dst + WSLOT + i * 1024), 16, voS,
+                                                     (int)((int64_t)(16 * i) * lds_ * 2) + r0 * 2, 0, 0);
+    };
+    // ---- read addresses (relative to a slot).  W operand of column tile j, half h: row 8 hi + 4 h + (i16 >> 2), chunk (2 j + ((i16 & 3) >> 1)) ^ g
+    const int hi = lane >> 4, i16 = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(ls_lds_ptr_t)smem + (uint32_t)(wave * (LD_D * SLOT));
+    const uint32_t aW = (uint32_t)((8 * hi + (i16 >> 2)) * 128) + (uint32_t)(((((i16 & 3) >> 1) ^ (2 * (((i16 >> 3) & 1) + 2 * (hi & 1))))) << 4) + 8u * (i16 & 1);
+    const uint32_t aS = (uint32_t)(WSLOT + i16 * 64) + (uint32_t)(((hi ^ ((-(i16 >> 2)) & 3))) << 4);
+
+    f32x4 acc[MBMAX][4];
+#pragma unroll
+    for (int i = 0; i < MBMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < LD_D && t < nt; ++t) issue(t, t);
+    for (int t = 0; t < nt; ++t) {
+        const int slot = t & (LD_D - 1);
+        const int rem = nt - 1 - t;                      // tiles issued after this one (at most D - 1)
+        if (rem >= LD_D - 1) asm volatile("s_waitcnt vmcnt(%[c])" :: [c] "n"((LD_D - 1) * OPS) : "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(%[c])" :: [c] "n"(2 * OPS) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%[c])" :: [c] "n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t base = lds0 + (uint32_t)(slot * SLOT);
+        const uint32_t w0 = base + aW, s0 = base + aS;
+        // the wave's W operand of its four column tiles (two transpose reads each), then the s fragments
+        u32x2 tw[4][2];
+        u32x4 sf[MBMAX];
+        ls_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            (void)&tw; (void)&w0;
+            uint32_t a_ = w0;
+            if constexpr (j > 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_) : "n"(j << 5), "v"(w0));
+            LS_DSTR(tw[j][0], a_, 0);
+            LS_DSTR(tw[j][1], a_, 512);
+        });
+        ls_for<0, MBMAX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            (void)&sf; (void)&s0;
+            LS_DSRD(sf[i], s0, i * 1024);
+        });
+        if constexpr (MBMAX == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tw[0][0]), "+v"(tw[0][1]), "+v"(tw[1][0]), "+v"(tw[1][1]), "+v"(tw[2][0]), "+v"(tw[2][1]),
+                         "+v"(tw[3][0]), "+v"(tw[3][1]), "+v"(sf[0]), "+v"(sf[1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tw[0][0]), "+v"(tw[0][1]), "+v"(tw[1][0]), "+v"(tw[1][1]), "+v"(tw[2][0]), "+v"(tw[2][1]),
+                         "+v"(tw[3][0]), "+v"(tw[3][1]), "+v"(sf[0]), "+v"(sf[1]), "+v"(sf[2]), "+v"(sf[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        // the slot is free as soon as its operands sit in registers: refill it before the MFMAs
+        if (t + LD_D < nt) issue(t + LD_D, slot);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 wv = {tw[j][0][0], tw[j][0][1], tw[j][1][0], tw[j][1][1]};
+            const bf16x8 wfrag = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i)
+                if (i < nb) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag, __builtin_bit_cast(bf16x8, sf[i]), acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- the four waves' partial sums (disjoint contraction rows) meet in LDS: wave w then owns column tile j = w
+    __syncthreads();                                     // every wave is done with its ring (all LDS-DMA landed: each waited vmcnt(0) on its last tile)
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [wave][i][j][lane]
+#pragma unroll
+    for (int i = 0; i < MBMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[((wave * MBMAX + i) * 4 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    const int col = cb * 64 + 16 * wave + 4 * hi;
+#pragma unroll
+    for (int i = 0; i < MBMAX; ++i) {
+        const int m = 16 * i + i16;
+        if (i < nb && m < M) {
+            f32x4 v = red[((0 * MBMAX + i) * 4 + wave) * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) v += red[((w2 * MBMAX + i) * 4 + wave) * 64 + lane];
+            TO* dst = c + (int64_t)m * ldc + col;
+            if (col + 3 < Kout && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c) & 15) == 0) {
+                if constexpr (sizeof(TO) == 4) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+                    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < Kout) dst[e] = from_f32<TO>(v[e]);
+            }
+        }
+    }
+}
+
+// splits of the contraction range: the smallest count that fills the chip (>= 224 workgroups), divides the tile count and leaves >= 4 tiles
+inline int dgrad_splits(int N, int Kout) {
+    const int cbs = Kout / 64, tiles = N / 128;
+    for (int s_ : {1, 2, 3, 4, 6, 8})
+        if (cbs * s_ >= 224 && cbs * s_ <= 1024 && tiles % s_ == 0 && tiles / s_ >= LD_D) return s_;
+    return 0;
+}
+
 template <typename TO, int MBMAX>
 int launch_stream(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
                   hipStream_t st) {
@@ -251,4 +405,56 @@ extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* b
     hipStream_t st = (hipStream_t)stream;
     if (out_dtype == LRP_F32) return launch_stream_m<float>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
     return launch_stream_m<bf16_t>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+}
+
+// fp32 slab reduction (+ cast) of gemm.hip's split-K path, re-used for the dgrad's contraction splits
+int lrp_launch_splitk_reduce(const float* ws, void* out, int M, int N, int64_t ldw, int64_t ldo, int splits, int64_t slab, int out_dtype,
+                             hipStream_t st);
+
+extern "C" int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds_, int64_t ldw) {
+    if (M < 1 || M > 64 || N < 512 || (N % 128) || Kout < 64 || (Kout % 64)) return 0;
+    if ((lds_ % 8) || (ldw % 8) || lds_ < N || ldw < Kout) return 0;
+    if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * lds_ >= (1ll << 30)) return 0;
+    return dgrad_splits(N, Kout) > 0;
+}
+
+extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
+    if (M < 1 || N < 1 || Kout < 1) return 0;
+    const int sp = dgrad_splits(N, Kout);
+    return sp > 1 ? (int64_t)sp * M * Kout * 4 : 0;
+}
+
+extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldw, int64_t ldc,
+                                       int dtype, int out_dtype, void* ws, void* stream) {
+    if (!sm || !W || !c || M < 0 || N < 0 || Kout < 0) return LRP_EINVAL;
+    if (M == 0 || Kout == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(sm) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (lds_ % 8) || (ldw % 8)) return LRP_EALIGN;
+    if (!lrp_linear_stream_dgrad_ok(M, N, Kout, lds_, ldw)) return LRP_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int sp = dgrad_splits(N, Kout), tps = N / 128 / sp;
+    if (sp > 1 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 15))) return LRP_EINVAL;
+    const int mb = ((M + 15) / 16 <= 2) ? 2 : 4;
+    const size_t lds = 4 * (size_t)LD_D * (4096 + mb * 1024);
+    dim3 grid(Kout / 64, sp), block(256);
+    const int64_t slab = (int64_t)M * Kout;
+#define LS_LAUNCH_DGRAD(TO, MB, OUT, LDO)                                                                                          \
+    {                                                                                                                               \
+        auto kern = linear_stream_dgrad_kernel<TO, MB>;                                                                             \
+        LRP_SET_MAX_LDS(kern, lds);                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, ldw, (int64_t)(LDO), tps, slab); \
+    }
+    if (sp > 1) {
+        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, ws, Kout) else LS_LAUNCH_DGRAD(float, 4, ws, Kout)
+        int rc = lrp_check_launch();
+        if (rc != LRP_OK) return rc;
+        return lrp_launch_splitk_reduce((const float*)ws, c, M, Kout, Kout, ldc, sp, slab, out_dtype, st);
+    }
+    if (out_dtype == LRP_F32) {
+        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, c, ldc) else LS_LAUNCH_DGRAD(float, 4, c, ldc)
+    } else {
+        if (mb == 2) LS_LAUNCH_DGRAD(bf16_t, 2, c, ldc) else LS_LAUNCH_DGRAD(bf16_t, 4, c, ldc)
+    }
+#undef LS_LAUNCH_DGRAD
+    return lrp_check_launch();
 }

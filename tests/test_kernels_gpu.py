@@ -142,6 +142,33 @@ def test_linear_stream_fwd(ops, M):
     assert not ops.linear_stream_ok(torch.empty(4, 4096, dtype=torch.bfloat16, device="cuda"), torch.empty(4096, 4096, dtype=torch.bfloat16, device="cuda"))
 
 
+@pytest.mark.parametrize("M", [1, 3, 16, 17, 33, 64])
+def test_linear_stream_dgrad(ops, M):
+    """lrp_linear_stream_dgrad (round 4): c = s W from the stored weight for M <= 64 -- 64-column workgroups, contraction range split over
+    workgroups (fp32 slabs + ordered reduce) or not (direct store), wave-private LDS rings, transpose-read W operand: both M buckets, shapes with
+    4 / 1 / 3 splits, a strided s, bf16 and fp32 outputs; vs fp64 on the same bf16 operands; deterministic (two runs bit-equal) and row-independent"""
+    g = torch.Generator().manual_seed(200 + M)
+    for (N, Kout) in ((14336, 4096), (4096, 14336), (1536, 4800), (128256 // 167 * 128, 4096)):
+        ss = torch.randn(M, N + 64, generator=g).bfloat16().cuda()
+        s_ = ss[:, :N]
+        W = (torch.randn(N, Kout, generator=g) * N ** -0.5).bfloat16().cuda()
+        assert ops.linear_stream_dgrad_ok(s_, W), (N, Kout)
+        ref = f64(s_) @ f64(W)
+        for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL[torch.bfloat16])):
+            out = torch.full((M, Kout), float("nan"), dtype=odt, device="cuda")
+            ops.linear_stream_dgrad(s_, W, out=out)
+            assert not torch.isnan(out).any() and nmax(out, ref) < tol, (M, N, Kout, odt, nmax(out, ref))
+            out2 = torch.empty_like(out)
+            ops.linear_stream_dgrad(s_, W, out=out2)
+            assert torch.equal(out, out2)
+        if M > 1:
+            assert torch.equal(ops.linear_stream_dgrad(s_[: M - 1], W), out[: M - 1])
+        if M > 2:
+            assert torch.equal(ops.linear_dgrad(s_, W), out)                 # the dispatcher takes this kernel
+    assert not ops.linear_stream_dgrad_ok(torch.empty(65, 14336, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096, dtype=torch.bfloat16, device="cuda"))
+    assert not ops.linear_stream_dgrad_ok(torch.empty(8, 14336 + 64, dtype=torch.bfloat16, device="cuda"), torch.empty(14336 + 64, 4096, dtype=torch.bfloat16, device="cuda"))
+
+
 def test_gemm_big_m_row_chunks(ops):
     """activations beyond 2^30 elements (32-bit buffer offsets of the ping-pong kernel): the library issues the launch in row chunks --
     same kernel, same layout, no W^T fallback (B >= 19 prompts at S = 2048 on the gate/up dgrad operand).  NN form on a

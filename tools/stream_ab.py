@@ -41,9 +41,14 @@ def main():
             ops.STREAM_FWD = flag
             res[name] = timed(lambda i: ops.linear_fwd(x, Ws[i % nrot], out=z))
         ops.STREAM_FWD = True
-        td = timed(lambda i: ops.linear_dgrad(s, Ws[i % nrot], out=c))
+        dg = {}
+        for name, flag in (("stream", True), ("old", False), ("stream2", True), ("old2", False)):
+            ops.STREAM_DGRAD = flag
+            dg[name] = timed(lambda i: ops.linear_dgrad(s, Ws[i % nrot], out=c))
+        ops.STREAM_DGRAD = True
         print(f"M={M:4d} fwd stream {res['stream']:7.2f} / {res['stream2']:7.2f} ({by / res['stream2'] / 1e6:5.2f}) | skinny {res['skinny']:7.2f} / {res['skinny2']:7.2f} "
-              f"({by / res['skinny2'] / 1e6:5.2f}) | dgrad {td:7.2f} ({by / td / 1e6:5.2f})", flush=True)
+              f"({by / res['skinny2'] / 1e6:5.2f}) | dgrad stream {dg['stream']:7.2f} / {dg['stream2']:7.2f} ({by / dg['stream2'] / 1e6:5.2f}) | old "
+              f"{dg['old']:7.2f} / {dg['old2']:7.2f} ({by / dg['old2'] / 1e6:5.2f})", flush=True)
 
 
 if __name__ == "__main__":
