@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
 inline int dgrad_splits(int N, int Kout) {
     const int cbs = Kout / 64, tiles = N / 128;
     for (int s_ : {1, 2, 3, 4, 6, 8})
-        if (cbs * s_ >= 224 && cbs * s_ <= 1024 && tiles % s_ == 0 && tiles / s_ >= LD_D) return s_;
+        if (cbs * s_ >= 224 && cbs * s_ <= 1024 && tiles % s_ == 0 && tiles / s_ >= LD_D) return s_;      // (validity; the policy is in _ok)
     return 0;
 }
 
@@ -411,11 +411,17 @@ extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* b
 int lrp_launch_splitk_reduce(const float* ws, void* out, int M, int N, int64_t ldw, int64_t ldo, int splits, int64_t slab, int out_dtype,
                              hipStream_t st);
 
-extern "C" int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds_, int64_t ldw) {
-    if (M < 1 || M > 64 || N < 512 || (N % 128) || Kout < 64 || (Kout % 64)) return 0;
-    if ((lds_ % 8) || (ldw % 8) || lds_ < N || ldw < Kout) return 0;
-    if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * lds_ >= (1ll << 30)) return 0;
+static bool dgrad_valid(int M, int N, int Kout, int64_t lds_, int64_t ldw) {
+    if (M < 1 || M > 64 || N < 512 || (N % 128) || Kout < 64 || (Kout % 64)) return false;
+    if ((lds_ % 8) || (ldw % 8) || lds_ < N || ldw < Kout) return false;
+    if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * lds_ >= (1ll << 30)) return false;
     return dgrad_splits(N, Kout) > 0;
+}
+// the kernel applies AND is the right one: measured (profiles/r04_call6_stream_dgrad_ab.txt) 1.5-2 us ahead of the split-K skinny path for
+// M <= 32 on layer-sized weights with <= 320 workgroups; behind it at M = 64 (four row blocks per wave) and on the 128256-row LM head (6 splits)
+extern "C" int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds_, int64_t ldw) {
+    if (!dgrad_valid(M, N, Kout, lds_, ldw)) return 0;
+    return M <= 32 && (Kout / 64) * dgrad_splits(N, Kout) <= 320;
 }
 
 extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
@@ -430,7 +436,7 @@ extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* W, void* c, i
     if (M == 0 || Kout == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(sm) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (lds_ % 8) || (ldw % 8)) return LRP_EALIGN;
-    if (!lrp_linear_stream_dgrad_ok(M, N, Kout, lds_, ldw)) return LRP_ESHAPE;
+    if (!dgrad_valid(M, N, Kout, lds_, ldw)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int sp = dgrad_splits(N, Kout), tps = N / 128 / sp;
     if (sp > 1 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 15))) return LRP_EINVAL;

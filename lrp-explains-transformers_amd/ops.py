@@ -701,8 +701,8 @@ STREAM_DGRAD = True       # module attribute (A/B measurements): False keeps eve
 
 
 def linear_stream_dgrad_ok(s2, W):
-    """does lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings, transpose-read W operand) serve c = s2 W?  bf16, M <= 64,
-    N % 128 == 0, Kout % 64 == 0, contiguous 16-byte aligned rows, and a split count that fills the chip"""
+    """is lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings, transpose-read W operand) the kernel for c = s2 W?  bf16,
+    M <= 32, N % 128 == 0, Kout % 64 == 0, contiguous 16-byte aligned rows, and a split count that fills the chip with <= 320 workgroups"""
     if not STREAM_DGRAD or s2.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or s2.dim() != 2 or W.dim() != 2:
         return False
     if s2.stride(1) != 1 or W.stride(1) != 1 or s2.data_ptr() % 16 or W.data_ptr() % 16:
@@ -727,7 +727,7 @@ def linear_stream_dgrad(s2, W, out=None, out_dtype=None):
 def linear_dgrad(s2, W, out=None, out_dtype=None):
     """c[M,K] = s2[M,N] @ W[N,K]: the redistribution half of the Linear eps-rule (ref: lxt/explicit/functional.py:355-364) from the
     STORED weight layout:
-       2 < M <= 64, bf16, N % 128 == 0, Kout % 64 == 0        : lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings)
+       2 < M <= 32, bf16, N % 128 == 0, Kout % 64 == 0        : lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings)
        M <= 2, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
        M <= 256, bf16, N % 64 == 0                           : split-K skinny path, NN form
        bf16 problems of >= 190 tiles of 256 x 256            : lrp_gemm_nn (no W^T copy)
@@ -735,7 +735,7 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     M, N = s2.shape
     K = W.shape[1]
     odt = out_dtype or (out.dtype if out is not None else W.dtype)
-    if 2 < M <= 64 and linear_stream_dgrad_ok(s2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
+    if 2 < M <= 32 and linear_stream_dgrad_ok(s2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
         return linear_stream_dgrad(s2, W, out=out, out_dtype=odt)
     nn = gemm_nn_ok(s2, W)
     if (M <= 2 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
