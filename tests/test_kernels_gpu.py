@@ -152,7 +152,7 @@ def test_linear_stream_dgrad(ops, M):
         ss = torch.randn(M, N + 64, generator=g).bfloat16().cuda()
         s_ = ss[:, :N]
         W = (torch.randn(N, Kout, generator=g) * N ** -0.5).bfloat16().cuda()
-        assert ops.linear_stream_dgrad_ok(s_, W) == (M <= 32 and N < 90000), (N, Kout)     # dispatch policy: M <= 32, <= 320 workgroups
+        assert ops.linear_stream_dgrad_ok(s_, W) == (M <= 32), (N, Kout)     # dispatch policy: M <= 32 (and <= 320 workgroups: true for these shapes)
         ref = f64(s_) @ f64(W)
         for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL[torch.bfloat16])):
             out = torch.full((M, Kout), float("nan"), dtype=odt, device="cuda")
@@ -163,10 +163,12 @@ def test_linear_stream_dgrad(ops, M):
             assert torch.equal(out, out2)
         if M > 1:
             assert torch.equal(ops.linear_stream_dgrad(s_[: M - 1], W), out[: M - 1])
-        if 2 < M <= 32 and N < 90000:
+        if 2 < M <= 32:
             assert torch.equal(ops.linear_dgrad(s_, W), out)                 # the dispatcher takes this kernel
     assert not ops.linear_stream_dgrad_ok(torch.empty(33, 14336, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096, dtype=torch.bfloat16, device="cuda"))
     assert not ops.linear_stream_dgrad_ok(torch.empty(8, 14336 + 64, dtype=torch.bfloat16, device="cuda"), torch.empty(14336 + 64, 4096, dtype=torch.bfloat16, device="cuda"))
+    # the 128256-row LM head would need 6 contraction splits (384 workgroups): stays on the split-K skinny path
+    assert not bool(ops.lib.lrp_linear_stream_dgrad_ok(8, 128256, 4096, 128256, 4096))
 
 
 def test_gemm_big_m_row_chunks(ops):
