@@ -149,3 +149,78 @@ def test_generic_attention_tile_swizzle():
         sw = min(nch, 16) - 1
         for kk in range(nch // 4):
             assert conflicts(lambda lane: (lane & 15) * pitch + ((((kk * 4) + (lane >> 4)) ^ ((lane & 15) & sw)) << 4), B128_GROUPS, 16) == 0
+
+
+def test_linear_stream_lds_images_are_conflict_free():
+    """linear_stream.hip (round 4).  Forward / dgrad operand images in the wave-private LDS rings:
+    (1) dgrad W image [32 contraction rows][128 B], 16-byte chunk c of row r at c ^ g(r), g(r) = 2 (((r >> 1) & 1) + 2 ((r >> 3) & 1)): the staging
+        map (piece p: rows 8 p + (l >> 3), slot l & 7, source chunk slot ^ g) tiles the image once, and the MFMA operand of column tile j (8
+        consecutive contraction rows of one output column) gathered by ds_read_b64_tr_b16 at row 8 hi + 4 h + (i16 >> 2), chunk (2 j + ((i16 & 3) >> 1))
+        ^ g, byte 8 (i16 & 1) is conflict-free under the 32-lane transpose-read groups;
+    (2) dgrad s image [16 rows][64 B] per row block, chunk c of row r at c ^ ((-(r >> 2)) & 3): the 16-row ds_read_b128 fragments (row l & 15,
+        chunk l >> 4) are conflict-free under the hardware's lane groups"""
+    g = lambda r: 2 * (((r >> 1) & 1) + 2 * ((r >> 3) & 1))           # noqa: E731
+    seen = {}
+    for p_, lane in itertools.product(range(4), range(64)):
+        row, slot = 8 * p_ + (lane >> 3), lane & 7
+        assert 2 * (((lane >> 4) & 1) + 2 * (p_ & 1)) == g(row)       # what the kernel computes from the lane id and p & 1
+        seen[(row, slot)] = slot ^ g(row)
+    assert len(seen) == 32 * 8
+    for row, c in itertools.product(range(32), range(8)):
+        assert seen[(row, c ^ g(row))] == c
+    for j, h in itertools.product(range(4), range(2)):
+        def tr(lane, j=j, h=h):
+            hi, i16 = lane >> 4, lane & 15
+            row = 8 * hi + 4 * h + (i16 >> 2)
+            gl = 2 * (((i16 >> 3) & 1) + 2 * (hi & 1))
+            assert gl == g(row)
+            a0 = (8 * hi + (i16 >> 2)) * 128 + ((((i16 & 3) >> 1) ^ gl) << 4) + 8 * (i16 & 1)      # the kernel's base (j = 0, h = 0)
+            addr = (a0 ^ (j << 5)) + 512 * h
+            assert addr == row * 128 + (((2 * j + ((i16 & 3) >> 1)) ^ g(row)) << 4) + 8 * (i16 & 1)
+            return addr
+        assert conflicts(tr, TR_GROUPS, 8) == 0
+    f = lambda r: (-(r >> 2)) & 3                                     # noqa: E731
+    img = {}
+    for lane in range(64):
+        row, slot = lane >> 2, lane & 3
+        assert ((-(lane >> 4)) & 3) == f(row)
+        img[(row, slot)] = slot ^ f(row)
+    for row, c in itertools.product(range(16), range(4)):
+        assert img[(row, c ^ f(row))] == c
+
+    def sfrag(lane):
+        hi, i16 = lane >> 4, lane & 15
+        return i16 * 64 + ((hi ^ f(i16)) << 4)
+    assert conflicts(sfrag, B128_GROUPS, 16) == 0
+
+
+def test_gemma3_mm_row_intervals_equal_hf_mask_semantics():
+    """engine_gemma3_mm.mm_row_intervals: per-row key intervals == (causal [and sliding window]) OR same-image-block, the mask HF's
+    create_masks_for_vision_model builds from token_type_ids (image tokens of one block attend to each other in both directions)"""
+    import torch
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lrp-explains-transformers_amd", "engine_gemma3_mm.py")
+    src = open(path).read()
+    ns = {}
+    start = src.index("def mm_row_intervals")
+    exec("import torch\n" + src[start: src.index("def vision_weights_from_hf")], ns)       # the pure function alone (the module needs the .so)
+    tt = torch.zeros(3, 40, dtype=torch.long)
+    tt[0, 3:11] = 1; tt[0, 20:24] = 1; tt[1, 0:8] = 1; tt[2, 32:40] = 1
+    for w in (5, 16, 64):
+        iv = ns["mm_row_intervals"](tt, w)
+        B, S = tt.shape
+        i = torch.arange(S)
+        for b in range(B):
+            row = tt[b].bool()
+            blk, cur = torch.full((S,), -1), -1
+            for j in range(S):
+                if row[j] and (j == 0 or not row[j - 1]):
+                    cur += 1
+                if row[j]:
+                    blk[j] = cur
+            same = (blk[:, None] == blk[None, :]) & (blk[:, None] >= 0)
+            causal = i[None, :] <= i[:, None]
+            for name, m in (("global", causal | same), ("local", (causal & (i[None, :] > i[:, None] - w)) | same)):
+                lo, hi = iv[name]
+                assert torch.equal(m, (i[None, :] >= lo[b][:, None]) & (i[None, :] < hi[b][:, None])), (b, name, w)

@@ -65,3 +65,34 @@ def test_monkey_patch_zennit_fails_loudly():
     from lxt_amd.efficient import monkey_patch_zennit
     with pytest.raises(NotImplementedError, match="GammaComposite"):
         monkey_patch_zennit()
+
+
+def test_gemma3_config_rope_under_both_transformers_schemas():
+    """engine_gemma3.config_from_hf: per-layer-type rotary frequencies from transformers-5 `rope_parameters` AND from the 4.x schema
+    (rope_theta / rope_local_base_freq / rope_scaling) -- equal tables, linear scaling = HF's own initialiser, dynamic types refused loudly"""
+    import pytest
+    import torch
+    from transformers import Gemma3TextConfig
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    import lxt_amd.engine_gemma3 as e
+    cfg = Gemma3TextConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                           head_dim=32, layer_types=["sliding_attention", "full_attention"],
+                           rope_parameters={"sliding_attention": {"rope_type": "default", "rope_theta": 10000.0},
+                                            "full_attention": {"rope_type": "linear", "factor": 8.0, "rope_theta": 1e6}})
+    c5 = e.config_from_hf(cfg)
+    inv, att = ROPE_INIT_FUNCTIONS["linear"](cfg, "cpu", layer_type="full_attention")
+    assert torch.equal(inv.float(), c5["rope"]["full_attention"][0]) and att == 1.0
+
+    class C4:                                                   # a transformers-4.x style config object
+        pass
+    c4 = C4()
+    c4.__dict__.update(dict(model_type="gemma3_text", layer_types=["sliding_attention", "full_attention"], head_dim=32, rope_theta=1e6,
+                            rope_local_base_freq=10000.0, rope_scaling={"rope_type": "linear", "factor": 8.0}, hidden_size=128, intermediate_size=256,
+                            num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=512, rms_norm_eps=1e-6,
+                            query_pre_attn_scalar=32, sliding_window=16, hidden_activation="gelu_pytorch_tanh"))
+    c4c = e.config_from_hf(c4)
+    for lt in ("sliding_attention", "full_attention"):
+        assert torch.equal(c4c["rope"][lt][0], c5["rope"][lt][0])
+    c4.rope_scaling = {"rope_type": "dynamic", "factor": 2.0}
+    with pytest.raises(NotImplementedError):
+        e.config_from_hf(c4)
