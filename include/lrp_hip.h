@@ -89,12 +89,15 @@ int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* 
  * and one of `splits` ranges of contraction rows, operands go through wave-private LDS rings (no barrier in the contraction loop), the
  * MFMA's W operand is gathered by ds_read_b64_tr_b16.  splits > 1 (few column blocks, e.g. Kout = 4096) writes fp32 slabs into `ws`
  * (lrp_linear_stream_dgrad_ws BYTES, caller-allocated) that a second small kernel sums in slab order; otherwise the result is written directly.
+ * z (optional, [M,N] with pitch ldz; NULL = none): the Linear's forward output -- the eps-rule's stabiliser is then formed on the fly,
+ * s' = s z / (z + eps) (s = incoming gradient) or, relevance_in = 1, s / (z + eps) (s = incoming relevance), rounded to bf16 as lrp_eps_scale
+ * would store it: one launch for  R/(z+eps) -> (.) W  (ref lxt/explicit/functional.py:355-358).
  * bf16 operands, out bf16 / fp32, N a multiple of 128, Kout of 64; lrp_linear_stream_dgrad_ok = 1 when the kernel applies and fills the chip.
  * ref: lxt/explicit/functional.py:355-364 (`relevance_norm @ weight`), lxt/explicit/rules.py:206-222. */
 int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds, int64_t ldw);
 int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout);
-int lrp_linear_stream_dgrad(const void* s, const void* W, void* c, int M, int N, int Kout, int64_t lds, int64_t ldw, int64_t ldc,
-                            int dtype, int out_dtype, void* ws, void* stream);
+int lrp_linear_stream_dgrad(const void* s, const void* z, const void* W, void* c, int M, int N, int Kout, int64_t lds, int64_t ldz,
+                            int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream);
 
 /* lrp_gemm_skinny: the same two products with SPLIT-K, for problems whose 256 x 256 tile count alone leaves CUs idle: 1 <= M <= 256 rows
  * (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic

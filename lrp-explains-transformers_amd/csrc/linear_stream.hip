@@ -222,12 +222,15 @@ constexpr int LD_D = 4;        // tiles in flight per wave
 
 #define LS_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <typename TO, int MBMAX>
+// SC: the eps-rule's stabiliser formed on the fly -- the operand is g (incoming gradient or relevance) and z (the Linear's forward output)
+// travels beside it: s = g z / (z + eps) (gradient form) or g / (z + eps) (relevance form, rel_in), rounded to bf16 like the stand-alone
+// lrp_eps_scale would store it: no separate launch, no s round trip (ref lxt/explicit/functional.py:355-358).
+template <typename TO, int MBMAX, bool SC>
 __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
-    const bf16_t* __restrict__ sm, const bf16_t* __restrict__ W, TO* __restrict__ c, int M, int N, int Kout, int64_t lds_, int64_t ldw,
-    int64_t ldc, int tiles_per_split, int64_t slab_stride) {
-    constexpr int OPS = 4 + MBMAX;                       // VMEM operations per tile and wave
-    constexpr int WSLOT = 4096, SSLOT = MBMAX * 1024, SLOT = WSLOT + SSLOT;
+    const bf16_t* __restrict__ sm, const bf16_t* __restrict__ zm, const bf16_t* __restrict__ W, TO* __restrict__ c, int M, int N, int Kout,
+    int64_t lds_, int64_t ldz, int64_t ldw, int64_t ldc, int tiles_per_split, int64_t slab_stride, float eps, int rel_in) {
+    constexpr int OPS = 4 + (SC ? 2 : 1) * MBMAX;        // VMEM operations per tile and wave
+    constexpr int WSLOT = 4096, SSLOT = MBMAX * 1024, SLOT = WSLOT + (SC ? 2 : 1) * SSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -247,6 +250,8 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
     for (int pp = 0; pp < 2; ++pp) voW[pp] = (int)((lane >> 3) * ldw * 2) + (((lane & 7) ^ (2 * (((lane >> 4) & 1) + 2 * pp))) << 4);
     // s piece i: rows 16 i + (l >> 2), LDS slot l & 3, source chunk slot ^ f(row), f(r) = (-(r >> 2)) & 3
     const int voS = (int)((lane >> 2) * lds_ * 2) + (((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? zm : sm), 0, (int)(((int64_t)(M - 1) * (SC ? ldz : lds_) + N) * 2), 0x00020000);
+    const int voZ = (int)((lane >> 2) * ldz * 2) + (((lane & 3) ^ ((-(lane >> 4)) & 3)) << 4);
     auto issue = [&](int t, int slot) {
         const int r0 = n_beg + t * 128 + wave * 32;
         char* dst = ring + slot * SLOT;
@@ -258,6 +263,12 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
         for (int i = 0; i < MBMAX; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (ls_lds_ptr_t)(dst + WSLOT + i * 1024), 16, voS,
                                                      (int)((int64_t)(16 * i) * lds_ * 2) + r0 * 2, 0, 0);
+        if constexpr (SC) {
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsZ, (ls_lds_ptr_t)(dst + WSLOT + SSLOT + i * 1024), 16, voZ,
+                                                         (int)((int64_t)(16 * i) * ldz * 2) + r0 * 2, 0, 0);
+        }
     };
     // ---- read addresses (relative to a slot).  W operand of column tile j, half h: row 8 hi + 4 h + (i16 >> 2), chunk (2 j + ((i16 & 3) >> 1)) ^ g
     const int hi = lane >> 4, i16 = lane & 15;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
         const uint32_t w0 = base + aW, s0 = base + aS;
         // the wave's W operand of its four column tiles (two transpose reads each), then the s fragments
         u32x2 tw[4][2];
-        u32x4 sf[MBMAX];
+        u32x4 sf[MBMAX], zf[MBMAX];
         ls_for<0, 4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             (void)&tw; (void)&w0;
@@ -298,6 +309,15 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
             (void)&sf; (void)&s0;
             LS_DSRD(sf[i], s0, i * 1024);
         });
+        if constexpr (SC) {
+            ls_for<0, MBMAX>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                (void)&zf; (void)&s0;
+                LS_DSRD(zf[i], s0, SSLOT + i * 1024);
+            });
+            if constexpr (MBMAX == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zf[0]), "+v"(zf[1]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zf[0]), "+v"(zf[1]), "+v"(zf[2]), "+v"(zf[3]));
+        }
         if constexpr (MBMAX == 2)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tw[0][0]), "+v"(tw[0][1]), "+v"(tw[1][0]), "+v"(tw[1][1]), "+v"(tw[2][0]), "+v"(tw[2][1]),
                          "+v"(tw[3][0]), "+v"(tw[3][1]), "+v"(sf[0]), "+v"(sf[1]));
@@ -308,6 +328,22 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
         // the slot is free as soon as its operands sit in registers: refill it before the MFMAs
         if (t + LD_D < nt) issue(t + LD_D, slot);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SC) {
+            // s = g z / (z + eps) or g / (z + eps), element-wise on the fragments (8 bf16 per lane and row block), rounded to bf16
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i)
+                if (i < nb) {
+                    const bf16x8 gv = __builtin_bit_cast(bf16x8, sf[i]), zv = __builtin_bit_cast(bf16x8, zf[i]);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float zz = (float)zv[e];
+                        const float r = __builtin_amdgcn_rcpf(zz + eps);
+                        o[e] = (bf16_t)((float)gv[e] * (rel_in ? 1.f : zz) * r);
+                    }
+                    sf[i] = __builtin_bit_cast(u32x4, o);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u32x4 wv = {tw[j][0][0], tw[j][0][1], tw[j][1][0], tw[j][1][1]};
@@ -430,9 +466,10 @@ extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
     return sp > 1 ? (int64_t)sp * M * Kout * 4 : 0;
 }
 
-extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldw, int64_t ldc,
-                                       int dtype, int out_dtype, void* ws, void* stream) {
+extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
+                                       int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream) {
     if (!sm || !W || !c || M < 0 || N < 0 || Kout < 0) return LRP_EINVAL;
+    if (zm && ((reinterpret_cast<uintptr_t>(zm) & 15) || (ldz % 8) || ldz < N || (int64_t)M * ldz >= (1ll << 30))) return LRP_EALIGN;
     if (M == 0 || Kout == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(sm) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (lds_ % 8) || (ldw % 8)) return LRP_EALIGN;
@@ -441,14 +478,23 @@ extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* W, void* c, i
     const int sp = dgrad_splits(N, Kout), tps = N / 128 / sp;
     if (sp > 1 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 15))) return LRP_EINVAL;
     const int mb = ((M + 15) / 16 <= 2) ? 2 : 4;
-    const size_t lds = 4 * (size_t)LD_D * (4096 + mb * 1024);
+    if (zm && mb == 4) return LRP_ESHAPE;              // the fused stabiliser doubles the small operand's LDS ring: 32 rows at most
+    const size_t lds = 4 * (size_t)LD_D * (4096 + (zm ? 2 : 1) * mb * 1024);
     dim3 grid(Kout / 64, sp), block(256);
     const int64_t slab = (int64_t)M * Kout;
 #define LS_LAUNCH_DGRAD(TO, MB, OUT, LDO)                                                                                          \
     {                                                                                                                               \
-        auto kern = linear_stream_dgrad_kernel<TO, MB>;                                                                             \
-        LRP_SET_MAX_LDS(kern, lds);                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, ldw, (int64_t)(LDO), tps, slab); \
+        if (zm) {                                                                                                                   \
+            auto kern = linear_stream_dgrad_kernel<TO, MB, true>;                                                                   \
+            LRP_SET_MAX_LDS(kern, lds);                                                                                             \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)zm, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, ldz, \
+                               ldw, (int64_t)(LDO), tps, slab, eps, relevance_in);                                                  \
+        } else {                                                                                                                    \
+            auto kern = linear_stream_dgrad_kernel<TO, MB, false>;                                                                  \
+            LRP_SET_MAX_LDS(kern, lds);                                                                                             \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)nullptr, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, \
+                               (int64_t)0, ldw, (int64_t)(LDO), tps, slab, 0.f, 0);                                                 \
+        }                                                                                                                           \
     }
     if (sp > 1) {
         if (mb == 2) LS_LAUNCH_DGRAD(float, 2, ws, Kout) else LS_LAUNCH_DGRAD(float, 4, ws, Kout)

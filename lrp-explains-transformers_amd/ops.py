@@ -710,17 +710,20 @@ def linear_stream_dgrad_ok(s2, W):
     return bool(lib.lrp_linear_stream_dgrad_ok(s2.shape[0], W.shape[0], W.shape[1], s2.stride(0), W.stride(0)))
 
 
-def linear_stream_dgrad(s2, W, out=None, out_dtype=None):
-    """c[M,Kout] = s2[M,N] @ W[N,Kout] for M <= 64 from the stored weight, W streamed once"""
+def linear_stream_dgrad(s2, W, out=None, out_dtype=None, z=None, eps=0.0, relevance_in=False):
+    """c[M,Kout] = s'[M,N] @ W[N,Kout] for M <= 64 from the stored weight, W streamed once; s' = s2, or with z (the Linear's forward output)
+    the eps-rule's stabilised operand formed inside the kernel: s2 z / (z + eps), or s2 / (z + eps) when s2 is a relevance (relevance_in)"""
     M, N = s2.shape
     Kout = W.shape[1]
-    same(s2, W)
+    same(s2, W, z)
+    if z is not None and (z.stride(1) != 1 or tuple(z.shape) != (M, N)):
+        raise ValueError("linear_stream_dgrad: z must be [M, N] with contiguous rows")
     if out is None:
         out = torch.empty(M, Kout, device=s2.device, dtype=out_dtype or s2.dtype)
     need = lib.lrp_linear_stream_dgrad_ws(M, N, Kout)
     ws = workspace(need, s2) if need else None
-    check(lib.lrp_linear_stream_dgrad(p(s2), p(W), p(out), M, N, Kout, s2.stride(0), W.stride(0), out.stride(0), dt(s2), _DT[out.dtype],
-                                      p(ws), stream()), "lrp_linear_stream_dgrad")
+    check(lib.lrp_linear_stream_dgrad(p(s2), p(z), p(W), p(out), M, N, Kout, s2.stride(0), z.stride(0) if z is not None else 0, W.stride(0),
+                                      out.stride(0), eps, int(relevance_in), dt(s2), _DT[out.dtype], p(ws), stream()), "lrp_linear_stream_dgrad")
     return out
 
 

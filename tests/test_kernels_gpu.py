@@ -163,6 +163,18 @@ def test_linear_stream_dgrad(ops, M):
             assert torch.equal(out, out2)
         if M > 1:
             assert torch.equal(ops.linear_stream_dgrad(s_[: M - 1], W), out[: M - 1])
+        if M <= 32:
+            # the eps-rule's stabiliser formed inside the kernel (gradient and relevance forms) vs fp64 on the same bf16 operands; the
+            # operand s' is rounded to bf16 inside the kernel exactly where the unfused pair (lrp_eps_scale + dgrad) stores it
+            zz = (torch.randn(M, N, generator=g) * 0.5).bfloat16().cuda()
+            for rel_in, eps in ((False, 1e-6), (True, 1e-6), (True, 1e-2)):
+                f = (1.0 if rel_in else f64(zz)) / (f64(zz) + eps)
+                sref = (f64(s_) * f).bfloat16()                                  # the rounding point of the operand
+                o32 = ops.linear_stream_dgrad(s_, W, z=zz, eps=eps, relevance_in=rel_in, out_dtype=torch.float32)
+                ref_s = f64(sref) @ f64(W)
+                assert nmax(o32, ref_s) < 2e-2, (M, N, Kout, rel_in, eps, nmax(o32, ref_s))
+                unf = ops.linear_stream_dgrad(ops.eps_scale(s_.contiguous(), zz, 1.0, eps, relevance=rel_in), W, out_dtype=torch.float32)
+                assert nmax(o32, unf) < 2e-2
         if 2 < M <= 32:
             assert torch.equal(ops.linear_dgrad(s_, W), out)                 # the dispatcher takes this kernel
     assert not ops.linear_stream_dgrad_ok(torch.empty(33, 14336, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096, dtype=torch.bfloat16, device="cuda"))
