@@ -114,7 +114,8 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
     kernel"; SURVEY.md 8d: bf16 arithmetic intensity ~2 M FLOP/B, HBM-bound for M <~ 160 rows).  Everything is timed THROUGH THE PRODUCT
     DISPATCH (ops.linear_fwd / ops.linear_dgrad: the one-launch weight-streaming forward / dgrad kernels of linear_stream.hip, the W-streaming
     small-M kernels, the split-K skinny path of the ping-pong GEMM in its NT and NN forms -- W is read ONCE per direction from its stored
-    layout, no W^T copy); the stabiliser is formed inside the dgrad kernel for M <= 32 and by a separate lrp_eps_scale launch above.  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
+    layout, no W^T copy); the stabiliser is formed inside the dgrad kernel for M <= 16 (one 16-row block: beyond that its
+    element-wise work outweighs the launch it saves, profiles/r04_call8_*.txt) and by a separate lrp_eps_scale launch above.  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
     [vocab, hidden] at M = prompts per step.  `table` = M = 1 ... 160 on the gate/up-sized weight [14336, 4096] and on the LM head.
     Algorithmic bytes = sizeof * (N K + M K + M N) forward, sizeof * (N K + M K + 2 M N) backward; HIP events on the launching
     stream, 21 launches each, ROTATING through three distinct layer-sized weights (3 x 117 MB > the 256-MB Infinity Cache: the figure is
@@ -151,7 +152,7 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
             W = Ws[i % len(Ws)]
             if M <= 2:
                 return ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the W stream (lane-local FMA kernel)
-            if M <= 32 and ops.linear_stream_dgrad_ok(gg, W):
+            if M <= 16 and ops.linear_stream_dgrad_ok(gg, W):
                 return ops.linear_stream_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the MFMA weight-streaming dgrad
             return ops.linear_dgrad(ops.eps_scale(gg, z, 1.0, 1e-6), W, out=out)
         bwd(0)

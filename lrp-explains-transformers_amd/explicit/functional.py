@@ -63,8 +63,8 @@ class linear_epsilon_fn(Function):
                                            relevance_out=True)
             return R_in.view(ctx.shp), None, None, None
         R2 = R_out.reshape(z.shape)
-        if 2 < z.shape[0] <= 32 and ctx.epsilon != 0.0 and R2.stride(-1) == 1 and ops.linear_stream_dgrad_ok(R2, w):
-            # 3 ... 32 rows, bf16: R / (z + eps) is formed inside the weight-streaming dgrad (one launch for the stabiliser and the contraction)
+        if 2 < z.shape[0] <= 16 and ctx.epsilon != 0.0 and R2.stride(-1) == 1 and ops.linear_stream_dgrad_ok(R2, w):
+            # 3 ... 16 rows, bf16: R / (z + eps) is formed inside the weight-streaming dgrad (one launch for the stabiliser and the contraction)
             R_in = ops.mul(ops.linear_stream_dgrad(R2, w, z=z, eps=ctx.epsilon, relevance_in=True), x2)
             return R_in.view(ctx.shp), None, None, None
         s = ops.eps_scale(R2, z, 1.0, ctx.epsilon, relevance=True)
