@@ -233,12 +233,11 @@ def mode_batch_probes(eng, ops, cfg, dev, peak, S, steps=3):
     return out
 
 
-def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048, image=True):
-    """BASELINE config 4's text tower through the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP), AFTER and OUTSIDE the headline
-    timed region: Gemma-3-4B shape (34 layers, H 2560, 8 / 4 heads of d = 256, I 10240, sliding window 1024 on 5 of 6 layers, tied
-    262208-token head), random init on the device, seq = 2048, 4 prompts per step."""
+def config4_text_engine(dev, dtype, S4=2048, L=34):
+    """Gemma-3-4B text tower shape (L layers of H 2560, 8 / 4 heads of d = 256, I 10240, window 1024 on 5 of 6 layers, tied 262208-token head),
+    random init on the device -> (engine, generator, vocab)"""
     from lxt_amd.engine_gemma3 import Gemma3LRP
-    L, H, I, nq, nk, d, V = 34, 2560, 10240, 8, 4, 256, 262208
+    H, I, nq, nk, d, V = 2560, 10240, 8, 4, 256, 262208
     g = torch.Generator(device=dev).manual_seed(7)
     rn = lambda sd, *s: (torch.randn(*s, generator=g, device=dev) * sd).to(dtype)  # noqa: E731
     inv = lambda theta, f: 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d)) / f  # noqa: E731
@@ -252,6 +251,14 @@ def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048, image=True):
         for _ in range(L)])
     eng = Gemma3LRP(cfg, W, dtype=dtype, device=dev, max_seq=S4)
     del W, emb
+    return eng, g, V
+
+
+def config4_probe(ops, dev, dtype, peak, steps=3, B4=4, S4=2048, image=True):
+    """BASELINE config 4's text tower through the fused Gemma-3 driver (lxt_amd.engine_gemma3.Gemma3LRP), AFTER and OUTSIDE the headline
+    timed region: Gemma-3-4B shape (34 layers, H 2560, 8 / 4 heads of d = 256, I 10240, sliding window 1024 on 5 of 6 layers, tied
+    262208-token head), random init on the device, seq = 2048, 4 prompts per step."""
+    eng, g, V = config4_text_engine(dev, dtype, S4)
     ids = torch.randint(0, V, (B4 * (steps + 1), S4), generator=torch.Generator().manual_seed(99)).to(dev)
     R = eng.explain(ids[:B4])["R_tok"]
     torch.cuda.synchronize()

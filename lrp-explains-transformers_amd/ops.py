@@ -646,6 +646,28 @@ def linear_smallm_dgrad(g, W, z=None, x=None, eps=0.0, relevance_in=False, relev
     return out
 
 
+TAIL_SPLIT = True        # module attribute (A/B measurements): False = the round-3 handling of 257 ... 511-tile GEMMs
+
+
+def tail_split_cols(M, Nout, Kc):
+    """GEMMs of 257 ... 511 tiles of 256 x 256 (Gemma-3-4B: 8192 x 2560 = 320 tiles = 1.25 rounds of the 256 CUs: the second round keeps a
+    quarter of the chip busy for a whole tile time).  -> the number of leading output columns that make exactly ONE full round (256 tiles);
+    the remaining columns (<= 128 tiles) are issued as a second problem through the split-K path, which spreads them over all CUs (K split so
+    that tail tiles x splits = 256).  Two launches of ~1 + 0.25 tile times instead of 2 (or, for K >= 8192, instead of splitting the WHOLE
+    problem in two with fp32 slabs of the whole output).  None when the shape does not qualify."""
+    if not TAIL_SPLIT:
+        return None
+    tm, tn = (M + 255) // 256, (Nout + 255) // 256
+    tiles = tm * tn
+    if not (256 < tiles < 512) or 256 % tm or tm > 256:
+        return None
+    main = (256 // tm) * 256
+    tail_tiles = tm * ((Nout - main + 255) // 256)
+    if main <= 0 or main >= Nout or tail_tiles > 128 or Kc // 64 < 8 * (256 // tail_tiles):
+        return None
+    return main
+
+
 STREAM_FWD = True        # module attribute (A/B measurements): False sends every M <= 256 forward to the split-K skinny path
 
 
@@ -682,6 +704,15 @@ def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
     odt = out_dtype or (out.dtype if out is not None else x2.dtype)
     if M <= SKINNY_MAX and linear_stream_ok(x2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
         return linear_stream_fwd(x2, W, bias, out=out, out_dtype=odt)
+    if gemm_nn_ok(x2, W) and M > SKINNY_MAX:
+        main = tail_split_cols(M, N, K)
+        if main is not None and (out is None or out.stride(1) == 1):
+            if out is None:
+                out = torch.empty(M, N, device=x2.device, dtype=odt)
+            bias = aux(bias, x2, N)
+            gemm_nt_2d(x2, W[:main], out[:, :main], None if bias is None else bias[:main])                  # one full round of the chip
+            gemm_skinny(x2, W[main:], out[:, main:], nn=False, bias=None if bias is None else bias[main:])    # the tail, K-split over all CUs
+            return out
     if splitk_ok(M, N, K) and gemm_nn_ok(x2, W):
         if out is None:
             out = torch.empty(M, N, device=x2.device, dtype=odt)
@@ -743,6 +774,14 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     nn = gemm_nn_ok(s2, W)
     if (M <= 2 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
         return linear_smallm_dgrad(s2, W, out=out, out_dtype=odt)
+    if nn and M > SKINNY_MAX:
+        main = tail_split_cols(M, K, N)
+        if main is not None and (out is None or out.stride(1) == 1) and W.data_ptr() % 16 == 0:
+            if out is None:
+                out = torch.empty(M, K, device=s2.device, dtype=odt)
+            gemm_nn_2d(s2, W[:, :main], out[:, :main])                           # one full round of the chip
+            gemm_skinny(s2, W[:, main:], out[:, main:], nn=True)                  # the tail (<= 128 tiles), contraction split over all CUs
+            return out
     if nn:
         split = splitk_ok(M, K, N)
         # the NN form exists only in the 256 x 256 ping-pong kernel: problems it cannot fill (fewer than 190 tiles and no split-K: BERT-sized

@@ -213,6 +213,51 @@ def test_gemm_big_m_row_chunks(ops):
     torch.cuda.empty_cache()
 
 
+def test_gemm_tail_split(ops):
+    """257 ... 511-tile GEMMs (Gemma-3-4B: 8192 x 2560 = 320 tiles) are issued as one full round of the chip (256 tiles, plain kernel) + the
+    remaining columns K-split over all CUs (ops.tail_split_cols).  Both operand forms through the dispatchers, with and without bias, into
+    padded outputs: equal to fp64 within bf16 rounding, and the main part bit-equal to the undivided launch (same kernel, same tiles)"""
+    g = torch.Generator().manual_seed(17)
+    assert ops.tail_split_cols(8192, 2560, 2048) == 2048 and ops.tail_split_cols(8192, 2560, 20480) == 2048
+    assert ops.tail_split_cols(8192, 4096, 4096) is None and ops.tail_split_cols(4096, 2560, 4096) is None
+    assert ops.tail_split_cols(8192, 2560, 1024) is None          # K loop too short for 4 splits of >= 8 tiles
+    assert ops.tail_split_cols(2048, 8192 + 2048, 4096) == 8192    # 8 x 40 tiles
+    for (M, N, K) in [(8192, 2560, 2048), (8000, 2560 - 8, 4096), (2048, 10240, 2560)]:
+        a = torch.randn(M, K, generator=g).bfloat16().cuda()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        bias = torch.randn(N, generator=g).bfloat16().cuda()
+        rows = torch.tensor([0, 1, 255, 256, M // 2 + 3, M - 1], device="cuda")
+        for b_ in (None, bias):
+            buf = torch.full((M, N + 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+            out = ops.linear_fwd(a, w, b_, out=buf[:, :N])
+            assert out.data_ptr() == buf.data_ptr() and not torch.isnan(out).any() and torch.isnan(buf[:, N:]).all()
+            ref = f64(a[rows]) @ f64(w).T + (0 if b_ is None else f64(b_))
+            assert nmax(out[rows], ref) < TOL[torch.bfloat16]
+            ops.TAIL_SPLIT = False
+            try:
+                whole = ops.linear_fwd(a, w, b_)
+            finally:
+                ops.TAIL_SPLIT = True
+            main = ops.tail_split_cols(M, N, K)
+            if not ops.splitk_ok(M, N, K):
+                assert torch.equal(out[:, :main], whole[:, :main])
+            assert nmax(out, whole.double()) < 2 * TOL[torch.bfloat16]
+        # NN form: c = s W with W [Kc = contraction, N = output columns]
+        s_ = torch.randn(M, K, generator=g).bfloat16().cuda()
+        wn = (torch.randn(K, N, generator=g) * K ** -0.5).bfloat16().cuda()
+        if N % 8 == 0:
+            c = ops.linear_dgrad(s_, wn)
+            assert nmax(c[rows], f64(s_[rows]) @ f64(wn)) < TOL[torch.bfloat16]
+            ops.TAIL_SPLIT = False
+            try:
+                whole = ops.linear_dgrad(s_, wn)
+            finally:
+                ops.TAIL_SPLIT = True
+            assert nmax(c, whole.double()) < 2 * TOL[torch.bfloat16]
+        del a, w, s_, wn
+    torch.cuda.empty_cache()
+
+
 def test_gemm_skinny_single_split_and_big_n(ops):
     """tile counts that fill the chip alone (one split: the plain kernel writes the output, no slabs) and the many-tile split case"""
     g = torch.Generator().manual_seed(5)
