@@ -1067,16 +1067,16 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-// bf16, d == 128: 32x32x16 MFMA kernels of attention32.hip (no head-transposed operands)
-int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
+// bf16, d in {64, 96, 128}: 32x32x16 MFMA kernels of attention32.hip (no head-transposed operands)
+int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int d, int64_t ldq,
                    int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
                    const int* row_hi, hipStream_t st);
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
-                  int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
+                  int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
                   hipStream_t st);
 int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
-                   void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
+                   void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
                    int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
                    const int* row_lo, const int* row_hi, hipStream_t st);
 int lrp_attn32_fwd_d256(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
@@ -1090,8 +1090,8 @@ int lrp_attn32_dkv_d256(const void* q, const void* k, const void* v, const void*
                         void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
                         int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
                         const int* row_lo, const int* row_hi, hipStream_t st);
-// bf16, d == 128 or 256: the 32x32x16 / transpose-read kernels of attention32.hip (no head-transposed operands)
-static inline bool use_attn32(int dtype, int d) { return dtype == LRP_BF16 && (d == 128 || d == 256); }
+// bf16, d in {64, 96, 128, 256}: the 32x32x16 / transpose-read kernels of attention32.hip (no head-transposed operands)
+static inline bool use_attn32(int dtype, int d) { return dtype == LRP_BF16 && (d == 64 || d == 96 || d == 128 || d == 256); }
 extern "C" int lrp_attn_needs_transposed(int dtype, int d) { return use_attn32(dtype, d) ? 0 : 1; }
 
 #define ATT_DISPATCH_D(T, d, ...)                                   \
@@ -1169,7 +1169,7 @@ extern "C" int lrp_attn_fwd(const void* q, const void* k, const void* v, const v
         if (!v) return LRP_EINVAL;
         if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldv % epc) || (ldo % 4)) return LRP_EALIGN;
         if (d == 256) return lrp_attn32_fwd_d256(q, k, v, o, lse, B, S, Hq, Hkv, ldq, ldk, ldv, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
-        return lrp_attn32_fwd(q, k, v, o, lse, B, S, Hq, Hkv, ldq, ldk, ldv, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
+        return lrp_attn32_fwd(q, k, v, o, lse, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldo, scale, causal, window, q_begin, row_lo, row_hi, st);
     }
     if (!v_t) return LRP_EINVAL;
     if (!al16(q) || !al16(k) || !al16(v_t) || !al16(o) || (ldq % epc) || (ldk % epc) || (ldt % epc) || (ldo % 4) || ldt < S) return LRP_EALIGN;
@@ -1232,7 +1232,7 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
     if (use_attn32(dtype, d) && d == 256)
         return lrp_attn32_dq_d256(q, k, v, Gho, lse, D, dq, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     if (use_attn32(dtype, d))
-        return lrp_attn32_dq(q, k, v, Gho, lse, D, dq, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+        return lrp_attn32_dq(q, k, v, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     if (!k_t) return LRP_EINVAL;
     if (!al16(k_t) || (ldt % epc) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
@@ -1296,7 +1296,7 @@ extern "C" int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, con
     if (use_attn32(dtype, d) && d == 256)
         return lrp_attn32_dkv_d256(q, k, v, Gho, lse, D, dk_h, dv_h, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     if (use_attn32(dtype, d))
-        return lrp_attn32_dkv(q, k, v, Gho, lse, D, dk_h, dv_h, B, S, Hq, Hkv, ldq, ldk, ldv, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+        return lrp_attn32_dkv(q, k, v, Gho, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     if (!q_t || !Gho_t) return LRP_EINVAL;
     if (!al16(q_t) || !al16(Gho_t) || (ldt % epc) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_dkv_t<float>(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddk, lddv, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);

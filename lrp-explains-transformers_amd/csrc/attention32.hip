@@ -32,11 +32,11 @@ constexpr int NW = 8;              // waves per workgroup of the dK/dV kernel (2
 constexpr int NWQ = A32_NWQ;       // waves per workgroup of the forward / dQ kernels: 128 queries, TWO workgroups per CU, so that
                                    // one workgroup's prologue / store tail and barrier waits run under the other's MFMAs
 constexpr int CT = 64;             // column-side rows per tile
-constexpr int D = 128;             // head dim
-constexpr int KP = D * 2;          // bytes per tile row
+constexpr int KP = 256;            // bytes per LDS tile row: the head-dim-128 image for EVERY head dim DH in {64, 96, 128} (16-byte chunks
+                                   // >= DH / 8 of a row are never staged and never read: one swizzle, one set of lane addresses)
 constexpr int TILE = CT * KP;      // 16 KiB
-constexpr int NK = D / 16;         // MFMA k-steps over the head dim
-constexpr int ND32 = D / 32;       // 32-wide head-dim blocks of an out^T accumulator
+constexpr int NKX = 8, NDX = 4;    // array bounds (DH = 128); an instantiation for DH runs NK = DH / 16 MFMA k-steps over the head dim and
+                                   // ND32 = DH / 32 32-wide head-dim blocks per out^T accumulator
 #define LRP_LOG2E 1.4426950408889634f
 
 LRP_DEVICE int rot4(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -58,12 +58,16 @@ inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 
 #ifndef A32_BUFFER_STAGING
 #define A32_BUFFER_STAGING 1
 #endif
-template <int NWV = NW>
+// Head dims below 128: a lane whose source chunk lies past the head (chunk >= DH / 8) gets an offset beyond num_records -- the buffer
+// unit returns zero without a memory request; its LDS slot is never read.
+constexpr int A32_OOB = 0x40000000;
+template <int NWV = NW, int DH = 128>
 LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char* lds, int wave, int lane) {
 #if A32_BUFFER_STAGING
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(S - 1) * ld + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(S - 1) * ld + DH) * 2), 0x00020000);
     const int rl = lane >> 4, slot = lane & 15;
-    const int voff = (int)(rl * ld * 2) + ((slot ^ ((rl << 2) | (wave & 3))) << 4);
+    const int chunk_ = slot ^ ((rl << 2) | (wave & 3));
+    const int voff = (DH == 128 || chunk_ < DH / 8) ? (int)(rl * ld * 2) + (chunk_ << 4) : A32_OOB;
 #pragma unroll
     for (int g = 0; g < 16 / NWV; ++g) {
         const int grp = g * NWV + wave;
@@ -77,7 +81,8 @@ LRP_DEVICE void stage_tile(const bf16_t* base, int64_t ld, int row0, int S, char
         const int chunk = slot ^ rot4(row);
         int gr = row0 + row;
         gr = gr < S ? gr : S - 1;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)gr * ld + chunk * 8), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
+        if (chunk * 8 < DH)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + (int64_t)gr * ld + chunk * 8), (lds_ptr_t)(lds + grp * 1024), 16, 0, 0);
     }
 #endif
 }
@@ -90,14 +95,14 @@ LRP_DEVICE void stage_stats(const float* base, int r0, int S, char* lds, int lan
 
 // per-lane LDS byte offsets (relative to a tile base), hoisted out of the tile loops
 struct LaneAddr {
-    uint32_t rm[NK];          // row fragment: row (lane & 31) of a 32-row block, head-dim chunk 2 ks + hi
-    uint32_t tr[ND32][2];     // transpose read: head-dim block db, half (rows +0..3 / +8..11 of a 16-row group, + 4 hi)
+    uint32_t rm[NKX];         // row fragment: row (lane & 31) of a 32-row block, head-dim chunk 2 ks + hi
+    uint32_t tr[NDX][2];      // transpose read: head-dim block db, half (rows +0..3 / +8..11 of a 16-row group, + 4 hi)
     LRP_DEVICE void init(int lane) {
         const int l31 = lane & 31, hi = lane >> 5, i16 = lane & 15;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) rm[ks] = l31 * KP + (((ks * 2 + hi) ^ rot4(l31)) << 4);
+        for (int ks = 0; ks < NKX; ++ks) rm[ks] = l31 * KP + (((ks * 2 + hi) ^ rot4(l31)) << 4);
 #pragma unroll
-        for (int db = 0; db < ND32; ++db)
+        for (int db = 0; db < NDX; ++db)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int r = half * 8 + 4 * hi + (i16 >> 2);                       // row within its 16-row group
@@ -144,12 +149,26 @@ LRP_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 #define A32_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(off))
 #define A32_WAIT(n, ...) asm volatile("s_waitcnt lgkmcnt(" #n ")" : __VA_ARGS__)
 #define A32_FENCE() __builtin_amdgcn_sched_barrier(0)
-// the 8 transpose reads (4 head-dim blocks x 2 halves) of one 16-row group
-#define A32_TR8(dst, adr, off)                                                                              \
-    A32_RDTR(dst[0][0], adr[0][0], off); A32_RDTR(dst[0][1], adr[0][1], off); A32_RDTR(dst[1][0], adr[1][0], off); \
-    A32_RDTR(dst[1][1], adr[1][1], off); A32_RDTR(dst[2][0], adr[2][0], off); A32_RDTR(dst[2][1], adr[2][1], off); \
-    A32_RDTR(dst[3][0], adr[3][0], off); A32_RDTR(dst[3][1], adr[3][1], off)
-#define A32_TRV(t) "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1])
+// the 2 ND transpose reads (ND head-dim blocks x 2 halves) of one 16-row group, and the counted waits that name them as results
+template <int ND, int OFF> LRP_DEVICE void tr_group(u32x2 (&dst)[NDX][2], const uint32_t (&adr)[NDX][2]) {
+    A32_RDTR(dst[0][0], adr[0][0], OFF); A32_RDTR(dst[0][1], adr[0][1], OFF);
+    A32_RDTR(dst[1][0], adr[1][0], OFF); A32_RDTR(dst[1][1], adr[1][1], OFF);
+    if constexpr (ND > 2) { A32_RDTR(dst[2][0], adr[2][0], OFF); A32_RDTR(dst[2][1], adr[2][1], OFF); }
+    if constexpr (ND > 3) { A32_RDTR(dst[3][0], adr[3][0], OFF); A32_RDTR(dst[3][1], adr[3][1], OFF); }
+}
+#define A32_TRV2(t) "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1])
+#define A32_TRV3(t) A32_TRV2(t), "+v"(t[2][0]), "+v"(t[2][1])
+#define A32_TRV4(t) A32_TRV3(t), "+v"(t[3][0]), "+v"(t[3][1])
+template <int ND, int N> LRP_DEVICE void wait_tr(u32x2 (&t)[NDX][2]) {
+    if constexpr (ND == 4) asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV4(t) : [n] "n"(N));
+    else if constexpr (ND == 3) asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV3(t) : [n] "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV2(t) : [n] "n"(N));
+}
+template <int ND, int N> LRP_DEVICE void wait_tr2(u32x2 (&t)[NDX][2], u32x2 (&u)[NDX][2]) {
+    if constexpr (ND == 4) asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV4(t), A32_TRV4(u) : [n] "n"(N));
+    else if constexpr (ND == 3) asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV3(t), A32_TRV3(u) : [n] "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%[n])" : A32_TRV2(t), A32_TRV2(u) : [n] "n"(N));
+}
 // Measured and NOT adopted (profiles/r02_attention_experiments.txt): s_setprio schemes that favour one of the two waves of a
 // SIMD (static, or high priority in the MFMA phases only) change nothing -- tools/attn_timeline.py shows the MFMA phases of a
 // wave already running at close to their single-wave time, i.e. the two waves of a SIMD are complementary; what is left is the
@@ -207,10 +226,11 @@ LRP_DEVICE bf16x8 join_tr(u32x2 a, u32x2 b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int DH>
 LRP_DEVICE void load_row_frags(bf16x8* f, const bf16_t* base, int64_t ld, int row, int S, int hi) {
     const bool ok = row < S;
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
+    for (int ks = 0; ks < DH / 16; ++ks) {
         if (ok) f[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)row * ld + ks * 16 + hi * 8);
         else {
             u32x4 z = {0, 0, 0, 0};
@@ -219,10 +239,11 @@ LRP_DEVICE void load_row_frags(bf16x8* f, const bf16_t* base, int64_t ld, int ro
     }
 }
 // out^T accumulators -> token-major rows: lane (row, hi) holds head-dim columns db*32 + 8 i + 4 hi + 0..3
+template <int DH>
 LRP_DEVICE void store_rows(bf16_t* base, int64_t ld, int row, int S, const f32x16* acc, float mul, int hi) {
     if (row >= S) return;
 #pragma unroll
-    for (int db = 0; db < ND32; ++db)
+    for (int db = 0; db < DH / 32; ++db)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x4 v;
@@ -248,11 +269,12 @@ LRP_DEVICE float lrp_ds(float s_raw, float p, float dp, float Dq, float scale, f
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
+template <int DH>
 __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
     float* __restrict__ lse, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
     int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
-    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE;
+    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE, NK = DH / 16, ND32 = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,11 +285,11 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
     const int qblk = nqb - 1 - item / rep;                       // heavy (late) causal blocks first
     const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
     if (q0 + BQ <= q_begin) return;
-    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D;
-    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * DH;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * DH;
 
     bf16x8 qf[NK];
-    load_row_frags(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, hi);
+    load_row_frags<DH>(qf, q + (int64_t)b * S * ldq + (int64_t)h * DH, ldq, qi, S, hi);
     int ivlo = 0, ivhi = S;
     if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
     f32x16 oacc[ND32];
@@ -282,13 +304,13 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
-        stage_tile<NWQ>(kb_, ldk, kt0, S, sb, wave, lane);
-        stage_tile<NWQ>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+        stage_tile<NWQ, DH>(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile<NWQ, DH>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
     };
     if (kbeg < kend) stage(kbeg, 0);
     __syncthreads();
     // absolute LDS addresses of the current tile's fragments (K tile; V tile = + TILE; 32-row block kb = + kb * 8192)
-    uint32_t arm[NK], atr[ND32][2];
+    uint32_t arm[NK], atr[NDX][2];
     {
         const uint32_t sbase = lds_addr(smem);
         LaneAddr la;
@@ -324,9 +346,9 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
                 A32_FENCE();
             });
             // ---- V^T fragments of the first key block: in flight under the softmax
-            u32x2 tv0[2][ND32][2], tv1[2][ND32][2];
-            A32_TR8(tv0[0], atr, TILE);
-            A32_TR8(tv0[1], atr, TILE + 16 * KP);
+            u32x2 tv0[2][NDX][2], tv1[2][NDX][2];
+            tr_group<ND32, TILE>(tv0[0], atr);
+            tr_group<ND32, TILE + 16 * KP>(tv0[1], atr);
             A32_FENCE();
             const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
             if (need_mask) {
@@ -342,7 +364,12 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
             mx = half_max(mx);
-            const float m_new = fmaxf(m_run, mx);
+            // LAZY running maximum (as the d = 256 forward): the reference point m_run moves only when some row's maximum grew by more than
+            // 2^8 in the exponent's units -- with 32 rows per wave "some row's maximum moved" is true on most tiles, and every move costs a
+            // rescale of the DH / 2 accumulator registers.  Between moves p = exp2((s - m_run) c1) <= 256 (exact in fp32, the same relative
+            // rounding in bf16); l_run uses the same reference, so o = acc / l and lse = m_run scale + log l are unchanged up to rounding.
+            float m_new = m_run;
+            if (__any((mx - m_run) * c1 > 8.f || (m_run == -INFINITY && mx != -INFINITY))) m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float nm2 = -m_use * c1;
             float rs = 0.f;
@@ -355,7 +382,6 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
                     rs += p;
                 }
             rs = half_sum(rs);
-            // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
             if (__any(m_new != m_run)) {
                 const float alpha = fast_exp2((m_run - m_use) * c1);
                 l_run = l_run * alpha + rs;
@@ -366,20 +392,20 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
             const bf16x8 p00 = pack8(st[0], 0), p01 = pack8(st[0], 1), p10 = pack8(st[1], 0), p11 = pack8(st[1], 1);
             A32_FENCE();
             // (lgkmcnt is a 4-bit counter on gfx9: never count on more than 15 outstanding reads)
-            A32_TR8(tv1[0], atr, TILE + 32 * KP);
-            A32_WAIT(8, A32_TRV(tv0[0]), A32_TRV(tv0[1]));
+            tr_group<ND32, TILE + 32 * KP>(tv1[0], atr);
+            wait_tr2<ND32, 2 * ND32>(tv0[0], tv0[1]);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv0[0][db][0], tv0[0][db][1]), p00, oacc[db]);
             A32_FENCE();
-            A32_TR8(tv1[1], atr, TILE + 48 * KP);
+            tr_group<ND32, TILE + 48 * KP>(tv1[1], atr);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv0[1][db][0], tv0[1][db][1]), p01, oacc[db]);
             A32_FENCE();
-            A32_WAIT(8, A32_TRV(tv1[0]));
+            wait_tr<ND32, 2 * ND32>(tv1[0]);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv1[0][db][0], tv1[0][db][1]), p10, oacc[db]);
             A32_FENCE();
-            A32_WAIT(0, A32_TRV(tv1[1]));
+            wait_tr<ND32, 0>(tv1[1]);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) oacc[db] = mfma32(join_tr(tv1[1][db][0], tv1[1][db][1]), p11, oacc[db]);
             A32_FENCE();
@@ -396,20 +422,20 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
         cur ^= 1;
     }
     const float inv = (l_run > 0.f) ? 1.f / l_run : 0.f;
-    store_rows(o + (int64_t)b * S * ldo + (int64_t)h * D, ldo, qi, S, oacc, inv, hi);
+    store_rows<DH>(o + (int64_t)b * S * ldo + (int64_t)h * DH, ldo, qi, S, oacc, inv, hi);
     if (hi == 0 && qi < S) lse[((int64_t)b * Hq + h) * S + qi] = m_run * scale + __logf(l_run);
 }
 
 // =====================================================================================================================
 // dQ: row side = 32 queries per wave; K and V tiles stream
 // =====================================================================================================================
-template <bool EXPL>
+template <bool EXPL, int DH>
 __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
     int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
     int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
-    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE;
+    constexpr int BQ = NWQ * 32, STAGE = 2 * TILE, NK = DH / 16, ND32 = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -420,12 +446,12 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     const int qblk = nqb - 1 - item / rep;
     const int q0 = qblk * BQ, qw = q0 + wave * 32, qi = qw + l31;
     if (q0 + BQ <= q_begin) return;
-    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * D;
-    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+    const bf16_t* kb_ = k + (int64_t)b * S * ldk + (int64_t)hk * DH;
+    const bf16_t* vb_ = v + (int64_t)b * S * ldv + (int64_t)hk * DH;
 
     bf16x8 qf[NK], gf[NK];
-    load_row_frags(qf, q + (int64_t)b * S * ldq + (int64_t)h * D, ldq, qi, S, hi);
-    load_row_frags(gf, gho + (int64_t)b * S * ldg + (int64_t)h * D, ldg, qi, S, hi);
+    load_row_frags<DH>(qf, q + (int64_t)b * S * ldq + (int64_t)h * DH, ldq, qi, S, hi);
+    load_row_frags<DH>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * DH, ldg, qi, S, hi);
     const float lse2 = ((qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f) * LRP_LOG2E;
     const float Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
     int ivlo = 0, ivhi = S;
@@ -441,14 +467,14 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
-        stage_tile<NWQ>(kb_, ldk, kt0, S, sb, wave, lane);
-        stage_tile<NWQ>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
+        stage_tile<NWQ, DH>(kb_, ldk, kt0, S, sb, wave, lane);
+        stage_tile<NWQ, DH>(vb_, ldv, kt0, S, sb + TILE, wave, lane);
     };
     if (kbeg < kend) stage(kbeg, 0);
     __syncthreads();
     // absolute LDS addresses of the current tile's fragments (K tile; V tile = + TILE; 32-row block kb = + kb * 8192), moved
     // from stage to stage with the loop
-    uint32_t arm[NK], atr[ND32][2];
+    uint32_t arm[NK], atr[NDX][2];
     {
         const uint32_t sbase = lds_addr(smem);
         LaneAddr la;
@@ -491,9 +517,9 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
             });
             A32_TS(1);                                                   // 1: S / dP phase
             // ---- K^T fragments of the dQ contraction: issued before the element-wise work that hides their latency
-            u32x2 tk[2][ND32][2];
-            A32_TR8(tk[0], atr, KO);
-            A32_TR8(tk[1], atr, KO + 16 * KP);
+            u32x2 tk[2][NDX][2];
+            tr_group<ND32, KO>(tk[0], atr);
+            tr_group<ND32, KO + 16 * KP>(tk[1], atr);
             A32_FENCE();
             const bool masked = (kk0 + 32 > S) || (causal && kk0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
             if (masked) {
@@ -515,11 +541,11 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
             const bf16x8 df0 = pack8(st, 0), df1 = pack8(st, 1);
             A32_FENCE();
             A32_TS(2);                                                   // 2: element-wise
-            A32_WAIT(8, A32_TRV(tk[0]));
+            wait_tr<ND32, 2 * ND32>(tk[0]);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) acc[db] = mfma32(join_tr(tk[0][db][0], tk[0][db][1]), df0, acc[db]);
             A32_FENCE();
-            A32_WAIT(0, A32_TRV(tk[1]));
+            wait_tr<ND32, 0>(tk[1]);
 #pragma unroll
             for (int db = 0; db < ND32; ++db) acc[db] = mfma32(join_tr(tk[1][db][0], tk[1][db][1]), df1, acc[db]);
             A32_FENCE();
@@ -538,10 +564,10 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
         }
         cur ^= 1;
     }
-    store_rows(dq + (int64_t)b * S * lddq + (int64_t)h * D, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+    store_rows<DH>(dq + (int64_t)b * S * lddq + (int64_t)h * DH, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
 #ifdef A32_TIMELINE
     if (lane == 0 && qw < S) {
-        uint32_t* w = reinterpret_cast<uint32_t*>(dq + ((int64_t)b * S + qw) * lddq + (int64_t)h * D);
+        uint32_t* w = reinterpret_cast<uint32_t*>(dq + ((int64_t)b * S + qw) * lddq + (int64_t)h * DH);
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = tl_acc[i];
         w[6] = (uint32_t)__builtin_readcyclecounter() - tl_start;
@@ -553,13 +579,13 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
 // =====================================================================================================================
 // dK / dV per query head: row side = 32 keys per wave; Q and Gho tiles (+ lse, D) stream
 // =====================================================================================================================
-template <bool EXPL>
+template <bool EXPL, int DH>
 __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int Hq,
     int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk, int64_t lddv, float scale, float eps_mask,
     float eps_qk, int causal, int window, int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
-    constexpr int BK = NW * 32, STAGE = 2 * TILE + 512, VROWS = 32 * KP;
+    constexpr int BK = NW * 32, STAGE = 2 * TILE + 512, VROWS = 32 * KP, NK = DH / 16, ND32 = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -567,8 +593,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
     const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
     const int k0 = kblk * BK, kw = k0 + wave * 32, ki = kw + l31;
-    const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * D;
-    const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * D;
+    const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * DH;
+    const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * DH;
     const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
     const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
     const int* rlo_b = row_lo ? row_lo + (int64_t)b * S : nullptr;
@@ -577,16 +603,17 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     // K fragments of the wave's 32 keys live in registers; the V fragments (32 more registers: with two 128-register
     // accumulators the kernel would spill) live in a per-wave [32 rows][256 B] LDS block in the tile layout
     bf16x8 kf[NK];
-    load_row_frags(kf, k + (int64_t)b * S * ldk + (int64_t)hk * D, ldk, ki, S, hi);
+    load_row_frags<DH>(kf, k + (int64_t)b * S * ldk + (int64_t)hk * DH, ldk, ki, S, hi);
     char* sVw = smem + 2 * STAGE + wave * VROWS;
     {
-        const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hk * D;
+        const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hk * DH;
 #if A32_BUFFER_STAGING
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)(S - 1) * ldv + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)(S - 1) * ldv + DH) * 2), 0x00020000);
         const int rl = lane >> 4, slot = lane & 15;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const int voff = (int)(rl * ldv * 2) + ((slot ^ ((rl << 2) | (g & 3))) << 4);
+            const int chunk_ = slot ^ ((rl << 2) | (g & 3));
+            const int voff = (DH == 128 || chunk_ < DH / 8) ? (int)(rl * ldv * 2) + (chunk_ << 4) : A32_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sVw + g * 1024), 16, voff, (int)((int64_t)(kw + g * 4) * ldv * 2), 0, 0);
         }
 #else
@@ -595,7 +622,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             const int row = g * 4 + (lane >> 4), slot = lane & 15;
             int gr = kw + row;
             gr = gr < S ? gr : S - 1;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (int64_t)gr * ldv + ((slot ^ rot4(row)) * 8)), (lds_ptr_t)(sVw + g * 1024), 16, 0, 0);
+            if ((slot ^ rot4(row)) * 8 < DH)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(vbase + (int64_t)gr * ldv + ((slot ^ rot4(row)) * 8)), (lds_ptr_t)(sVw + g * 1024), 16, 0, 0);
         }
 #endif
     }
@@ -610,8 +638,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
 
     auto stage = [&](int qt0, int buf) {
         char* sb = smem + buf * STAGE;
-        stage_tile(qb_, ldq, qt0, S, sb, wave, lane);
-        stage_tile(gb_, ldg, qt0, S, sb + TILE, wave, lane);
+        stage_tile<NW, DH>(qb_, ldq, qt0, S, sb, wave, lane);
+        stage_tile<NW, DH>(gb_, ldg, qt0, S, sb + TILE, wave, lane);
         if (wave == 0) stage_stats(lse_b, qt0, S, sb + 2 * TILE, lane);
         if (wave == 1) stage_stats(D_b, qt0, S, sb + 2 * TILE + 256, lane);
     };
@@ -681,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
 #define A32_TIE(sl_) "+v"(tg[sl_][0]), "+v"(tg[sl_][1]), "+v"(tq[sl_][0]), "+v"(tq[sl_][1])
 #define A32_DKV_STEP(g, wait_stmt)                                                                     \
     {                                                                                                  \
-        constexpr int j_ = (g) >> 2, db_ = (g)&3, sl_ = (g)&1;                                         \
+        constexpr int j_ = (g) / ND32, db_ = (g) % ND32, sl_ = (g)&1;                                  \
         wait_stmt;                                                                                     \
         dvacc[db_] = mfma32(join_tr(tg[sl_][0], tg[sl_][1]), pf[j_], dvacc[db_]);                      \
         dkacc[db_] = mfma32(join_tr(tq[sl_][0], tq[sl_][1]), df[j_], dkacc[db_]);                      \
@@ -702,6 +730,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 } else if constexpr (i == 2) {
                     A32_RD128(sl[nx], ast, SO + 96); A32_RD128(sd[nx], ast, SO + 96 + 256);
                     A32_WAIT(6, "+v"(sl[cu]), "+v"(sd[cu]));
+                } else if constexpr (ND32 == 3) {
+                    A32_WAIT(0, "+v"(sl[cu]), "+v"(sd[cu]), A32_TIE(1));        // group (1, 0) is g = ND32: slot g & 1
                 } else {
                     A32_WAIT(0, "+v"(sl[cu]), "+v"(sd[cu]), A32_TIE(0));
                 }
@@ -721,27 +751,54 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 }
                 A32_FENCE();
             };
+            // group g = (j, db) = (g / ND32, g % ND32) uses register slot g & 1; its reads are issued one group ahead
             A32_TRG(0, 0, 0);                                           // g = 0
             A32_FENCE();
             elementwise(IC<0>{});
             elementwise(IC<1>{});
-            A32_TRG(1, 0, 1);
-            A32_DKV_STEP(0, (void)0);
-            A32_TRG(0, 0, 2);
-            A32_DKV_STEP(1, A32_WAIT(4, A32_TIE(1)));
-            A32_TRG(1, 0, 3);
-            A32_DKV_STEP(2, A32_WAIT(4, A32_TIE(0)));
-            A32_TRG(0, 1, 0);                                           // g = 4: in flight under B(1)
-            A32_DKV_STEP(3, A32_WAIT(4, A32_TIE(1)));
-            elementwise(IC<2>{});
-            elementwise(IC<3>{});
-            A32_TRG(1, 1, 1);
-            A32_DKV_STEP(4, (void)0);
-            A32_TRG(0, 1, 2);
-            A32_DKV_STEP(5, A32_WAIT(4, A32_TIE(1)));
-            A32_TRG(1, 1, 3);
-            A32_DKV_STEP(6, A32_WAIT(4, A32_TIE(0)));
-            A32_DKV_STEP(7, A32_WAIT(0, A32_TIE(1)));
+            if constexpr (ND32 == 4) {
+                A32_TRG(1, 0, 1);
+                A32_DKV_STEP(0, (void)0);
+                A32_TRG(0, 0, 2);
+                A32_DKV_STEP(1, A32_WAIT(4, A32_TIE(1)));
+                A32_TRG(1, 0, 3);
+                A32_DKV_STEP(2, A32_WAIT(4, A32_TIE(0)));
+                A32_TRG(0, 1, 0);                                       // g = 4: in flight under B(1)
+                A32_DKV_STEP(3, A32_WAIT(4, A32_TIE(1)));
+                elementwise(IC<2>{});
+                elementwise(IC<3>{});
+                A32_TRG(1, 1, 1);
+                A32_DKV_STEP(4, (void)0);
+                A32_TRG(0, 1, 2);
+                A32_DKV_STEP(5, A32_WAIT(4, A32_TIE(1)));
+                A32_TRG(1, 1, 3);
+                A32_DKV_STEP(6, A32_WAIT(4, A32_TIE(0)));
+                A32_DKV_STEP(7, A32_WAIT(0, A32_TIE(1)));
+            } else if constexpr (ND32 == 3) {
+                A32_TRG(1, 0, 1);
+                A32_DKV_STEP(0, (void)0);
+                A32_TRG(0, 0, 2);
+                A32_DKV_STEP(1, A32_WAIT(4, A32_TIE(1)));
+                A32_TRG(1, 1, 0);                                       // g = 3: in flight under B(1)
+                A32_DKV_STEP(2, A32_WAIT(4, A32_TIE(0)));
+                elementwise(IC<2>{});
+                elementwise(IC<3>{});
+                A32_TRG(0, 1, 1);
+                A32_DKV_STEP(3, (void)0);
+                A32_TRG(1, 1, 2);
+                A32_DKV_STEP(4, A32_WAIT(4, A32_TIE(0)));
+                A32_DKV_STEP(5, A32_WAIT(0, A32_TIE(1)));
+            } else {
+                A32_TRG(1, 0, 1);
+                A32_DKV_STEP(0, (void)0);
+                A32_TRG(0, 1, 0);                                       // g = 2: in flight under B(1)
+                A32_DKV_STEP(1, A32_WAIT(4, A32_TIE(1)));
+                elementwise(IC<2>{});
+                elementwise(IC<3>{});
+                A32_TRG(1, 1, 1);
+                A32_DKV_STEP(2, (void)0);
+                A32_DKV_STEP(3, A32_WAIT(0, A32_TIE(1)));
+            }
 #undef A32_DKV_STEP
 #undef A32_TIE
 #undef A32_TRG
@@ -757,8 +814,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
         }
         cur ^= 1;
     }
-    store_rows(dk + (int64_t)b * S * lddk + (int64_t)h * D, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, hi);
-    store_rows(dv + (int64_t)b * S * lddv + (int64_t)h * D, lddv, ki, S, dvacc, 1.f, hi);
+    store_rows<DH>(dk + (int64_t)b * S * lddk + (int64_t)h * DH, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, hi);
+    store_rows<DH>(dv + (int64_t)b * S * lddv + (int64_t)h * DH, lddv, ki, S, dvacc, 1.f, hi);
 }
 
 
@@ -1371,62 +1428,68 @@ int lrp_attn32_dkv_d256(const void* q, const void* k, const void* v, const void*
     return lrp_check_launch();
 }
 
-// ---- entry points used by the dispatchers of attention.hip (bf16, d == 128) ------------------------------------------
-int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int64_t ldq,
+// ---- entry points used by the dispatchers of attention.hip (bf16, d in {64, 96, 128}) ----------------------------------
+#define A32_FOR_DH(d, ...)                                     \
+    switch (d) {                                               \
+        case 64: { constexpr int DH = 64; __VA_ARGS__ } break; \
+        case 96: { constexpr int DH = 96; __VA_ARGS__ } break; \
+        case 128: { constexpr int DH = 128; __VA_ARGS__ } break; \
+        default: return LRP_ESHAPE;                            \
+    }
+
+int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int Hq, int Hkv, int d, int64_t ldq,
                    int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, int window, int q_begin, const int* row_lo,
                    const int* row_hi, hipStream_t st) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE);
-    auto kern = fwd_kernel;
-    set_lds(kern, lds);
     dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
-    hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
-                       Hkv, ldq, ldk, ldv, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
+    A32_FOR_DH(d, {
+        auto kern = fwd_kernel<DH>;
+        LRP_SET_MAX_LDS(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, Hq,
+                           Hkv, ldq, ldk, ldv, ldo, scale, causal, window, B, q_begin, row_lo, row_hi);
+    })
     return lrp_check_launch();
 }
 
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
-                  int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
+                  int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
                   hipStream_t st) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE);
     dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
-    if (eps_mask != 0.f || eps_qk != 0.f) {
-        auto kern = dq_kernel<true>;
-        set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
-                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
-                           q_begin, row_lo, row_hi);
-    } else {
-        auto kern = dq_kernel<false>;
-        set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
-                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,
-                           q_begin, row_lo, row_hi);
+    const bool expl = eps_mask != 0.f || eps_qk != 0.f;
+#define A32_LAUNCH_DQ(EX)                                                                                                                  \
+    {                                                                                                                                       \
+        auto kern = dq_kernel<EX, DH>;                                                                                                      \
+        LRP_SET_MAX_LDS(kern, lds);                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho, \
+                           lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,         \
+                           q_begin, row_lo, row_hi);                                                                                       \
     }
+    A32_FOR_DH(d, { if (expl) A32_LAUNCH_DQ(true) else A32_LAUNCH_DQ(false) })
+#undef A32_LAUNCH_DQ
     return lrp_check_launch();
 }
 
 int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
-                   void* dv, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
+                   void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
                    int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
                    const int* row_lo, const int* row_hi, hipStream_t st) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE + 512) + (size_t)NW * 32 * KP;
     dim3 grid(xcd_group_grid(B * Hq, (S + 255) / 256));
-    if (eps_mask != 0.f || eps_qk != 0.f) {
-        auto kern = dkv_kernel<true>;
-        set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
-                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
-                           causal, window, B, q_begin, row_lo, row_hi);
-    } else {
-        auto kern = dkv_kernel<false>;
-        set_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
-                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
-                           causal, window, B, q_begin, row_lo, row_hi);
+    const bool expl = eps_mask != 0.f || eps_qk != 0.f;
+#define A32_LAUNCH_DKV(EX)                                                                                                             \
+    {                                                                                                                                   \
+        auto kern = dkv_kernel<EX, DH>;                                                                                                 \
+        LRP_SET_MAX_LDS(kern, lds);                                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,   \
+                           lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,     \
+                           causal, window, B, q_begin, row_lo, row_hi);                                                                \
     }
+    A32_FOR_DH(d, { if (expl) A32_LAUNCH_DKV(true) else A32_LAUNCH_DKV(false) })
+#undef A32_LAUNCH_DKV
     return lrp_check_launch();
 }

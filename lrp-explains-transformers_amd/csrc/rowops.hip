@@ -328,29 +328,34 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* logits, 
 template <typename T, int W>
 __global__ void attn_bwd_prep_kernel(const T* Go, const T* o, T* Gho, float* D, int B, int S, int Hq, int d,
                                      int64_t ldgo, int64_t ldo, int64_t ldgho, float eps_pv, float factor) {
-    const int lpg = d / W;                                   // lanes per (row, head) group: power of two <= 64
+    const int lpw = d / W;                                   // working lanes per (row, head) group
+    int lpg = 1;                                             // lanes per group: the next power of two <= 64 (d = 96: 12 of 16 lanes work)
+    while (lpg < lpw) lpg <<= 1;
     const int gpb = blockDim.x / lpg;
     const int64_t ngroups = (int64_t)B * S * Hq;
     const int lg = threadIdx.x % lpg;
+    const bool on = lg < lpw;
     // all lanes of a group share gidx, so a whole group leaves the loop together and the
     // xor-shuffles (offsets < lpg) never cross into a retired group
     for (int64_t gidx = (int64_t)blockIdx.x * gpb + threadIdx.x / lpg; gidx < ngroups; gidx += (int64_t)gridDim.x * gpb) {
         const int h = (int)(gidx % Hq);
         const int64_t row = gidx / Hq;
         RChunk<T, W> g, oo, r;
-        g.load(Go + row * ldgo + (int64_t)h * d + lg * W);
-        oo.load(o + row * ldo + (int64_t)h * d + lg * W);
         float s = 0.f;
+        if (on) {
+            g.load(Go + row * ldgo + (int64_t)h * d + lg * W);
+            oo.load(o + row * ldo + (int64_t)h * d + lg * W);
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            // D is taken from the ROUNDED Gho so that sum_j P_ij dP_ij == D_i holds for what the
-            // backward kernels actually multiply with
-            const float t = to_f32(from_f32<T>(factor * g.v[k] * eps_ratio(oo.v[k], 1.f, eps_pv)));
-            r.v[k] = t;
-            s += t * oo.v[k];
+            for (int k = 0; k < W; ++k) {
+                // D is taken from the ROUNDED Gho so that sum_j P_ij dP_ij == D_i holds for what the
+                // backward kernels actually multiply with
+                const float t = to_f32(from_f32<T>(factor * g.v[k] * eps_ratio(oo.v[k], 1.f, eps_pv)));
+                r.v[k] = t;
+                s += t * oo.v[k];
+            }
         }
         for (int off = lpg >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        r.store(Gho + row * ldgho + (int64_t)h * d + lg * W);
+        if (on) r.store(Gho + row * ldgho + (int64_t)h * d + lg * W);
         if (lg == 0) {
             const int64_t b = row / S, sidx = row % S;
             D[(b * Hq + h) * S + sidx] = s;
@@ -549,8 +554,10 @@ extern "C" int lrp_attn_bwd_prep(const void* Go, const void* o, void* Gho, float
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, {
         constexpr int EPC = 16 / sizeof(T);
-        const int lpg = d / EPC;
-        if (d % EPC || lpg < 1 || lpg > 64 || (lpg & (lpg - 1))) return LRP_ESHAPE;
+        const int lpw = d / EPC;
+        if (d % EPC || lpw < 1 || lpw > 64) return LRP_ESHAPE;
+        int lpg = 1;                                         // lane group = the next power of two (d = 96 in bf16: 12 working lanes of 16)
+        while (lpg < lpw) lpg <<= 1;
         if (!al16(Go) || !al16(o) || !al16(Gho) || (ldgo % EPC) || (ldo % EPC) || (ldgho % EPC)) return LRP_EALIGN;
         const int gpb = 256 / lpg;
         const int64_t ngroups = (int64_t)B * S * Hq;

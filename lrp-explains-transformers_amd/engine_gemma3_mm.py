@@ -15,7 +15,7 @@ fixture tests/golden/gemma3_mm.npz, both attention implementations):
     lxt/efficient/patches.py:193-203), with "eager" it does not -- `vision_attn_rule` selects which (default True = sdpa).
   * patch embedding: Conv2d with stride = kernel as ONE GEMM over the unfolded patches; pixel relevance = pixel (*) d logit / d pixel,
     patch relevance = its sum over a patch.
-MI355X notes: head_dim 72 is zero-padded to 128 and the MLP width 4304 to 4352 inside the fused weights (exact: padded rows / columns
+MI355X notes: head_dim 72 is zero-padded to 96 (bf16; fp32 parity runs: 128) and the MLP width 4304 to 4352 inside the fused weights (exact: padded rows / columns
 are zero), so every contraction runs on the 256 x 256 MFMA GEMM and the 32 x 32 attention kernels; the average pool is a GEMM with a
 constant [tokens, patches] matrix (power-of-two pooling windows: 1 / k^2 exact in bf16)."""
 import torch
@@ -83,7 +83,8 @@ class SiglipLRP:
         self.cfg, self.dtype, self.device, self.attn_rule = dict(cfg), dtype, torch.device(device), bool(vision_attn_rule)
         H, I, nh = cfg["hidden"], cfg["inter"], cfg["n_heads"]
         d0 = H // nh
-        dp = next(c for c in (32, 64, 128, 256) if c >= d0)            # head dim the attention kernels are built for (SigLIP: 72 -> 128)
+        # head dim the attention kernels are built for (SigLIP: 72 -> 96 in bf16: the 32 x 32 kernels exist for 64 / 96 / 128 / 256; fp32: -> 128)
+        dp = next(c for c in ((32, 64, 96, 128, 256) if dtype == torch.bfloat16 else (32, 64, 128, 256)) if c >= d0)
         Ip = (I + 63) // 64 * 64                                        # MLP width on the 64-element K tiles of the MFMA GEMM (4304 -> 4352)
         self.d0, self.dp, self.Ip = d0, dp, Ip
         g = cfg["image"] // cfg["patch"]

@@ -604,18 +604,22 @@ def _tm(x):      # [B,H,S,d] -> token-major [B*S, H*d]
 @pytest.mark.parametrize("B,S,Hq,Hkv,d,causal,window", [
     (1, 16, 4, 2, 16, True, 0), (2, 100, 4, 2, 32, True, 0), (1, 192, 4, 1, 128, True, 0),
     (1, 130, 2, 2, 64, False, 0), (1, 200, 2, 1, 64, True, 48), (1, 300, 8, 2, 128, True, 0),
-    (1, 150, 2, 1, 256, True, 0), (1, 150, 2, 1, 256, True, 64),
+    (1, 150, 2, 1, 256, True, 0), (1, 150, 2, 1, 256, True, 64), (1, 300, 6, 2, 96, True, 0), (2, 260, 3, 3, 96, False, 0), (1, 400, 2, 1, 96, True, 90),
+    (2, 520, 8, 2, 64, True, 0), (1, 333, 4, 4, 64, False, 0),
     (1, 500, 4, 2, 128, True, 100), (1, 260, 4, 2, 128, False, 0), (2, 700, 8, 2, 128, True, 0), (1, 257, 4, 4, 128, True, 0)])
 @pytest.mark.parametrize("mode", ["efficient", "explicit"])
 def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     if dtype == torch.bfloat16 and d < 32:
         pytest.skip("bf16 needs head_dim >= 32 (one 64-byte MFMA K chunk)")
+    if dtype == torch.float32 and d == 96:
+        pytest.skip("head_dim 96 exists on the bf16 32 x 32 kernels only (SigLIP's 72 padded)")
     tol = 3e-5 if dtype == torch.float32 else 3e-2
     q, k, v = rnd(B, Hq, S, d, dtype=dtype, seed=1), rnd(B, Hkv, S, d, dtype=dtype, seed=2), rnd(B, Hkv, S, d, dtype=dtype, seed=3)
     scale = d ** -0.5
     qt, kt, vt = _tm(q), _tm(k), _tm(v)
     v_t = ops.transpose_heads(vt, B, S, Hkv, d)
     assert torch.equal(v_t[..., :S], v.transpose(-1, -2))
+    assert ops.attn_needs_transposed(qt, d) == (not (dtype == torch.bfloat16 and d in (64, 96, 128, 256)))
     o = torch.empty(B * S, Hq * d, dtype=dtype, device="cuda")
     lse = torch.empty(B, Hq, S, device="cuda")
     ops.attn_fwd(qt, kt, vt, v_t, o, lse, B, S, Hq, Hkv, d, scale, causal, window)
@@ -688,13 +692,15 @@ def _intervals(kind, B, S):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["left_pad", "right_pad", "packed", "image_block"])
-@pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40),
+@pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40), (2, 210, 2, 1, 96, 0),
                                                  (2, 330, 4, 2, 128, 0), (2, 300, 2, 1, 128, 70)])
 def test_attention_row_intervals(ops, dtype, kind, B, S, Hq, Hkv, d, window):
     """per-row key intervals (padding / packed sequences / bidirectional blocks) against an fp64 eager attention with
     the same boolean mask; rows with an empty interval must come out as exact zeros and stay NaN-free"""
     if kind == "image_block" and window:
         pytest.skip("bidirectional blocks are used with global layers")
+    if dtype == torch.float32 and d == 96:
+        pytest.skip("head_dim 96 exists on the bf16 32 x 32 kernels only")
     tol = 3e-5 if dtype == torch.float32 else 3e-2
     lo, hi, causal = _intervals(kind, B, S)
     row_iv = (lo.cuda().contiguous(), hi.cuda().contiguous())

@@ -23,7 +23,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) * 1e-3 / n
 
 
-def bench(B, S, Hq, Hkv, d, window, mode):
+def bench(B, S, Hq, Hkv, d, window, mode, causal=True):
     g = torch.Generator(device="cuda").manual_seed(1)
     rn = lambda *s: torch.randn(*s, generator=g, device="cuda").bfloat16()   # noqa: E731
     q, k, v, Go = rn(B * S, Hq * d), rn(B * S, Hkv * d), rn(B * S, Hkv * d), rn(B * S, Hq * d)
@@ -32,23 +32,23 @@ def bench(B, S, Hq, Hkv, d, window, mode):
     o, lse = torch.empty_like(q), torch.empty(B, Hq, S, device="cuda")
     sc = d ** -0.5
     e = 1e-8 if mode == "explicit" else 0.0
-    vis = (S * (S + 1) / 2) if window <= 0 else sum(min(i + 1, window) for i in range(S))
+    vis = float(S) * S if not causal else ((S * (S + 1) / 2) if window <= 0 else sum(min(i + 1, window) for i in range(S)))
     unit = 2.0 * vis * d * Hq * B                        # one contraction over the visible scores
-    tf = timeit(lambda: ops.attn_fwd(q, k, v, v_t, o, lse, B, S, Hq, Hkv, d, sc, True, window))
+    tf = timeit(lambda: ops.attn_fwd(q, k, v, v_t, o, lse, B, S, Hq, Hkv, d, sc, causal, window))
     Gho, D = torch.empty_like(q), torch.empty(B, Hq, S, device="cuda")
     ops.attn_bwd_prep(Go, o, Gho, D, B, S, Hq, d, 1e-6 if e else 0.0, 0.5)
     k_t = ops.transpose_heads(k, B, S, Hkv, d) if need_t else None
     q_t = ops.transpose_heads(q, B, S, Hq, d) if need_t else None
     Gho_t = ops.transpose_heads(Gho, B, S, Hq, d) if need_t else None
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-    tq = timeit(lambda: ops.attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, sc, e, e, True, window))
-    tk = timeit(lambda: ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk, dv, B, S, Hq, Hkv, d, sc, e, e, True, window))
+    tq = timeit(lambda: ops.attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, sc, e, e, causal, window))
+    tk = timeit(lambda: ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk, dv, B, S, Hq, Hkv, d, sc, e, e, causal, window))
     tt = 0.0
     if need_t:
         tt = timeit(lambda: (ops.transpose_heads(v, B, S, Hkv, d), ops.transpose_heads(k, B, S, Hkv, d), ops.transpose_heads(q, B, S, Hq, d),
                              ops.transpose_heads(Gho, B, S, Hq, d)))
     tot = tf + tq + tk + tt
-    print(f"B={B} S={S} {Hq}/{Hkv} heads d={d} window={window} {mode}: fwd {tf * 1e6:7.1f} us ({2 * unit / tf / 1e12:6.1f} TF/s) | dQ {tq * 1e6:7.1f} us "
+    print(f"B={B} S={S} {Hq}/{Hkv} heads d={d} window={window} {'causal' if causal else 'full'} {mode}: fwd {tf * 1e6:7.1f} us ({2 * unit / tf / 1e12:6.1f} TF/s) | dQ {tq * 1e6:7.1f} us "
           f"({2 * unit / tq / 1e12:6.1f}) | dK/dV {tk * 1e6:7.1f} us ({3 * unit / tk / 1e12:6.1f}) | head transposes {tt * 1e6:6.1f} us | composite "
           f"{7 * unit / tot / 1e12:6.1f} TF/s = {7 * unit / tot / 2.5e15:.3f} of peak, {tot * 1e6:7.1f} us per layer", flush=True)
 
@@ -58,4 +58,8 @@ if __name__ == "__main__":
         bench(4, 2048, 8, 4, 256, w, "efficient")
     bench(4, 2048, 32, 8, 128, 0, "efficient")
     bench(4, 2048, 32, 8, 128, 0, "explicit")
+    bench(4, 2048, 32, 8, 64, 0, "efficient")                       # Llama-3.2-1B-like heads of d = 64
+    bench(64, 128, 12, 12, 64, 0, "efficient", causal=False)        # BERT-base, batch 64
+    for d in (96, 128):                                              # SigLIP tower: 4096 patches, 16 heads of d = 72 padded to 96 / 128
+        bench(4, 4096, 16, 16, d, 0, "efficient", causal=False)
     bench(64, 128, 12, 12, 64, 0, "efficient")
