@@ -312,6 +312,7 @@ def config4_image_probe(text_eng, ops, dev, dtype, peak, g, steps=3, B4=4, S4=20
     t0 = time.perf_counter()
     for i in range(steps):
         r = eng.explain(ids[(i + 1) * B4: (i + 2) * B4], pix[(i + 1) * B4: (i + 2) * B4])
+    t_issue = time.perf_counter() - t0                                         # host time to ISSUE the steps (no arena / hipGraph in this driver)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ops.GEMM_TIMER = None
@@ -321,7 +322,7 @@ def config4_image_probe(text_eng, ops, dev, dtype, peak, g, steps=3, B4=4, S4=20
                         f"seq={S4} prompt, {B4} prompts per step, {steps} steps; relevance of text tokens and ViT patches (fused driver "
                         "engine_gemma3_mm.Gemma3MMLRP, lxt.efficient placement, tower attention under the AttnLRP rule = the reference with sdpa)",
             "value": B4 * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3,
-            "gemm_TFLOPs_timed_launches": flops / max(secs, 1e-9) / 1e12, "gemm_time_frac_of_step": secs / el}
+            "gemm_TFLOPs_timed_launches": flops / max(secs, 1e-9) / 1e12, "gemm_time_frac_of_step": secs / el, "host_issue_frac_of_step": t_issue / el}
 
 
 def dry_run(args):

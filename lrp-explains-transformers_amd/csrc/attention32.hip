@@ -266,6 +266,80 @@ LRP_DEVICE float lrp_ds(float s_raw, float p, float dp, float Dq, float scale, f
     }
 }
 
+// ---- per-row key intervals: what a workgroup / a wave can see at all -------------------------------------------------------------------
+// Callers that express their whole mask as intervals (causal = 0: Gemma-3 image + text prompts, packed sequences) would otherwise stream
+// EVERY key tile past every query block and mask element by element.  The kernels derive the tile range from the intervals themselves:
+// forward / dQ: the union [min lo, max hi) over the workgroup's query rows bounds the key loop, the wave's own union skips dead tiles, and a
+// tile inside the INTERSECTION [max lo, min hi) of the wave's rows needs no per-element interval mask; dK / dV: the query rows whose interval
+// meets the workgroup's keys bound the query loop.  No assumption on the intervals (monotone or not); one LDS round trip per workgroup.
+struct IvWave { int lo_min, hi_max, lo_max, hi_min; };
+LRP_DEVICE int wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+LRP_DEVICE int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// lane's row interval [lo, hi) (rows >= S: in_range = false) -> the wave's bounds; sh[2 * wave], sh[2 * wave + 1] <- its union (the caller
+// barriers and folds the waves' unions with iv_fold)
+LRP_DEVICE IvWave iv_wave(int lo, int hi, bool in_range, int wave, int* sh) {
+    const bool sees = in_range && hi > lo;
+    IvWave w;
+    w.lo_min = wave_min(sees ? lo : 0x7fffffff);
+    w.hi_max = wave_max(sees ? hi : 0);
+    w.lo_max = wave_max(in_range ? lo : 0);
+    w.hi_min = wave_min(in_range ? hi : 0x7fffffff);
+    sh[2 * wave] = w.lo_min;
+    sh[2 * wave + 1] = w.hi_max;
+    return w;
+}
+template <int NWAVES> LRP_DEVICE void iv_fold(const int* sh, int& lo, int& hi) {
+    lo = sh[0];
+    hi = sh[1];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) { lo = min(lo, sh[2 * w]); hi = max(hi, sh[2 * w + 1]); }
+}
+// dK / dV (the row side is keys; queries stream): a table [S / 32][4] = {lo_min, hi_max, lo_max, hi_min} of every 32-query block of batch entry b
+// behind the kernel's tile buffers (host: + 16 bytes per block of dynamic LDS), built once per workgroup; from it the query range whose
+// intervals meet the workgroup's keys [k0, k0 + BK), and per (query block, wave) "dead" / "no interval mask needed" as for forward / dQ
+// one table row, read with a hand-issued ds_read_b128 (a compiler-visible LDS read in the tile loop would make the compiler drain the
+// in-flight direct-to-LDS loads of the next tile first) and moved to scalar registers (wave-uniform branches)
+LRP_DEVICE void iv_row(const int* tab, int blk, int& lo_min, int& hi_max, int& lo_max, int& hi_min) {
+    u32x4 t;
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_ptr_t)tab + 16u * (uint32_t)blk;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(a));
+    lo_min = __builtin_amdgcn_readfirstlane((int)t[0]);
+    hi_max = __builtin_amdgcn_readfirstlane((int)t[1]);
+    lo_max = __builtin_amdgcn_readfirstlane((int)t[2]);
+    hi_min = __builtin_amdgcn_readfirstlane((int)t[3]);
+}
+template <int NWAVES> LRP_DEVICE void iv_block_table(const int* rlo, const int* rhi, int S, int k0, int BK, int wave, int lane, int* tab, int* sh,
+                                                     int& qlo, int& qhi) {
+    const int nblk = (S + 31) >> 5;
+    for (int blk = wave; blk < nblk; blk += NWAVES) {
+        const int r = blk * 32 + (lane & 31);
+        const bool in = r < S;
+        const int lo = in ? rlo[r] : 0, hi = in ? rhi[r] : 0;
+        const bool sees = in && hi > lo;
+        const int a = wave_min(sees ? lo : 0x7fffffff), e = wave_max(sees ? hi : 0), c = wave_max(in ? lo : 0), d_ = wave_min(in ? hi : 0x7fffffff);
+        if (lane == 0) { tab[4 * blk] = a; tab[4 * blk + 1] = e; tab[4 * blk + 2] = c; tab[4 * blk + 3] = d_; }
+    }
+    __syncthreads();
+    int a = 0x7fffffff, e = 0;
+    for (int blk = threadIdx.x; blk < nblk; blk += NWAVES * 64)
+        if (tab[4 * blk] < k0 + BK && tab[4 * blk + 1] > k0) { a = min(a, blk * 32); e = max(e, blk * 32 + 32); }
+    a = wave_min(a);
+    e = wave_max(e);
+    sh[2 * wave] = a;
+    sh[2 * wave + 1] = e;
+    __syncthreads();
+    iv_fold<NWAVES>(sh, qlo, qhi);
+    __syncthreads();                                              // the scratch words are free again (they lie in the first tile buffer)
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
@@ -301,6 +375,17 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
     if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+    IvWave ivw = {0, S, 0, S};
+    if (row_lo != nullptr) {
+        int* ivsh = reinterpret_cast<int*>(smem);                 // the tile buffers are still unused (a static __shared__ array would move
+        ivw = iv_wave(ivlo, ivhi, qi < S, wave, ivsh);            // the dynamic base off the alignment the swizzled addresses rely on)
+        __syncthreads();
+        int glo, ghi;
+        iv_fold<NWQ>(ivsh, glo, ghi);
+        __syncthreads();                                          // everyone has read the scratch words before the first tile lands on them
+        kbeg = max(kbeg, (min(glo, S) / CT) * CT);
+        kend = min(kend, ghi);
+    }
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -324,7 +409,7 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
     for (int kt0 = kbeg; kt0 < kend; kt0 += CT) {
         if (kt0 + CT < kend) stage(kt0 + CT, cur ^ 1);
         // this wave's rows see nothing of the tile (causal: every key beyond the wave's last query): skip its arithmetic
-        const bool dead = causal && kt0 > qw + 31;
+        const bool dead = (causal && kt0 > qw + 31) || kt0 >= ivw.hi_max || kt0 + CT <= ivw.lo_min;
         if (!dead) {
             // ---- S^T of both 32-key blocks: 8 steps x 2 K fragments, read two steps ahead
             f32x16 st[2] = {zero16(), zero16()};
@@ -350,7 +435,8 @@ __global__ __launch_bounds__(NWQ * 64, 2) void fwd_kernel(
             tr_group<ND32, TILE>(tv0[0], atr);
             tr_group<ND32, TILE + 16 * KP>(tv0[1], atr);
             A32_FENCE();
-            const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) || (row_lo != nullptr);
+            const bool need_mask = (kt0 + CT > S) || (causal && kt0 + CT - 1 > qw) || (window > 0) ||
+                                   (row_lo != nullptr && !(kt0 >= ivw.lo_max && kt0 + CT <= ivw.hi_min));
             if (need_mask) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -464,6 +550,17 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
     if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT) * CT; }
+    IvWave ivw = {0, S, 0, S};
+    if (row_lo != nullptr) {
+        int* ivsh = reinterpret_cast<int*>(smem);                 // the tile buffers are still unused (a static __shared__ array would move
+        ivw = iv_wave(ivlo, ivhi, qi < S, wave, ivsh);            // the dynamic base off the alignment the swizzled addresses rely on)
+        __syncthreads();
+        int glo, ghi;
+        iv_fold<NWQ>(ivsh, glo, ghi);
+        __syncthreads();                                          // everyone has read the scratch words before the first tile lands on them
+        kbeg = max(kbeg, (min(glo, S) / CT) * CT);
+        kend = min(kend, ghi);
+    }
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -495,7 +592,7 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
         sfor<0, 2>([&](auto kbc) {
             constexpr int kb = decltype(kbc)::value, KO = kb * 32 * KP;
             const int kk0 = kt0 + kb * 32;
-            if ((causal && kk0 > qw + 31) || kk0 >= S) return;          // block invisible to every row of this wave
+            if ((causal && kk0 > qw + 31) || kk0 >= S || kk0 >= ivw.hi_max || kk0 + 32 <= ivw.lo_min) return;   // block invisible to every row of this wave
             // ---- S^T and dP^T: 8 steps x {K fragment, V fragment}, read two steps ahead
             f32x16 st = zero16(), dp = zero16();
             bf16x8 fk[3], fv[3];
@@ -521,7 +618,8 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
             tr_group<ND32, KO>(tk[0], atr);
             tr_group<ND32, KO + 16 * KP>(tk[1], atr);
             A32_FENCE();
-            const bool masked = (kk0 + 32 > S) || (causal && kk0 + 31 > qw) || (window > 0) || (row_lo != nullptr);
+            const bool masked = (kk0 + 32 > S) || (causal && kk0 + 31 > qw) || (window > 0) ||
+                                (row_lo != nullptr && !(kk0 >= ivw.lo_max && kk0 + 32 <= ivw.hi_min));
             if (masked) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -599,6 +697,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
     const int* rlo_b = row_lo ? row_lo + (int64_t)b * S : nullptr;
     const int* rhi_b = row_lo ? row_hi + (int64_t)b * S : nullptr;
+    int* const ivtab = reinterpret_cast<int*>(smem + 2 * STAGE + NW * VROWS);    // per-32-query-block interval bounds (only with row intervals)
 
     // K fragments of the wave's 32 keys live in registers; the V fragments (32 more registers: with two 128-register
     // accumulators the kernel would spill) live in a per-wave [32 rows][256 B] LDS block in the tile layout
@@ -635,6 +734,12 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     if (causal) qbeg = (k0 / CT) * CT;
     if (window > 0) qend = min(S, k0 + BK - 1 + window);
     if (q_begin > qbeg) qbeg = (q_begin / CT) * CT;              // queries below q_begin carry no relevance
+    if (rlo_b != nullptr) {
+        int qlo, qhi;
+        iv_block_table<NW>(rlo_b, rhi_b, S, k0, BK, wave, lane, ivtab, reinterpret_cast<int*>(smem), qlo, qhi);
+        qbeg = max(qbeg, (min(qlo, S) / CT) * CT);
+        qend = min(qend, qhi);
+    }
 
     auto stage = [&](int qt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -665,6 +770,13 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             constexpr int qb = decltype(qbc)::value, QO = qb * 32 * KP, SO = qb * 128;
             const int qq0 = qt0 + qb * 32;
             if ((causal && qq0 + 31 < kw) || qq0 >= S) return;          // every query of the block precedes every key of the wave
+            bool iv_mask = false;
+            if (rlo_b != nullptr) {
+                int t0_, t1_, t2_, t3_;
+                iv_row(ivtab, qq0 >> 5, t0_, t1_, t2_, t3_);
+                if (t1_ <= kw || t0_ >= kw + 32) return;                 // no query of the block sees a key of this wave
+                iv_mask = !(t2_ <= kw && t3_ >= kw + 32);                // some row's interval ends inside the wave's keys
+            }
             // ---- S^T (8 steps x Q fragment), then dP^T (8 steps x {Gho fragment, V fragment}), read one step ahead; the two
             // contractions run one after the other so that only 16 fragment registers are in flight (register budget)
             f32x16 st = zero16(), dp = zero16();
@@ -716,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
         A32_FENCE();                                                                                   \
     }
             // lane (key, hi) holds queries qq0 + 8 i + 4 hi + e (i = r >> 2, e = r & 3)
-            const bool masked = (qq0 + 32 > S) || (causal && qq0 < kw + 31) || (window > 0) || (row_lo != nullptr);
+            const bool masked = (qq0 + 32 > S) || (causal && qq0 < kw + 31) || (window > 0) || iv_mask;
             bf16x8 pf[2], df[2];
             auto elementwise = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, cu = i & 1, nx = cu ^ 1;
@@ -948,6 +1060,17 @@ __global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
     if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT2) * CT2; }
+    IvWave ivw = {0, S, 0, S};
+    if (row_lo != nullptr) {
+        int* ivsh = reinterpret_cast<int*>(smem);                 // the tile buffers are still unused (a static __shared__ array would move
+        ivw = iv_wave(ivlo, ivhi, qi < S, wave, ivsh);            // the dynamic base off the alignment the swizzled addresses rely on)
+        __syncthreads();
+        int glo, ghi;
+        iv_fold<NW2>(ivsh, glo, ghi);
+        __syncthreads();                                          // everyone has read the scratch words before the first tile lands on them
+        kbeg = max(kbeg, (min(glo, S) / CT2) * CT2);
+        kend = min(kend, ghi);
+    }
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -961,7 +1084,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
     int cur = 0;
     for (int kt0 = kbeg; kt0 < kend; kt0 += CT2) {
         if (kt0 + CT2 < kend) stage(kt0 + CT2, cur ^ 1);
-        const bool dead = (causal && kt0 > qw + 31) || (window > 0 && kt0 + CT2 - 1 <= qw - window);
+        const bool dead = (causal && kt0 > qw + 31) || (window > 0 && kt0 + CT2 - 1 <= qw - window) || kt0 >= ivw.hi_max || kt0 + CT2 <= ivw.lo_min;
         if (!dead) {
             // ---- S^T of the 32 keys: 16 steps, fragments read two steps ahead
             f32x16 st = zero16();
@@ -987,7 +1110,8 @@ __global__ __launch_bounds__(NW2 * 64, 1) void fwd256_kernel(
             A2_UNIT(tv[0], at0, at1, 0, 0, TILE2);
             A32_FENCE();
             // (a sliding window only needs per-element masks where the tile crosses the window's lower edge for some row of the wave)
-            const bool need_mask = (kt0 + CT2 > S) || (causal && kt0 + CT2 - 1 > qw) || (window > 0 && kt0 <= qw + 31 - window) || (row_lo != nullptr);
+            const bool need_mask = (kt0 + CT2 > S) || (causal && kt0 + CT2 - 1 > qw) || (window > 0 && kt0 <= qw + 31 - window) ||
+                                   (row_lo != nullptr && !(kt0 >= ivw.lo_max && kt0 + CT2 <= ivw.hi_min));
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -1096,6 +1220,17 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dq256_kernel(
     if (causal) kend = min(S, q0 + BQ);
     int kbeg = 0;
     if (window > 0) { kbeg = q0 - window + 1; kbeg = kbeg < 0 ? 0 : (kbeg / CT2) * CT2; }
+    IvWave ivw = {0, S, 0, S};
+    if (row_lo != nullptr) {
+        int* ivsh = reinterpret_cast<int*>(smem);                 // the tile buffers are still unused (a static __shared__ array would move
+        ivw = iv_wave(ivlo, ivhi, qi < S, wave, ivsh);            // the dynamic base off the alignment the swizzled addresses rely on)
+        __syncthreads();
+        int glo, ghi;
+        iv_fold<NW2>(ivsh, glo, ghi);
+        __syncthreads();                                          // everyone has read the scratch words before the first tile lands on them
+        kbeg = max(kbeg, (min(glo, S) / CT2) * CT2);
+        kend = min(kend, ghi);
+    }
 
     auto stage = [&](int kt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -1109,7 +1244,8 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dq256_kernel(
     int cur = 0;
     for (int kt0 = kbeg; kt0 < kend; kt0 += CT2) {
         if (kt0 + CT2 < kend) stage(kt0 + CT2, cur ^ 1);
-        const bool dead = (causal && kt0 > qw + 31) || kt0 >= S || (window > 0 && kt0 + CT2 - 1 <= qw - window);
+        const bool dead = (causal && kt0 > qw + 31) || kt0 >= S || (window > 0 && kt0 + CT2 - 1 <= qw - window) || kt0 >= ivw.hi_max ||
+                          kt0 + CT2 <= ivw.lo_min;
         if (!dead) {
             // ---- S^T and dP^T: 16 steps x {K fragment, V fragment}, read two steps ahead
             f32x16 st = zero16(), dp = zero16();
@@ -1135,7 +1271,8 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dq256_kernel(
             u32x2 tk[2][4][2];
             A2_UNIT(tk[0], at0, at1, 0, 0, 0);
             A32_FENCE();
-            const bool masked = (kt0 + 32 > S) || (causal && kt0 + 31 > qw) || (window > 0 && kt0 <= qw + 31 - window) || (row_lo != nullptr);
+            const bool masked = (kt0 + 32 > S) || (causal && kt0 + 31 > qw) || (window > 0 && kt0 <= qw + 31 - window) ||
+                                (row_lo != nullptr && !(kt0 >= ivw.lo_max && kt0 + 32 <= ivw.hi_min));
             if (masked) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1218,12 +1355,19 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
     bf16x8 kf[NK2];
     load_row_frags2(kf, k + (int64_t)b * S * ldk + (int64_t)hk * D2, ldk, ki, S, hi);
     char* sVw = smem + 2 * STAGE + wave * VROWS;
+    int* const ivtab = reinterpret_cast<int*>(smem + 2 * STAGE + NW2 * VROWS);   // per-32-query-block interval bounds (only with row intervals)
     stage_block2(v + (int64_t)b * S * ldv + (int64_t)hk * D2, ldv, kw, S, sVw, lane);
     const float c1 = scale * LRP_LOG2E;
     int qbeg = 0, qend = S;
     if (causal) qbeg = (k0 / CT2) * CT2;
     if (window > 0) qend = min(S, k0 + BK - 1 + window);
     if (q_begin > qbeg) qbeg = (q_begin / CT2) * CT2;
+    if (rlo_b != nullptr) {
+        int qlo, qhi;
+        iv_block_table<NW2>(rlo_b, rhi_b, S, k0, BK, wave, lane, ivtab, reinterpret_cast<int*>(smem), qlo, qhi);
+        qbeg = max(qbeg, (min(qlo, S) / CT2) * CT2);
+        qend = min(qend, qhi);
+    }
 
     auto stage = [&](int qt0, int buf) {
         char* sb = smem + buf * STAGE;
@@ -1247,7 +1391,14 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
         int cur = 0;
         for (int qt0 = qbeg; qt0 < qend; qt0 += CT2) {
             if (qt0 + CT2 < qend) stage(qt0 + CT2, cur ^ 1);
-            const bool dead = (causal && qt0 + 31 < kw) || qt0 >= S || (window > 0 && qt0 - window >= kw + 31);
+            bool dead = (causal && qt0 + 31 < kw) || qt0 >= S || (window > 0 && qt0 - window >= kw + 31);
+            bool iv_mask = false;
+            if (rlo_b != nullptr && !dead) {
+                int t0_, t1_, t2_, t3_;
+                iv_row(ivtab, qt0 >> 5, t0_, t1_, t2_, t3_);
+                dead = t1_ <= kw || t0_ >= kw + 32;                       // no query of the tile sees a key of this wave
+                iv_mask = !(t2_ <= kw && t3_ >= kw + 32);                // some row's interval ends inside the wave's keys
+            }
             if (!dead) {
                 // ---- S^T (16 steps x Q fragment); pass 1: dP^T as well (16 steps x {Gho fragment, V fragment})
                 f32x16 st = zero16(), dp = zero16();
@@ -1292,7 +1443,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
                 u32x2 tt[2][4][2];
                 A2_UNIT(tt[0], at0, at1, 0, 0, TOFF);
                 A32_FENCE();
-                const bool masked = (qt0 + 32 > S) || (causal && qt0 < kw + 31) || (window > 0 && qt0 + 31 - window >= kw) || (row_lo != nullptr);
+                const bool masked = (qt0 + 32 > S) || (causal && qt0 < kw + 31) || (window > 0 && qt0 + 31 - window >= kw) || iv_mask;
                 bf16x8 xf[2];                                             // pass 0: P, pass 1: dS (per 16-query group)
                 f32x4 sl[2], sd[2];
                 sfor<0, 2>([&](auto jc) {
@@ -1359,6 +1510,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
 
 }  // namespace d256
 
+constexpr size_t A32_LDS_MAX = 160 * 1024;       // gfx950: 160 KiB per workgroup (the dK / dV kernels' interval table grows with S: S <= ~60000 with row intervals)
 template <typename K> void set_lds(K kern, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1410,17 +1562,18 @@ int lrp_attn32_dkv_d256(const void* q, const void* k, const void* v, const void*
                         const int* row_lo, const int* row_hi, hipStream_t st) {
     using namespace attn32;
     using namespace attn32::d256;
-    const size_t lds = 2 * (2 * (size_t)TILE2 + 512) + (size_t)NW2 * 32 * KP2;
+    const size_t lds = 2 * (2 * (size_t)TILE2 + 512) + (size_t)NW2 * 32 * KP2 + (row_lo ? (size_t)((S + 31) / 32) * 16 : 0);   // + the interval table
+    if (lds > A32_LDS_MAX) return LRP_ESHAPE;
     dim3 grid(xcd_group_grid(B * Hq, (S + NW2 * 32 - 1) / (NW2 * 32)));
     if (eps_mask != 0.f || eps_qk != 0.f) {
         auto kern = dkv256_kernel<true>;
-        LRP_SET_MAX_LDS(kern, lds);
+        LRP_SET_MAX_LDS(kern, A32_LDS_MAX);
         hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
                            lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
                            causal, window, B, q_begin, row_lo, row_hi);
     } else {
         auto kern = dkv256_kernel<false>;
-        LRP_SET_MAX_LDS(kern, lds);
+        LRP_SET_MAX_LDS(kern, A32_LDS_MAX);
         hipLaunchKernelGGL(kern, grid, dim3(NW2 * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,
                            lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,
                            causal, window, B, q_begin, row_lo, row_hi);
@@ -1478,13 +1631,14 @@ int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho,
                    int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
                    const int* row_lo, const int* row_hi, hipStream_t st) {
     using namespace attn32;
-    const size_t lds = 2 * (2 * (size_t)TILE + 512) + (size_t)NW * 32 * KP;
+    const size_t lds = 2 * (2 * (size_t)TILE + 512) + (size_t)NW * 32 * KP + (row_lo ? (size_t)((S + 31) / 32) * 16 : 0);   // + the interval table
+    if (lds > A32_LDS_MAX) return LRP_ESHAPE;
     dim3 grid(xcd_group_grid(B * Hq, (S + 255) / 256));
     const bool expl = eps_mask != 0.f || eps_qk != 0.f;
 #define A32_LAUNCH_DKV(EX)                                                                                                             \
     {                                                                                                                                   \
         auto kern = dkv_kernel<EX, DH>;                                                                                                 \
-        LRP_SET_MAX_LDS(kern, lds);                                                                                                     \
+        LRP_SET_MAX_LDS(kern, A32_LDS_MAX);                                                                                             \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,   \
                            lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,     \
                            causal, window, B, q_begin, row_lo, row_hi);                                                                \

@@ -682,6 +682,18 @@ def _intervals(kind, B, S):
             for a, e in zip(cuts[:-1], cuts[1:]):
                 lo[b, a:e] = a
             hi[b] = i + 1
+        elif kind == "blocks_full":      # packed sequences WITHOUT a causal flag: bidirectional block-diagonal, the whole mask lives in the intervals
+            causal = False               # (the kernels derive their tile ranges from the intervals: no tile outside a block is visited)
+            cuts = [0, S // 3 + b, (2 * S) // 3, S]
+            for a, e in zip(cuts[:-1], cuts[1:]):
+                lo[b, a:e], hi[b, a:e] = a, e
+        elif kind == "random":           # arbitrary, NON-monotone intervals (some empty): nothing about the interval structure may be assumed
+            causal = False
+            g = torch.Generator().manual_seed(77 + b)
+            a = torch.randint(0, S, (S,), generator=g)
+            e = torch.randint(0, S + 1, (S,), generator=g)
+            lo[b], hi[b] = torch.minimum(a, e).int(), torch.maximum(a, e).int()
+            hi[b, ::7] = lo[b, ::7]       # every 7th row sees nothing
         elif kind == "image_block":      # Gemma-3: causal text, bidirectional inside an image block -> not causal-bounded
             causal = False
             a, e = S // 4, S // 4 + S // 3
@@ -691,13 +703,13 @@ def _intervals(kind, B, S):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", ["left_pad", "right_pad", "packed", "image_block"])
+@pytest.mark.parametrize("kind", ["left_pad", "right_pad", "packed", "image_block", "blocks_full", "random"])
 @pytest.mark.parametrize("B,S,Hq,Hkv,d,window", [(2, 150, 4, 2, 64, 0), (2, 200, 2, 1, 128, 0), (1, 140, 2, 1, 256, 0), (2, 160, 2, 2, 64, 40), (2, 210, 2, 1, 96, 0),
                                                  (2, 330, 4, 2, 128, 0), (2, 300, 2, 1, 128, 70)])
 def test_attention_row_intervals(ops, dtype, kind, B, S, Hq, Hkv, d, window):
     """per-row key intervals (padding / packed sequences / bidirectional blocks) against an fp64 eager attention with
     the same boolean mask; rows with an empty interval must come out as exact zeros and stay NaN-free"""
-    if kind == "image_block" and window:
+    if kind in ("image_block", "blocks_full", "random") and window:
         pytest.skip("bidirectional blocks are used with global layers")
     if dtype == torch.float32 and d == 96:
         pytest.skip("head_dim 96 exists on the bf16 32 x 32 kernels only")
