@@ -50,6 +50,10 @@ def _load():
         raise LrpLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    # PyTorch wheels ship their OWN libamdhip64; the tensors this binding receives live in THAT runtime.  Load torch first so that the
+    # dynamic linker binds liblrp_hip.so to the runtime already in the process -- with `import lxt_amd` ahead of `import torch` the library
+    # would pull in the system ROCm's copy and every launch would fail with hipErrorNoDevice (two HIP runtimes in one process).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     decls = parse_header()
     for name, (ret, types) in decls.items():

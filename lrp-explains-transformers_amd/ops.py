@@ -650,22 +650,24 @@ TAIL_SPLIT = True        # module attribute (A/B measurements): False = the roun
 
 
 def tail_split_cols(M, Nout, Kc):
-    """GEMMs of 257 ... 511 tiles of 256 x 256 (Gemma-3-4B: 8192 x 2560 = 320 tiles = 1.25 rounds of the 256 CUs: the second round keeps a
-    quarter of the chip busy for a whole tile time).  -> the number of leading output columns that make exactly ONE full round (256 tiles);
-    the remaining columns (<= 128 tiles) are issued as a second problem through the split-K path, which spreads them over all CUs (K split so
-    that tail tiles x splits = 256).  Two launches of ~1 + 0.25 tile times instead of 2 (or, for K >= 8192, instead of splitting the WHOLE
-    problem in two with fp32 slabs of the whole output).  None when the shape does not qualify."""
+    """GEMMs whose tile count (256 x 256 tiles) is not a whole number of rounds of the 256 CUs and whose LAST round is at most half full
+    (Gemma-3-4B: 8192 x 2560 = 320 tiles = 1.25 rounds; SigLIP: 16384 x 4352 = 1088 tiles = 4.25 rounds: the last round keeps a quarter of the
+    chip busy for a whole tile time).  -> the number of leading output columns that make whole rounds; the remaining tile columns (<= 128
+    tiles) are issued as a second problem through the split-K path, which spreads them over all CUs (K split so that tail tiles x splits =
+    256).  Two launches of n + ~0.25 tile times instead of n + 1 (or, for 257 ... 384 tiles and K >= 8192, instead of splitting the WHOLE problem
+    in two with fp32 slabs of the whole output).  None when the shape does not qualify (a K loop too short to split: the tail's slab round trip
+    would cost more than the partial round it replaces)."""
     if not TAIL_SPLIT:
         return None
     tm, tn = (M + 255) // 256, (Nout + 255) // 256
-    tiles = tm * tn
-    if not (256 < tiles < 512) or 256 % tm or tm > 256:
+    if tm * tn <= 256 or tm > 256 or 256 % tm:
         return None
-    main = (256 // tm) * 256
-    tail_tiles = tm * ((Nout - main + 255) // 256)
-    if main <= 0 or main >= Nout or tail_tiles > 128 or Kc // 64 < 8 * (256 // tail_tiles):
+    cpr = 256 // tm                                         # tile columns per full round
+    tail_cols = tn % cpr
+    tail_tiles = tm * tail_cols
+    if tail_cols == 0 or tail_tiles > 128 or Kc // 64 < 8 * (256 // tail_tiles):
         return None
-    return main
+    return (tn - tail_cols) * 256
 
 
 STREAM_FWD = True        # module attribute (A/B measurements): False sends every M <= 256 forward to the split-K skinny path

@@ -415,3 +415,20 @@ def test_conservation_check_mode_covers_wrapped_rules():
             y = mod(*inputs)                                          # flag off again: the rule's real (non-uniform) relevance
             y.backward(torch.ones_like(y))
             assert any(float(x.grad.max() - x.grad.min()) != 0.0 for x in inputs)
+
+
+def test_import_order_package_before_torch():
+    """`import lxt_amd` AHEAD of `import torch` in a fresh interpreter: the binding loads torch's HIP runtime before liblrp_hip.so, so both
+    use ONE libamdhip64 (PyTorch wheels ship their own; bound to the system copy, every launch failed with hipErrorNoDevice)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import lxt_amd.ops as ops\n"
+            "import torch\n"
+            "x = torch.randn(64, 96, device='cuda').bfloat16()\n"
+            "assert torch.equal(ops.transpose(x), x.t().contiguous())\n"
+            "print('ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

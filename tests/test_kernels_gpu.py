@@ -214,15 +214,16 @@ def test_gemm_big_m_row_chunks(ops):
 
 
 def test_gemm_tail_split(ops):
-    """257 ... 511-tile GEMMs (Gemma-3-4B: 8192 x 2560 = 320 tiles) are issued as one full round of the chip (256 tiles, plain kernel) + the
-    remaining columns K-split over all CUs (ops.tail_split_cols).  Both operand forms through the dispatchers, with and without bias, into
+    """GEMMs whose last round of 256 x 256 tiles is at most half full (Gemma-3-4B: 8192 x 2560 = 320 tiles = 1.25 rounds; SigLIP: 1088 tiles =
+    4.25 rounds) are issued as whole rounds on the plain kernel + the remaining columns K-split over all CUs (ops.tail_split_cols).  Both operand forms through the dispatchers, with and without bias, into
     padded outputs: equal to fp64 within bf16 rounding, and the main part bit-equal to the undivided launch (same kernel, same tiles)"""
     g = torch.Generator().manual_seed(17)
     assert ops.tail_split_cols(8192, 2560, 2048) == 2048 and ops.tail_split_cols(8192, 2560, 20480) == 2048
     assert ops.tail_split_cols(8192, 4096, 4096) is None and ops.tail_split_cols(4096, 2560, 4096) is None
     assert ops.tail_split_cols(8192, 2560, 1024) is None          # K loop too short for 4 splits of >= 8 tiles
     assert ops.tail_split_cols(2048, 8192 + 2048, 4096) == 8192    # 8 x 40 tiles
-    for (M, N, K) in [(8192, 2560, 2048), (8000, 2560 - 8, 4096), (2048, 10240, 2560)]:
+    assert ops.tail_split_cols(16384, 4352, 2560) == 4096 and ops.tail_split_cols(16384, 4352, 1152) is None     # 4.25 rounds; K too short
+    for (M, N, K) in [(8192, 2560, 2048), (8000, 2560 - 8, 4096), (2048, 10240, 2560), (16384, 4352, 2560)]:
         a = torch.randn(M, K, generator=g).bfloat16().cuda()
         w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
         bias = torch.randn(N, generator=g).bfloat16().cuda()
