@@ -376,6 +376,7 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--per-step", action="store_true", help="dev: print per-step wall times to stderr (adds a full sync per step)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="prompts per step per GPU")
@@ -472,7 +473,7 @@ def main():
         # never idles (the next step is already queued) and the step time is reproducible.
         if i >= 1:
             done[i - 1].synchronize()
-        if os.environ.get("LRP_BENCH_PER_STEP"):            # dev: per-step wall times (adds a full sync per step)
+        if args.per_step:                                   # dev: per-step wall times (adds a full sync per step)
             torch.cuda.synchronize()
             per_step.append(time.perf_counter() - t0)
     # C2: ONE all-gather of the job's [steps * prompts_per_rank, S] fp32 token relevances, inside the timed region
