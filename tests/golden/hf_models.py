@@ -43,6 +43,20 @@ def build_gemma3_4bdims(layers=2, seed=5, attn="eager", vocab=4096):
     return m
 
 
+def build_llama_8bdims(layers=8, seed=17, attn="sdpa", vocab=4096):
+    """Llama-3-8B layer dimensions (H 4096, I 14336, 32 query / 8 kv heads of d = 128, rope theta 5e5), `layers` decoder layers, small
+    vocabulary, HF's default seeded init: the depth / bf16 conditioning fixture (make_golden_llama_bf16_depth.py)"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    kw = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers, num_attention_heads=32, num_key_value_heads=8,
+              vocab_size=vocab, rms_norm_eps=1e-5, max_position_embeddings=8192, tie_word_embeddings=False, attn_implementation=attn)
+    try:
+        cfg = LlamaConfig(rope_parameters=dict(rope_type="default", rope_theta=500000.0), **kw)
+    except TypeError:
+        cfg = LlamaConfig(rope_theta=500000.0, **kw)
+    return LlamaForCausalLM(cfg).eval()
+
+
 def build_gemma3_mm(seed=11, attn="eager"):
     """tiny Gemma3ForConditionalGeneration: text tower (sliding + global layers) + SigLIP tower (head_dim 72 like the real
     SigLIP-So400m: 1152 / 16) + multi-modal projector.  HF leaves the projector weight at zeros on random init -> seeded here."""
