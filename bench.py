@@ -325,6 +325,53 @@ def config4_image_probe(text_eng, ops, dev, dtype, peak, g, steps=3, B4=4, S4=20
             "gemm_TFLOPs_timed_launches": flops / max(secs, 1e-9) / 1e12, "gemm_time_frac_of_step": secs / el, "host_issue_frac_of_step": t_issue / el}
 
 
+def dropin_probe(dev, S=2048, B=4, steps=3):
+    """The DROP-IN path at the headline shape, after and outside the timed region: a HuggingFace LlamaForCausalLM at the Llama-3-8B dimensions
+    (32 layers, random init on the device, bf16) under `lxt_amd.efficient.monkey_patch(modeling_llama)`, driven by autograd exactly as the
+    reference's quickstart drives lxt.efficient (docs/source/quickstart.rst:120-141: inputs_embeds.requires_grad_(), logits[.., -1, idx]
+    .backward(), (e * e.grad).sum(-1)); 4 prompts per step as one batch.  The rules run on the same HIP kernels as the fused engine; what
+    it adds is HF's module graph, autograd bookkeeping and HF's own (un-fused) RMSNorm / RoPE / residual kernels."""
+    import warnings
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.models.llama import modeling_llama
+    from lxt_amd.efficient import monkey_patch
+    kw = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+              rms_norm_eps=1e-5, max_position_embeddings=8192, tie_word_embeddings=False, attn_implementation="sdpa")
+    try:
+        hcfg = LlamaConfig(rope_parameters=dict(rope_type="default", rope_theta=500000.0), **kw)
+    except TypeError:
+        hcfg = LlamaConfig(rope_theta=500000.0, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_llama)
+        torch.manual_seed(0)
+        with torch.device(dev):
+            model = LlamaForCausalLM(hcfg).to(torch.bfloat16).eval()
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    ids = torch.randint(0, 128256, (B * (steps + 1), S), generator=torch.Generator().manual_seed(77)).to(dev)
+    rows = torch.arange(B, device=dev)
+
+    def run(chunk):
+        e = model.get_input_embeddings()(chunk).detach().requires_grad_()
+        last = model(inputs_embeds=e, use_cache=False, logits_to_keep=1).logits[:, -1]
+        last[rows, last.argmax(-1)].sum().backward()
+        return (e * e.grad).float().sum(-1)
+    R = run(ids[:B])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        R = run(ids[(i + 1) * B: (i + 2) * B])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(R).all()
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": f"HF LlamaForCausalLM (Llama-3-8B dims, 32 layers, bf16, random init) under lxt_amd.efficient.monkey_patch, autograd-driven "
+                        f"(the reference's own protocol), seq={S}, {B} prompts per step, {steps} steps",
+            "value": B * steps / el, "unit": "explanations/s", "ms_per_step": el / steps * 1e3}
+
+
 def dry_run(args):
     """the N-rank control flow of main() with the explanation replaced by a pure function of the ids (no engine, no device):
     what torch.distributed.run + this script must get right before any kernel matters"""
@@ -388,6 +435,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the seq=4096 probe that follows the headline region")
     ap.add_argument("--no-config4", action="store_true", help="skip the Gemma-3-4B text-tower probe that follows the headline region")
     ap.add_argument("--no-config4-image", action="store_true", help="skip the image + text part of the Gemma-3-4B probe")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the HF-model-under-monkey_patch probe that follows the headline region")
     ap.add_argument("--no-extra-modes", action="store_true", help="skip the explicit-mode and one-prompt-per-step probes that follow the headline region")
     ap.add_argument("--no-smallm", action="store_true", help="skip the small-M Linear tables that follow the headline region (profiling: their "
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
@@ -544,6 +592,12 @@ def main():
             line["config4_gemma3_4b_text"], mm_line = config4_probe(ops, dev, dtype, peak, image=not args.no_config4_image)
             if mm_line is not None:
                 line["config4_gemma3_4b_image_text"] = mm_line
+        if not args.no_dropin and args.layers == 32 and dtype == torch.bfloat16 and world == 1:
+            eng.release()
+            try:
+                line["dropin_monkey_patch"] = dropin_probe(dev, S=S, B=args.batch)
+            except Exception as exc:  # noqa: BLE001  (a transformers API drift must not take the headline line down with it)
+                line["dropin_monkey_patch"] = {"error": repr(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)
