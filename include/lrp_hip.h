@@ -257,7 +257,7 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
  *        lxt/explicit/rules.py:267-282 (P.V uniform-epsilon), llama.py:379-391.
  * Layout: q [B*S, Hq, d], k/v [B*S, Hkv, d] token-major with row strides ldq/ldk/ldv
  * (slices of a fused QKV GEMM output are consumed in place); o [B*S, Hq, d] (ldo);
- * lse fp32 [B, Hq, S] = log-sum-exp of the scaled scores; d in {16,32,64,128,256}.
+ * lse fp32 [B, Hq, S] = log-sum-exp of the scaled scores; d in {16,32,64,128,256}, bf16 also 96.
  * "_t" operands are head-transposed copies [B, H, d, ldt] (ldt >= S, multiple of 16 bytes'
  * worth of elements, pad columns FINITE -- zero them once) made by lrp_transpose_heads.  They are read ONLY by the kernels
  * for which lrp_attn_needs_transposed(dtype, d) returns 1 (fp32, and bf16 head dims without a transpose-read kernel); the
@@ -268,8 +268,10 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
  *   entirely below it are skipped (top-layer sparsity: above the last attention layer only the last
  *   token of a prompt has a non-zero seed); rows below q_begin in outputs are unspecified (fwd, dq).
  *   row_lo / row_hi (int32 [B*S], both or neither; NULL = none): per-query-row key interval -- key j is visible to
- *   query (b, i) only if row_lo[b*S+i] <= j < row_hi[b*S+i], IN ADDITION to (causal, window), which keep describing
- *   the mask's structure and bound the tiles visited.  Every mask HF builds for the supported families is of this
+ *   query (b, i) only if row_lo[b*S+i] <= j < row_hi[b*S+i], IN ADDITION to (causal, window).  The bf16 kernels of
+ *   attention32.hip derive the tiles they visit from the intervals themselves (union over a workgroup's rows; no assumption
+ *   on the intervals), so a mask handed over ONLY as intervals (causal = 0) costs what the causal flag costs; the fp32 /
+ *   small-head-dim kernels bound their tiles by (causal, window) only.  Every mask HF builds for the supported families is of this
  *   form (left / right padding, packed sequences, Gemma-3's bidirectional image blocks: causal = 0 there).  A row
  *   with an empty interval yields o = 0, lse = -inf and contributes nothing to dQ / dK / dV
  *   (ref: the additive-mask argument of HF eager_attention_forward, which lxt/efficient/patches.py:193-203 wraps).
@@ -284,8 +286,8 @@ int lrp_rope_bwd(const void* Gr, const void* xr, const void* x, void* A, const f
 int lrp_transpose_heads(const void* x, void* xt, int B, int S, int H, int d, int64_t ldx,
                         int64_t ldt, int dtype, void* stream);
 /* 1 if the kernels serving (dtype, d) read the head-transposed "_t" copies, 0 if they take every operand from the
- * token-major tensors (bf16, d = 128: 32x32x16 MFMA kernels, transposed fragments by ds_read_b64_tr_b16 out of the
- * row-major LDS tile).  With 0 the "_t" arguments below may be NULL and no lrp_transpose_heads launch is needed. */
+ * token-major tensors (bf16, d in {64, 96, 128, 256}: 32x32x16 MFMA kernels, transposed fragments by ds_read_b64_tr_b16
+ * out of the row-major LDS tile).  With 0 the "_t" arguments below may be NULL and no lrp_transpose_heads launch is needed. */
 int lrp_attn_needs_transposed(int dtype, int d);
 int lrp_attn_fwd(const void* q, const void* k, const void* v, const void* v_t, void* o, float* lse,
                  int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,
