@@ -3,10 +3,10 @@
 # (2) FETCH_SIZE / WRITE_SIZE PMC passes of a 4-layer run -> GEMM traffic per launch (stamped with the kernel source hash by r4_traffic.py),
 # (3) SQ counter passes of the attention kernels (d = 128 and the new d = 256), (4) kernel split of the small-M Linear paths.
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=$GRAFT_REPO_ROOT/gpurun_out/r4prof
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r4prof}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --no-config4 --no-smallm --no-extra-modes"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --no-config4 --no-smallm --no-extra-modes --no-dropin"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $BENCH --steps 4 --warmup 1 > $O/bench_under_rocprof.json 2> $O/kt.log
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) > $O/kernel_stats.txt 2>&1
 head -32 $O/kernel_stats.txt | cut -c1-200
