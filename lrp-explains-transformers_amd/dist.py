@@ -44,9 +44,17 @@ def shard_range(n_items, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+SINGLE_RANK_COLLECTIVES = False      # module attribute (tests): True sends a ONE-rank job through the collectives too instead of short-cutting them
+                                     # (RCCL on the one GPU a test box has: the same calls, buffers and dtypes as the 8-rank job)
+
+
+def _collectives_off():
+    return not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not SINGLE_RANK_COLLECTIVES)
+
+
 def broadcast_weights(tensors, src=0):
     """in-place broadcast of a list of (already allocated) tensors from rank `src`"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _collectives_off():
         return
     for t in tensors:
         dist.broadcast(t, src=src)
@@ -54,22 +62,23 @@ def broadcast_weights(tensors, src=0):
 
 def checksum(t, chunk=1 << 27):
     """exact integer checksum of a tensor's BYTES (sum of its 16-bit words as int64, in chunks: no 4x-sized temporary for a 16-GB
-    weight buffer) -> python int; equal bytes <=> equal checksum up to collisions, independent of device and dtype"""
+    weight buffer), reduced modulo 2^62 -> non-negative python int; equal bytes <=> equal checksum up to collisions, independent of device
+    and dtype"""
     v = t.detach().contiguous().view(-1).view(torch.int16)
     tot = 0
     for i in range(0, v.numel(), chunk):
         tot += int(v[i: i + chunk].to(torch.int64).sum())
-    return tot
+    return tot & ((1 << 62) - 1)
 
 
 def check_replicas(tensors):
     """after broadcast_weights: every rank's copy of `tensors` carries rank 0's bytes -- one all-gather of the per-rank checksums,
     AssertionError on every rank if any replica differs.  Returns the checksum list (one entry per rank)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _collectives_off():
         return [sum(checksum(t) for t in tensors)]
     dev = tensors[0].device
     # (an int64 does not survive a float reduction; split into two 31-bit halves carried as int64 through all_gather)
-    mine = sum(checksum(t) for t in tensors)
+    mine = sum(checksum(t) for t in tensors)                 # non-negative (each term < 2^62)
     loc = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF, (mine >> 62) & 0x7FFFFFFF], dtype=torch.int64, device=dev)
     allc = torch.empty(dist.get_world_size() * 3, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allc, loc)
@@ -99,7 +108,7 @@ def check_gather_order(n_total, S, device, dtype=torch.float32):
 
 def gather_relevance(R_local, n_total):
     """R_local [n_local, S] -> [n_total, S] on every rank, rows in global prompt order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _collectives_off():
         return R_local
     world = dist.get_world_size()
     S = R_local.shape[1]

@@ -314,6 +314,51 @@ def test_two_rank_job_on_two_gpus(tmp_path):
     assert r.returncode == 0 and (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists(), r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_single_rank_job_through_rccl(tmp_path):
+    """the job's collectives on RCCL with the ONE GPU a test box has: a one-rank `nccl` process group, the short cuts for world == 1 switched
+    off (dist.SINGLE_RANK_COLLECTIVES): broadcast of the engine's flat weight buffer, all-gather of the replica checksums (int64 on the
+    device), the rank-tagged gather-order check and the job's own all-gather of fp32 relevances -- the same calls, buffers and dtypes the
+    8-rank job issues, through librccl; result equal to the un-sharded explanation bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import os, socket, subprocess, sys, textwrap
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    script = tmp_path / "w1.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, %r)
+        import lxt_amd.dist as D, lxt_amd.engine as E
+        import torch.distributed as dist
+        from tests.util import llama_case
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        assert dist.get_backend() == "nccl"
+        D.SINGLE_RANK_COLLECTIVES = True
+        cfg, W, ids, fx = llama_case("mid")
+        eng = E.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="efficient", max_seq=512, device="cuda:0")
+        before = D.checksum(eng.flat)
+        D.broadcast_weights([eng.flat], src=0)
+        sums = D.check_replicas([eng.flat])
+        assert sums == [before], (sums, before)
+        D.check_gather_order(7, ids.shape[0], torch.device("cuda:0"))
+        job = torch.stack([torch.roll(ids, k) for k in range(5)]).cuda()
+        R = D.explain_sharded(lambda x: eng.explain(x)["R_tok"], job, batch=2)
+        whole = torch.cat([eng.explain(job[i:i + 2])["R_tok"] for i in range(0, 5, 2)])
+        assert R.shape == whole.shape and torch.equal(R, whole), "gathered != local"
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("rccl ok", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+    """) % root)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(r.stdout[-300:])
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_llama_arena_reuse_and_graph_replay(eng_mod, dtype):
     """the workspace arena is reused across calls of different (B, S) without cross-talk (results equal a fresh engine's, bit for bit),
