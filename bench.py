@@ -423,6 +423,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="dev, 1 GPU: run the N > 1 code path (RCCL broadcast / self-checks / all-gather / barriers) with a one-rank process group")
     ap.add_argument("--per-step", action="store_true", help="dev: print per-step wall times to stderr (adds a full sync per step)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -461,6 +463,15 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # dev (a 1-GPU box): --single-rank-collectives sends the ONE-rank run through the N > 1 code path below -- an `nccl` process group of
+    # world size 1, the world == 1 short cuts of lxt_amd.dist switched off: the same RCCL calls, buffers and dtypes as the 8-rank job
+    coll = world > 1
+    if args.single_rank_collectives and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        D.SINGLE_RANK_COLLECTIVES = True
+        coll = True
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = dict(LLAMA3_8B, n_layers=args.layers)
 
@@ -469,7 +480,7 @@ def main():
     del W
     torch.cuda.empty_cache()
     selfcheck = None
-    if world > 1:
+    if coll:
         # C1 of SURVEY.md 8e: ONE collective over the engine's flat weight buffer (forward layouts only, 16 GB) -- outside the timed region;
         # the dgrad GEMMs read the stored weights, so nothing is rebuilt (build_transposes only drops cached fp32 transposes).  SELF-CHECKING
         # (VERDICT r3): every rank but 0 ZEROES its replica first, so the ranks can only produce finite, equal results if the broadcast
@@ -501,7 +512,7 @@ def main():
     for i in range(args.warmup):
         R = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if coll:
         dist.barrier()
     timer = ops.KernelTimer()
     ops.GEMM_TIMER = timer
@@ -527,12 +538,12 @@ def main():
     # C2: ONE all-gather of the job's [steps * prompts_per_rank, S] fp32 token relevances, inside the timed region
     R = D.gather_relevance(torch.cat(shards, 0), n_total * args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if coll:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.GEMM_TIMER = None
     assert R.shape[0] == n_total * args.steps and torch.isfinite(R).all()
-    if world > 1:
+    if coll:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
@@ -601,7 +612,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 
