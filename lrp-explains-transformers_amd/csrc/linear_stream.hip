@@ -15,7 +15,8 @@
 //   * every wait is a hand-counted s_waitcnt: loads retire in order, so "x(t) has landed" = "all but the XD (P + 2) younger VMEM operations
 //     have retired" -- which also covers W(t), issued 8 tiles earlier (2 W pieces + P x pieces per wave and K tile).  The last 8 tiles are peeled: nothing is fetched past K.
 //   * 16-row blocks past M are not multiplied (nb live blocks of the MBMAX the instantiation has accumulators for).
-// Grid: ceil(N / 64) workgroups; the host uses the kernel when that fills the chip (>= 192) and K is a multiple of 512.
+// Grid: ceil(N / (4 rw)) workgroups, rw = W rows per wave (8 .. 16, stream_rows_per_wave: whole rounds of the 256 CUs); the host uses the kernel when
+// ceil(N / 64) >= 192 and K is a multiple of 512.
 // D = mfma(Wfrag, xfrag): lane l holds z[m = 16 i + (l & 15)][n = n0 + 16 w + 4 (l >> 4) + e].
 #include "common.hpp"
 
@@ -56,12 +57,15 @@ template <int I, int N, typename F> LRP_DEVICE void ls_for(F&& f) {
 template <typename TO, int MBMAX>
 __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, TO* __restrict__ z, const bf16_t* __restrict__ bias, int M, int N, int K,
-    int64_t ldx, int64_t ldw, int64_t ldz) {
+    int64_t ldx, int64_t ldw, int64_t ldz, int rw) {
     using C = LSCfg<MBMAX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 64;
+    // rw = W rows per wave (8 .. 16): the host picks it so that ceil(N / (4 rw)) workgroups cover the 256 CUs in whole rounds -- N = 14336 with
+    // 16 rows per wave is 224 workgroups, and a CU streams at ~23 GB/s whatever the others do: 32 idle CUs are 12.5 % of the bandwidth.  Rows
+    // rw .. 15 of the wave's 16-row MFMA block are never fetched (offset beyond num_records: zero fill) and never stored.
+    const int n0 = blockIdx.x * (4 * rw);
     const int nkt = K / LS_KT;
     int nb = (M + 15) >> 4;
     nb = nb > MBMAX ? MBMAX : nb;
@@ -69,8 +73,10 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
     // ---- W: raw buffer over the whole weight (rows past N read as zero); this wave's rows n0 + 16 w .. + 15 as two 8-row pieces per K tile
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(((int64_t)(N - 1) * ldw + K) * 2), 0x00020000);
     const int prow = lane >> 3, pslot = lane & 7;
-    const int voW = (int)(prow * ldw * 2) + ((pslot ^ prow) << 4);
-    const int soW = (int)((int64_t)(n0 + 16 * wave) * ldw * 2);
+    int voW[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) voW[p] = (8 * p + prow < rw) ? (int)(prow * ldw * 2) + ((pslot ^ prow) << 4) : 0x40000000;
+    const int soW = (int)((int64_t)(n0 + rw * wave) * ldw * 2);
     char* const wring = smem + C::NBUF * C::XTILE + wave * (LS_WD * 2048);       // [LS_WD tiles][16 rows][128 B], wave-private
     // ---- x: LDS-DMA pieces of 8 rows x 128 B; lane l -> row l >> 3, LDS slot l & 7, source chunk slot ^ (row & 7)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
         constexpr int s = decltype(sc)::value;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ls_lds_ptr_t)(wring + s * 2048 + p * 1024), 16, voW,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ls_lds_ptr_t)(wring + s * 2048 + p * 1024), 16, voW[p],
                                                      soW + (int)((int64_t)(8 * p) * ldw * 2) + kt * 128, 0, 2);
     };
 
@@ -176,14 +182,15 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
     ls_for<0, LS_WD>([&](auto sc) { tile(sc, LSI<1>{}, t0 + decltype(sc)::value); });
 
     // ---- epilogue: lane holds z[16 i + (l & 15)][n0 + 16 w + 4 (l >> 4) + e]
-    const int ncol = n0 + 16 * wave + 4 * (lane >> 4);
+    const int c16 = 4 * (lane >> 4);                                  // column of the wave's 16-row block: live while < rw
+    const int ncol = n0 + rw * wave + c16;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (ncol + e < N) bv[e] = to_f32(bias[ncol + e]);
+            if (c16 + e < rw && ncol + e < N) bv[e] = to_f32(bias[ncol + e]);
     }
-    const bool vec = (ncol + 3 < N) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
+    const bool vec = (c16 + 3 < rw) && (ncol + 3 < N) && ((ncol & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < MBMAX; ++i) {
         const int m = 16 * i + (lane & 15);
@@ -199,10 +206,21 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (ncol + e < N) dst[e] = from_f32<TO>(v[e]);
+                    if (c16 + e < rw && ncol + e < N) dst[e] = from_f32<TO>(v[e]);
             }
         }
     }
+}
+
+// rows of W per wave: the count in 8 .. 16 that covers N in the fewest whole rounds of the 256 CUs (cost = rounds x rows per workgroup; ties
+// go to the larger block).  N = 14336: 14 (256 workgroups instead of 224); N = 28672: 14 (512 = two rounds instead of 448 = 1.75).
+inline int stream_rows_per_wave(int N) {
+    int best = 16, best_cost = ((((N + 63) / 64) + 255) / 256) * 16;
+    for (int rw = 15; rw >= 8; --rw) {
+        const int wgs = (N + 4 * rw - 1) / (4 * rw), cost = ((wgs + 255) / 256) * rw;
+        if (cost < best_cost) { best = rw; best_cost = cost; }
+    }
+    return best;
 }
 
 // =====================================================================================================================
@@ -402,8 +420,9 @@ int launch_stream(const void* x, const void* W, const void* bias, void* z, int M
     const size_t lds = (size_t)C::NBUF * C::XTILE + 4 * (size_t)LS_WD * 2048;        // x ring + four wave-private W rings
     auto kern = linear_stream_fwd_kernel<TO, MBMAX>;
     LRP_SET_MAX_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((N + 63) / 64), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (TO*)z, (const bf16_t*)bias, M, N, K,
-                       ldx, ldw, ldz);
+    const int rw = stream_rows_per_wave(N);
+    hipLaunchKernelGGL(kern, dim3((N + 4 * rw - 1) / (4 * rw)), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (TO*)z, (const bf16_t*)bias, M,
+                       N, K, ldx, ldw, ldz, rw);
     return lrp_check_launch();
 }
 
