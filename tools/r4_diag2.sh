@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical) ran diagnostic builds of the library (tools/ab/liblrp_diagN.so: the dK/dV kernel with parts of its work removed; build switches not committed) -> profiles/r04_dkv_diagnostic_builds.txt
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 echo "release:"; python tools/attn_dkv_only.py 2>&1 | grep -v amdgpu.ids
