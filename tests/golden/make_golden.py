@@ -203,8 +203,9 @@ class _AV(nn.Module):
         return torch.matmul(a, v)
 
 
-def ref_explicit_llama(cfg, W, emb, target=None):
-    """Hand-composed lxt.explicit Llama (batch 1) from the REFERENCE's Functions."""
+def ref_explicit_llama(cfg, W, emb, target=None, seed=None):
+    """Hand-composed lxt.explicit Llama (batch 1) from the REFERENCE's Functions.  `seed` [V]: the relevance pattern handed to
+    `logits[0, -1].backward(seed)` instead of the explained logit itself (contrastive explanations, ref docs/source/quickstart.rst:267-270)."""
     dt = emb.dtype
     S = emb.shape[0]
     d, nq, nk = cfg["head_dim"], cfg["n_heads"], cfg["n_kv"]
@@ -259,7 +260,10 @@ def ref_explicit_llama(cfg, W, emb, target=None):
     last = logits[0, -1]
     if target is None:
         target = int(last.argmax())
-    last[target].backward(last[target].detach())                                 # examples/paper/llama.py:45
+    if seed is not None:
+        last.backward(seed.to(last.dtype))
+    else:
+        last[target].backward(last[target].detach())                             # examples/paper/llama.py:45
     R_emb = e.grad[0]
     layer_R = [float(R_emb.sum())] + [float(t.grad.sum()) for t in hs[1:]]
     return dict(idx=target, logit=float(last[target]), R_tok=R_emb.sum(-1), R_emb=R_emb, layer_R=layer_R,

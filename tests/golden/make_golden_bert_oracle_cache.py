@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pre-computes the fp64 oracle results (oracle/bert.py + its fp32-conditioning noise draws) the BERT GPU tests compare against, for the
+"""Pre-computes the fp64 oracle results (oracle/bert.py in fp64) the BERT GPU tests compare against, for the
 exact cases those tests run -> tests/golden/bert_oracle_cache.npz (tests/util.py: bert_oracle).  CPU only; needs neither the GPU nor
 the reference: the oracle itself is pinned against the reference by the bert_base*.npz fixtures.
 
@@ -33,8 +33,7 @@ def add(ids, target, eps_zero, draws, rel=1e-7):
     out[key + "/R_tok"] = r["R_tok"].double().numpy()
     out[key + "/logit"] = np.float64(r["logit"])
     out[key + "/layer_R"] = np.asarray(r["layer_R"], dtype=np.float64)
-    out[key + "/cond"] = np.float64(r["cond"])
-    print(f"{key}: logit {r['logit']:+.6f} cond {r['cond']:.2e}", flush=True)
+    print(f"{key}: logit {r['logit']:+.6f}", flush=True)
 
 
 # tests/test_bert_engine_gpu.py::test_bert_engine_explicit_fp32_vs_reference_and_oracle

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from tests.golden.hf_models import build_bert, wsum
-from tests.util import nmax, load, t, bert_oracle
+from tests.util import nmax, load, t, bert_oracle, ref_case, ref_bar
 
 pytestmark = pytest.mark.gpu
 
@@ -150,7 +150,9 @@ def test_bert_engine_bf16_close_to_fp32(bert):
 @pytest.mark.parametrize("B,S", [(1, 37), (3, 100), (2, 192)])      # explicit mode: first prompt only (each fp64 conditioning estimate costs seconds)
 def test_bert_engine_ragged_lengths_vs_oracle(bert, B, S):
     """sequence lengths that are not a multiple of any tile (attention key/query tiles of 64, GEMM rows of 32/64/128), both modes:
-    efficient vs the fp64 oracle with every stabiliser at 0 (1e-4), explicit within the instance's conditioning"""
+    efficient vs the fp64 oracle with every stabiliser at 0 (1e-4); explicit (first prompt): 1e-4, or 3x what the REFERENCE's own explicit
+    composite (lxt.explicit.functional / rules composed as lxt/explicit/models/bert.py) loses in fp32 on the same prompt
+    (tests/golden/small_cases_ref.npz, run in the build container)"""
     from lxt_amd.engine_bert import BertLRP
     from oracle import bert as ob
     from tests.golden import bert_explicit_compose as C
@@ -163,6 +165,11 @@ def test_bert_engine_ragged_lengths_vs_oracle(bert, B, S):
             o64 = bert_oracle(W64, ids[b], int(r["idx"][b]), eps_zero=(mode == "efficient"), draws=0 if mode == "efficient" else 2, rel=1e-7,
                               wsum_=wsum(bert))
             e = nmax(r["R_tok"][b], o64["R_tok"])
-            bar = 1e-4 if mode == "efficient" else max(1e-4, 5 * o64["cond"])
-            print(f"[BertLRP {mode} B={B} S={S} prompt {b}] token vs oracle fp64 {e:.2e} (bar {bar:.1e}{', cached oracle' if o64['cached'] else ''})")
+            bar = 1e-4
+            if mode == "explicit":
+                fx = ref_case(f"bert_ragged_S{S}_b{b}")
+                assert int(r["idx"][b]) == fx["idx"] and nmax(o64["R_tok"], fx["R_tok"]) < 1e-9       # same instance, same exact result
+                bar = ref_bar(fx["gap"])
+            print(f"[BertLRP {mode} B={B} S={S} prompt {b}] token vs oracle fp64 {e:.2e} (bar {bar:.1e}"
+                  f"{' = max(1e-4, 3x the reference fp32 gap)' if mode == 'explicit' else ''}{', cached oracle' if o64['cached'] else ''})")
             assert abs(float(r["logit"][b]) - o64["logit"]) < 1e-4 and e < bar

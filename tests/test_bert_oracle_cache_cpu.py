@@ -1,5 +1,5 @@
 """CPU: the committed fp64-oracle cache the BERT GPU tests read (tests/golden/bert_oracle_cache.npz, tests/util.py: bert_oracle) is what
-oracle/bert.py computes -- one cached case is recomputed live (S = 37, efficient placement and explicit with its noise draws)."""
+oracle/bert.py computes -- one cached case is recomputed live (S = 37, efficient and explicit placement)."""
 import torch
 
 from tests.golden import bert_explicit_compose as C
@@ -27,4 +27,4 @@ def test_cached_bert_oracle_matches_live_oracle():
             U._BERT_CACHE = saved
         assert cached["cached"] and not live["cached"]
         assert nmax(cached["R_tok"], live["R_tok"]) < 1e-9 and abs(cached["logit"] - live["logit"]) < 1e-12
-        assert nmax(cached["layer_R"], live["layer_R"]) < 1e-9 and abs(cached["cond"] - live["cond"]) <= 1e-6 * max(live["cond"], 1e-30) + 1e-12
+        assert nmax(cached["layer_R"], live["layer_R"]) < 1e-9

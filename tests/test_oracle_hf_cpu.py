@@ -98,20 +98,21 @@ def test_bert_explicit_oracle_vs_reference_fixture():
     assert gap < 10 * float(fx["cond_gap"])
 
 
-def test_bert_conditioning_estimate_is_deterministic_and_zero_without_noise():
-    """tests/util.fp32_conditioning_bert (the bar of the explicit BERT GPU tests): seeded noise -> reproducible estimate; rel = 0
-    reproduces the oracle exactly; the estimate grows with the noise level"""
+def test_small_case_reference_fixture_matches_live_oracle():
+    """tests/golden/small_cases_ref.npz (the yardsticks of the small explicit-mode GPU cases, written from the imported reference by
+    tests/golden/make_golden_small_cases.py): its `R_tok` is the exact result the live fp64 oracle computes on the regenerated instance, and
+    the oracle run in fp32 -- the same op sequence as the reference's Functions -- lands where the reference's own fp32 run did."""
     import torch
-    from transformers import BertConfig, BertForSequenceClassification
-    from tests.golden import bert_explicit_compose as C
-    from tests.util import fp32_conditioning_bert
-    torch.manual_seed(3)
-    model = BertForSequenceClassification(BertConfig(vocab_size=200, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
-                                                     intermediate_size=64, max_position_embeddings=64, num_labels=2)).eval()
-    W64 = C.weights_from_hf(model, torch.float64)
-    ids = torch.randint(0, 200, (24,), generator=torch.Generator().manual_seed(4))
-    a = fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-7)
-    b = fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-7)
-    assert a == b and a > 0
-    assert fp32_conditioning_bert(W64, ids, 0, draws=1, rel=0.0) == 0.0
-    assert fp32_conditioning_bert(W64, ids, 0, draws=2, rel=1e-5) > a
+    from oracle import llama as ol
+    from tests.util import ref_case, nmax
+    cfg = dict(hidden=256, inter=512, n_layers=2, n_heads=8, n_kv=2, head_dim=32, vocab=512, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=302)
+    for S, b in ((37, 0), (100, 2)):
+        ids = torch.randint(0, 512, (3 if S == 100 else 1, S), generator=torch.Generator().manual_seed(S))[b]
+        fx = ref_case(f"llama_ragged_S{S}_b{b}")
+        o64 = ol.explain(cfg, W, ids=ids, mode="explicit", dtype=torch.float64)
+        o32 = ol.explain(cfg, W, ids=ids, target=o64["idx"], mode="explicit", dtype=torch.float32)
+        assert o64["idx"] == fx["idx"] and nmax(o64["R_tok"], fx["R_tok"]) < 1e-10
+        gap = nmax(o32["R_tok"], o64["R_tok"])
+        print(f"S={S} prompt {b}: oracle fp32 vs exact {gap:.2e}; the reference's own fp32 {fx['gap']:.2e}")
+        assert gap < 10 * fx["gap"] + 1e-6
