@@ -58,6 +58,15 @@ inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 
 #ifndef A32_BUFFER_STAGING
 #define A32_BUFFER_STAGING 1
 #endif
+// dK / dV kernel (d <= 128) build switches, kept for A/B builds (tools/ab): A32_DKV_P1 = fragment read-ahead of the S^T / dP^T phase in
+// steps (0: the round 2-4 form), A32_DKV_EW = 1: one mask branch per 4-query group in the element-wise phase
+#ifndef A32_DKV_P1
+#define A32_DKV_P1 2
+#endif
+#ifndef A32_DKV_EW
+#define A32_DKV_EW 1
+#endif
+
 // Head dims below 128: a lane whose source chunk lies past the head (chunk >= DH / 8) gets an offset beyond num_records -- the buffer
 // unit returns zero without a memory request; its LDS slot is never read.
 constexpr int A32_OOB = 0x40000000;
@@ -677,7 +686,10 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
 // =====================================================================================================================
 // dK / dV per query head: row side = 32 keys per wave; Q and Gho tiles (+ lse, D) stream
 // =====================================================================================================================
-template <bool EXPL, int DH>
+// IV: the caller handed per-row key intervals (row_lo / row_hi).  A compile-time switch because the interval loads of the masked element-wise path
+// sit behind a compiler-placed s_waitcnt vmcnt(0), which also drains the in-flight direct-to-LDS loads of the next tile -- in EVERY diagonal block
+// of a plain causal call, intervals or not.
+template <bool EXPL, int DH, bool IV>
 __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int Hq,
@@ -695,8 +707,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const bf16_t* gb_ = gho + (int64_t)b * S * ldg + (int64_t)h * DH;
     const float* lse_b = lse + ((int64_t)b * Hq + h) * S;
     const float* D_b = Dd + ((int64_t)b * Hq + h) * S;
-    const int* rlo_b = row_lo ? row_lo + (int64_t)b * S : nullptr;
-    const int* rhi_b = row_lo ? row_hi + (int64_t)b * S : nullptr;
+    const int* rlo_b = (IV && row_lo) ? row_lo + (int64_t)b * S : nullptr;
+    const int* rhi_b = (IV && row_lo) ? row_hi + (int64_t)b * S : nullptr;
     int* const ivtab = reinterpret_cast<int*>(smem + 2 * STAGE + NW * VROWS);    // per-32-query-block interval bounds (only with row intervals)
 
     // K fragments of the wave's 32 keys live in registers; the V fragments (32 more registers: with two 128-register
@@ -750,6 +762,11 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     };
     if (qbeg < qend) stage(qbeg, 0);
     __syncthreads();
+    // Measured and NOT adopted (round 5, profiles/r05_attention_experiments.txt): running the two 4-wave groups of the workgroup (waves w and w + 4
+    // share a SIMD) HALF A BLOCK APART -- S^T / dP^T of one beside {element-wise, dV / dK} of the other, raw s_barrier between the half blocks,
+    // one extra barrier up front for group 1, the GEMM's recipe -- is SLOWER (413 -> 471 us): beside a partner that streams MFMAs the element-wise
+    // phase takes 1190 cycles per block instead of 890 beside a partner that is in its own element-wise phase, the S^T / dP^T phase does not get
+    // faster (1150 cycles for 16 MFMAs either way), and four barriers per tile cost 2200 cycles of waiting instead of 1260.
     // absolute LDS addresses of the current stage (Q tile; Gho tile = + TILE; 32-row block qb = + qb * 8192; statistics at
     // + 2 TILE), moved from stage to stage with the loop; the wave's V block sits at a fixed address
     uint32_t arm0, avw0, atr[ND32][2], ast;
@@ -763,25 +780,32 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
         for (int db = 0; db < ND32; ++db) { atr[db][0] = sbase + la.tr[db][0]; atr[db][1] = sbase + la.tr[db][1]; }
         ast = sbase + 2 * TILE + hi * 16;
     }
+#ifdef A32_TIMELINE
+    uint32_t tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_prev = (uint32_t)__builtin_readcyclecounter();
+    const uint32_t tl_start = tl_prev;
+#endif
     int cur = 0;
     for (int qt0 = qbeg; qt0 < qend; qt0 += CT) {
         if (qt0 + CT < qend) stage(qt0 + CT, cur ^ 1);
+        A32_TS(0);                                                       // 0: loop overhead + staging issue
         sfor<0, 2>([&](auto qbc) {
             constexpr int qb = decltype(qbc)::value, QO = qb * 32 * KP, SO = qb * 128;
             const int qq0 = qt0 + qb * 32;
-            if ((causal && qq0 + 31 < kw) || qq0 >= S) return;          // every query of the block precedes every key of the wave
+            bool live = !((causal && qq0 + 31 < kw) || qq0 >= S);       // false: every query of the block precedes every key of the wave
             bool iv_mask = false;
-            if (rlo_b != nullptr) {
+            if (live && rlo_b != nullptr) {
                 int t0_, t1_, t2_, t3_;
                 iv_row(ivtab, qq0 >> 5, t0_, t1_, t2_, t3_);
-                if (t1_ <= kw || t0_ >= kw + 32) return;                 // no query of the block sees a key of this wave
+                if (t1_ <= kw || t0_ >= kw + 32) live = false;           // no query of the block sees a key of this wave
                 iv_mask = !(t2_ <= kw && t3_ >= kw + 32);                // some row's interval ends inside the wave's keys
             }
-            // ---- S^T (8 steps x Q fragment), then dP^T (8 steps x {Gho fragment, V fragment}), read one step ahead; the two
-            // contractions run one after the other so that only 16 fragment registers are in flight (register budget)
+            if (!live) return;
+            // ---- S^T and dP^T
             f32x16 st = zero16(), dp = zero16();
-            bf16x8 fq[2], fg[2], fv[2];
             f32x4 sl[2], sd[2];                                         // lse / D of the queries 8 i + 4 hi + 0..3, double-buffered
+#if A32_DKV_P1 == 0
+            // (round 2-4 form, kept for A/B: the contractions one after the other, fragment reads ONE step = one MFMA = 32 pipe cycles ahead)
+            bf16x8 fq[2], fg[2], fv[2];
             A32_RD128(fq[0], arm0, QO);
             sfor<0, NK>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value, cu = ks & 1, nx = cu ^ 1;
@@ -809,6 +833,41 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 dp = mfma32(fg[cu], fv[cu], dp);
                 A32_FENCE();
             });
+#else
+            // round 5: S^T and dP^T step by step side by side (two independent accumulator chains: the MFMAs of a step issue back to back) with
+            // the step's three fragments -- Q, Gho, V -- read A32_DKV_P1 steps = 2 A32_DKV_P1 MFMAs = 64 A32_DKV_P1 pipe cycles ahead through a
+            // ring of A32_DKV_P1 + 1 slots.  With one MFMA of cover (32 cycles) every contraction step waited out the LDS latency: ~100+ cycles
+            // per MFMA in this phase, on BOTH waves of the SIMD at once (ISA: ds_read, s_waitcnt lgkmcnt(1), v_mfma per step).  The ring costs
+            // no registers at the kernel's peak: the transpose-read groups, P / dS operands and statistics of phase C are dead here.
+            constexpr int PD = A32_DKV_P1, RS = PD + 1;
+            bf16x8 fq[RS], fg[RS], fv[RS];
+            static_assert(PD < NK, "read-ahead deeper than the contraction");
+#define A32_P1_PRO(pk)                                                                                          \
+    if constexpr (PD > (pk)) {                                                                                  \
+        const uint32_t aq = frag_addr<(pk)>(arm0), av = frag_addr<(pk)>(avw0);                                  \
+        A32_RD128(fq[pk], aq, QO); A32_RD128(fg[pk], aq, QO + TILE); A32_RD128(fv[pk], av, 0);                  \
+    }
+            A32_P1_PRO(0) A32_P1_PRO(1) A32_P1_PRO(2) A32_P1_PRO(3)
+#undef A32_P1_PRO
+            sfor<0, NK>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cu = ks % RS, nx = (ks + PD) % RS;
+                // reads younger than step ks's at the wait: the steps ks + 1 .. min(ks + PD, NK - 1) (3 each) and, from step NK - 2 on, the
+                // first pair of statistics (2)
+                constexpr int ahead = (ks + PD < NK ? PD : NK - 1 - ks);
+                if constexpr (ks + PD < NK) {
+                    const uint32_t aq = frag_addr<ks + PD>(arm0), av = frag_addr<ks + PD>(avw0);
+                    A32_RD128(fq[nx], aq, QO); A32_RD128(fg[nx], aq, QO + TILE); A32_RD128(fv[nx], av, 0);
+                }
+                if constexpr (ks == NK - 2) { A32_RD128(sl[0], ast, SO); A32_RD128(sd[0], ast, SO + 256); }
+                constexpr int nw = 3 * ahead + (ks >= NK - 2 ? 2 : 0);
+                static_assert(nw <= 14, "lgkmcnt is a 4-bit counter");
+                asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fq[cu]), "+v"(fg[cu]), "+v"(fv[cu]) : [n] "n"(nw));
+                st = mfma32(fq[cu], kf[ks], st);
+                dp = mfma32(fg[cu], fv[cu], dp);
+                A32_FENCE();
+            });
+#endif
+            A32_TS(1);                                                   // 1: S^T / dP^T phase
             // ---- element-wise work and the dV / dK contractions, one 16-query group j at a time:
             //   B(j): P and dS of the group's 8 accumulator registers (statistics double-buffered, one read pair ahead);
             //   C(j): dV^T += Gho^T P^T, dK^T += Q^T dS^T over the four head-dim blocks, transpose-read group g = (j, db)
@@ -847,6 +906,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 } else {
                     A32_WAIT(0, "+v"(sl[cu]), "+v"(sd[cu]), A32_TIE(0));
                 }
+#if A32_DKV_EW == 0
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * i + e;
@@ -855,12 +915,34 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                     if (masked) {
                         const int qi = qq0 + 8 * i + 4 * hi + e;
                         int ivlo = 0, ivhi = S;
-                        if (rlo_b != nullptr && qi < S) { ivlo = rlo_b[qi]; ivhi = rhi_b[qi]; }
+                        if constexpr (IV) { if (rlo_b != nullptr && qi < S) { ivlo = rlo_b[qi]; ivhi = rhi_b[qi]; } }
                         p = ((qi < S) & visible(qi, ki, S, causal, window, ivlo, ivhi)) ? p : 0.f;
                     }
                     pf[i >> 1][4 * (i & 1) + e] = (bf16_t)p;
                     df[i >> 1][4 * (i & 1) + e] = (bf16_t)lrp_ds<EXPL>(s_raw, p, dp[r], sd[cu][e], scale, eps_mask, eps_qk);
                 }
+#else
+                // round 5: ONE wave-uniform branch per 4-query group instead of one per element (the per-element form compiled to 16 taken
+                // s_cbranch per 32 x 32 block on the interior fast path, each between an exp2 and its consumers)
+                float pe[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pe[e] = fast_exp2(__builtin_fmaf(st[4 * i + e], c1, -(sl[cu][e] * LRP_LOG2E)));
+                if (masked) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qi = qq0 + 8 * i + 4 * hi + e;
+                        int ivlo = 0, ivhi = S;
+                        if constexpr (IV) { if (rlo_b != nullptr && qi < S) { ivlo = rlo_b[qi]; ivhi = rhi_b[qi]; } }
+                        pe[e] = ((qi < S) & visible(qi, ki, S, causal, window, ivlo, ivhi)) ? pe[e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * i + e;
+                    pf[i >> 1][4 * (i & 1) + e] = (bf16_t)pe[e];
+                    df[i >> 1][4 * (i & 1) + e] = (bf16_t)lrp_ds<EXPL>(st[r], pe[e], dp[r], sd[cu][e], scale, eps_mask, eps_qk);
+                }
+#endif
                 A32_FENCE();
             };
             // group g = (j, db) = (g / ND32, g % ND32) uses register slot g & 1; its reads are issued one group ahead
@@ -869,6 +951,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             elementwise(IC<0>{});
             elementwise(IC<1>{});
             if constexpr (ND32 == 4) {
+                A32_TS(2);                                              // 2: element-wise
                 A32_TRG(1, 0, 1);
                 A32_DKV_STEP(0, (void)0);
                 A32_TRG(0, 0, 2);
@@ -877,8 +960,10 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 A32_DKV_STEP(2, A32_WAIT(4, A32_TIE(0)));
                 A32_TRG(0, 1, 0);                                       // g = 4: in flight under B(1)
                 A32_DKV_STEP(3, A32_WAIT(4, A32_TIE(1)));
+                A32_TS(3);                                              // 3: dV / dK contractions
                 elementwise(IC<2>{});
                 elementwise(IC<3>{});
+                A32_TS(2);
                 A32_TRG(1, 1, 1);
                 A32_DKV_STEP(4, (void)0);
                 A32_TRG(0, 1, 2);
@@ -886,6 +971,7 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
                 A32_TRG(1, 1, 3);
                 A32_DKV_STEP(6, A32_WAIT(4, A32_TIE(0)));
                 A32_DKV_STEP(7, A32_WAIT(0, A32_TIE(1)));
+                A32_TS(3);
             } else if constexpr (ND32 == 3) {
                 A32_TRG(1, 0, 1);
                 A32_DKV_STEP(0, (void)0);
@@ -916,7 +1002,9 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
 #undef A32_TRG
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next tile has landed (this wave's pieces)
+        A32_TS(4);                                                       // 4: wait for the next tile
         __syncthreads();
+        A32_TS(5);                                                       // 5: barrier
         {
             const uint32_t delta = cur ? (uint32_t)-STAGE : (uint32_t)STAGE;
             arm0 += delta;
@@ -928,6 +1016,16 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     }
     store_rows<DH>(dk + (int64_t)b * S * lddk + (int64_t)h * DH, lddk, ki, S, dkacc, EXPL ? 1.f : 0.5f * scale, hi);
     store_rows<DH>(dv + (int64_t)b * S * lddv + (int64_t)h * DH, lddv, ki, S, dvacc, 1.f, hi);
+#ifdef A32_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && kw < S) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(dk + ((int64_t)b * S + kw) * lddk + (int64_t)h * DH);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = tl_acc[i];
+        w[6] = (uint32_t)__builtin_readcyclecounter() - tl_start;
+        w[7] = (uint32_t)((qend - qbeg + CT - 1) / CT);
+    }
+#endif
 }
 
 
@@ -1635,15 +1733,19 @@ int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho,
     if (lds > A32_LDS_MAX) return LRP_ESHAPE;
     dim3 grid(xcd_group_grid(B * Hq, (S + 255) / 256));
     const bool expl = eps_mask != 0.f || eps_qk != 0.f;
-#define A32_LAUNCH_DKV(EX)                                                                                                             \
+#define A32_LAUNCH_DKV(EX, IVF)                                                                                                        \
     {                                                                                                                                   \
-        auto kern = dkv_kernel<EX, DH>;                                                                                                 \
+        auto kern = dkv_kernel<EX, DH, IVF>;                                                                                            \
         LRP_SET_MAX_LDS(kern, A32_LDS_MAX);                                                                                             \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho,   \
                            lse, D_, (bf16_t*)dk, (bf16_t*)dv, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddk, lddv, scale, eps_mask, eps_qk,     \
                            causal, window, B, q_begin, row_lo, row_hi);                                                                \
     }
-    A32_FOR_DH(d, { if (expl) A32_LAUNCH_DKV(true) else A32_LAUNCH_DKV(false) })
+    const bool iv = row_lo != nullptr;
+    A32_FOR_DH(d, {
+        if (expl) { if (iv) A32_LAUNCH_DKV(true, true) else A32_LAUNCH_DKV(true, false) }
+        else { if (iv) A32_LAUNCH_DKV(false, true) else A32_LAUNCH_DKV(false, false) }
+    })
 #undef A32_LAUNCH_DKV
     return lrp_check_launch();
 }

@@ -35,6 +35,19 @@ static inline void lrp_set_max_lds_once(std::atomic<uint64_t>& done, const void*
         lrp_set_max_lds_once(lds_done_, reinterpret_cast<const void*>(kern), (bytes));     \
     } while (0)
 
+// compute units of the current device (one query per device and process)
+static inline int lrp_num_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev & 63].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 static inline int lrp_check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_lrp_last_hip_error = (int)e; return LRP_ELAUNCH; }
@@ -146,6 +159,29 @@ template <bool FAST> LRP_DEVICE float act_apply_t(float x, int act) {
         }
     }
     return act_apply(x, act);
+}
+
+// ---- the gated-MLP backward rule on ONE (gate, up) pair, bf16 STORAGE: identity rule on act (y / (g + eps_g), 0 where g + eps_g = 0) and uniform
+// rule on the product, the up-projection's Linear stabiliser u / (u + eps_lin) folded in (ref lxt/efficient/patches.py:145-157,
+// lxt/explicit/models/llama.py:84-86,273-281).  Shared by the fused down-projection dgrad epilogue (gemm_pp.hip, EPI 2) and the stand-alone
+// lrp_gated_act_bwd / _il kernels (eltwise.hip): the two must agree bit for bit.  gmh = 0.5 * (bf16-rounded Gm); y is rounded to bf16 (what
+// the forward stored in m = y * u was formed from).  LEAN = (eps_g >= 1e-30 and eps_lin == 0), the lxt.efficient placement: g + eps_g is then
+// never a denormal (no 2^24 rescue of v_rcp_f32) and the up-projection factor is exactly 1 -- bit-identical to the general form on those
+// arguments, at 3 transcendentals + ~19 plain VALU per pair instead of 4 + ~34 (the fused epilogue was VALU-bound: ~640 instructions per 16
+// pairs and wave, 20 of the 26 us a tile's epilogue took; profiles/r05_epi2_valu.txt).
+template <bool LEAN, int ACT_CT = -1>
+LRP_DEVICE void gated_bwd_pair_bf16(float g, float u, float gmh, float eps_g, float eps_lin, int act, float& ag, float& au) {
+    const int a_ = ACT_CT >= 0 ? ACT_CT : act;
+    const float y = (float)(bf16_t)act_apply_t<true>(g, a_);
+    const float den = g + eps_g;
+    if constexpr (LEAN) {
+        const float q = y * __builtin_amdgcn_rcpf(den);
+        ag = gmh * u * ((den == 0.f) ? 0.f : q);
+        au = gmh * y;
+    } else {
+        ag = (den == 0.f) ? 0.f : gmh * u * fdiv_small_t<true>(y, den);
+        au = gmh * y * eps_ratio_t<true>(u, 1.f, eps_lin);
+    }
 }
 
 // ---- MFMA 16x16 "macro" op, identical byte geometry for both dtypes ---------------------------

@@ -214,14 +214,24 @@ __global__ void gated_bwd_kernel(const T* Gm, const T* g, const T* u, T* Ag, T* 
         gm.load(Gm + r * ldgm + c);
         a.load(g + r * ldg + cg);
         b.load(u + r * ldu + cg);
+        if constexpr (sizeof(T) == 2) {
+            // bf16 storage: the rcp / exp forms shared with the fused epilogue of gemm_pp.hip (common.hpp: gated_bwd_pair_bf16), bit for bit
+            if (eps_g >= 1e-30f && eps_lin == 0.f) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            constexpr bool FAST = sizeof(T) == 2;                      // bf16 storage: rcp / exp forms (common.hpp), as the fused epilogue
-            const float y = to_f32(from_f32<T>(act_apply_t<FAST>(a.v[k], act)));
-            const float half = 0.5f * gm.v[k];
-            const float den = a.v[k] + eps_g;
-            og.v[k] = (den == 0.f) ? 0.f : half * b.v[k] * fdiv_small_t<FAST>(y, den);
-            ou.v[k] = half * y * eps_ratio_t<FAST>(b.v[k], 1.f, eps_lin);
+                for (int k = 0; k < W; ++k) gated_bwd_pair_bf16<true>(a.v[k], b.v[k], 0.5f * gm.v[k], eps_g, eps_lin, act, og.v[k], ou.v[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) gated_bwd_pair_bf16<false>(a.v[k], b.v[k], 0.5f * gm.v[k], eps_g, eps_lin, act, og.v[k], ou.v[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float y = act_apply(a.v[k], act);
+                const float half = 0.5f * gm.v[k];
+                const float den = a.v[k] + eps_g;
+                og.v[k] = (den == 0.f) ? 0.f : half * b.v[k] * (y / den);
+                ou.v[k] = half * y * eps_ratio(b.v[k], 1.f, eps_lin);
+            }
         }
         og.store(Ag + r * ldag + cg);
         ou.store(Au + r * ldau + cg);

@@ -43,7 +43,24 @@
 // the weight is streamed exactly once and the tile count alone would leave most CUs idle (lrp_gemm_skinny, reduced by a second kernel).
 // Barriers: L | barrier | M | barrier per phase; group 1 executes ONE extra barrier up front, which puts it half a phase behind
 // for the whole kernel (and group 0 one at the very end to balance the count).
+// Round 5 -- PERSISTENT tile walk (PP_PERSIST, default on): the launch is min(tiles, CUs) workgroups; workgroup w computes the tiles w, w + grid,
+// w + 2 grid, ... (the same tile every CU got from the dispatcher before: block b runs on XCD b % 8 and the XCD remap keeps the 32 tiles a XCD
+// works on at any time a compact group).  What it buys: the K loop's prologue loads of the NEXT tile (14 LDS-DMA pieces per wave into the two
+// buffers the finished K loop no longer reads) are issued BEFORE the epilogue's stores, so their HBM / L2 latency -- paid by all 256 CUs at once
+// at every round boundary of the non-persistent launch, together with the dispatch of a fresh 512-thread, 128-KiB workgroup -- runs under the
+// store phase (and, in the fused down-projection dgrad, under its gu reads).  LDS safety: group 0 reaches that point one interval ahead of group 1,
+// which by then has finished every read of the shared B rows (B fragments are read in phase (t, 0) only) and otherwise reads only its OWN A rows,
+// which only its own waves re-stage.  vmcnt counts loads and stores in issue order on gfx9, so "the first two staging units of the new tile have
+// landed" is vmcnt(8 + stores issued since) -- the stores themselves are never waited for.
+// Measured (profiles/r05_gemm_experiments.txt): +0.8 % on the seven Llama shapes, +1.1 % on the short-K SigLIP / Gemma-3 shapes in the isolated A/B,
+// within noise in situ -- the per-tile prologue / dispatch cost the round-4 notes hoped to recover (3-15 %) is ~1 %.  A staggered first round
+// (workgroups starting up to 17 us apart to de-phase the CUs' epilogue bursts) changed nothing and was removed: the fused epilogues are bound by
+// their own VALU issue (see gated_bwd_pair_bf16 in common.hpp), not by a shared HBM burst.
 #include "common.hpp"
+
+#ifndef PP_PERSIST
+#define PP_PERSIST 1
+#endif
 
 namespace {
 
@@ -82,7 +99,7 @@ struct PPEpi {
 // SK ("skinny"): the problem has ONE row of tiles and fewer than 241 rows (the HBM-bound regime of the Linear eps-rule, M <~ 160): 16-row
 // blocks of the 256-row tile that lie past M are not multiplied -- the full tile's 2 x 256 x 256 x 64 FLOP per K tile would make a
 // 16-row problem MATRIX-pipe-bound (13.7 us per workgroup for a [14336, 4096] weight) under the 15-us weight stream it serves.
-template <typename TO, bool NN, int EPI, int ACT, bool SK = false>
+template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
@@ -95,9 +112,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const int kt0 = blockIdx.y * kt_per_split;
     const int nkt = min(kt_per_split, nkt_all - kt0);
     C += (int64_t)blockIdx.y * slab_stride;
-    int tm, tn;
-    grouped_tile(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int ntiles = tiles_m * tiles_n;
+    int tile = blockIdx.x;
+    int m0, n0;                                                        // the tile whose K loop runs / ran last (epilogue coordinates)
+    {
+        int tm, tn;
+        grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
+    }
 
     // ---- staging (buffer_load_dwordx4 .. lds, 1 KiB per wave instruction; rows / columns past the operand read as zero)
     // A (both forms): piece = 8 rows x 128 B; lane l -> row (l >> 3), LDS position (l & 7), source chunk position ^ (row & 7).  A pieces of
@@ -106,10 +128,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)M * lda * 2), 0x00020000);
     const int voA = (int)(prow * lda * 2) + ((pslot ^ prow) << 4);
     int soA[2][2];
+    auto set_soA = [&](int m0_) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) soA[a][p] = (int)((int64_t)(m0 + g * 128 + a * 64 + wc * 16 + 8 * p) * lda * 2) + kt0 * 128;
+            for (int p = 0; p < 2; ++p) soA[a][p] = (int)((int64_t)(m0_ + g * 128 + a * 64 + wc * 16 + 8 * p) * lda * 2) + kt0 * 128;
+    };
+    set_soA(m0);
     // B, NT form: piece = 8 rows of B x 128 B, rows wave*32 + 8 p (p = 0..3), same swizzle as A.
     // B, NN form: piece = 2 contraction rows x 512 B (the tile's 256 output columns), contraction rows 8 wave + 2 p + (l >> 5),
     //             LDS position (l & 31), source chunk position ^ f(row), f(row) = 2 ((row & 3) + 4 ((row >> 3) & 1)).
@@ -123,13 +148,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             const int f = 2 * ((r & 3) + 4 * (wave & 1));
             voB[pp] = (int)((lane >> 5) * ldb * 2) + (((lane & 31) ^ f) << 4);
         }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) soB[p] = (int)(((int64_t)(kt0 * PP_KT + 8 * wave + 2 * p) * ldb + n0) * 2);
     } else {
         voB[0] = voB[1] = (int)(prow * ldb * 2) + ((pslot ^ prow) << 4);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) soB[p] = (int)((int64_t)(n0 + wave * 32 + 8 * p) * ldb * 2) + kt0 * 128;
     }
+    auto set_soB = [&](int n0_) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            soB[p] = NN ? (int)(((int64_t)(kt0 * PP_KT + 8 * wave + 2 * p) * ldb + n0_) * 2) : (int)((int64_t)(n0_ + wave * 32 + 8 * p) * ldb * 2) + kt0 * 128;
+    };
+    set_soB(n0);
     const int bstep = NN ? (int)(PP_KT * ldb * 2) : 128;                // bytes per K tile along B
     char* const ldsA = smem + (g * 128 + wc * 16) * 128;               // + buf*PP_OPND + a*8192 + p*1024
     char* const ldsB = smem + 2 * PP_OPND + (NN ? wave * 8 * 512 : wave * 32 * 128);      // + buf*PP_OPND + p*1024
@@ -178,12 +205,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         }
     }
     f32x4 acc[2][4][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[4][2];                                                    // [16-row block][k-step]
     union BFrag { bf16x8 v; bf16x4 h[2]; } fb[4][2];                    // [16-column tile][k-step]; NN: two 4-row transpose reads each
 
@@ -194,9 +215,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     unsigned tl_idx = 0;
     PP_STAMP(__builtin_amdgcn_s_memtime)
 #endif
-    // ---- prologue: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
-    stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1);
+    // ---- prologue of a tile: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
+    auto issue_prologue = [&]() { stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1); };
+    issue_prologue();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // persistent walk: one iteration per tile (PP_PERSIST 0, split-K slabs and the timeline build: exactly one)
+    for (;;) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                          // the half-phase offset between the two groups
 
@@ -273,11 +303,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     uint64_t* const tl_out = (uint64_t*)bias;
     bias = nullptr;
 #endif
+    // ---- the next tile of this workgroup: its first staging units go out NOW, ahead of the epilogue's memory traffic
+    bool has_next = false;
+    const int em0 = m0, en0 = n0;                                     // the epilogue's tile
+#if PP_PERSIST && !defined(PP_TIMELINE)
+    tile += gridDim.x;
+    has_next = tile < ntiles;
+    if (has_next) {
+        int tm, tn;
+        grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
+        set_soA(m0);
+        set_soB(n0);
+        issue_prologue();
+    }
+#endif
 
     // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
-    const int mrow = m0 + g * 128 + (lane & 15);
-    const int ncol = n0 + wc * 64;
-    bool full = (m0 + 256 <= M) && (n0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const int mrow = em0 + g * 128 + (lane & 15);
+    const int ncol = en0 + wc * 64;
+    bool full = (em0 + 256 <= M) && (en0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     if constexpr (EPI == 1) full = full && ((ep.ldc2 & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.c2) & 15) == 0);
     if constexpr (EPI == 2) full = full && ((ep.ldgu & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.gu) & 15) == 0);
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
@@ -329,11 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float y = (float)(bf16_t)act_apply_t<true>(gq[jj][e], ACT);
                             const float half = 0.5f * (float)(bf16_t)acc[b >> 2][b & 3][2 * q + jj][e];
-                            const float den = gq[jj][e] + ep.eps_g;
-                            ag[jj][e] = (den == 0.f) ? 0.f : half * uq[jj][e] * fdiv_small_t<true>(y, den);
-                            au[jj][e] = half * y * eps_ratio_t<true>(uq[jj][e], 1.f, ep.eps_lin);
+                            float ag_, au_;
+                            gated_bwd_pair_bf16<LEAN, ACT>(gq[jj][e], uq[jj][e], half, ep.eps_g, ep.eps_lin, ACT, ag_, au_);
+                            ag[jj][e] = ag_;
+                            au[jj][e] = au_;
                         }
                     out[2 * q] = swz(ag);
                     out[2 * q + 1] = swz(au);
@@ -407,11 +452,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                             const int ci = 16 * jj + 4 * hi + e;
                             if (gm < M && ncol + 32 * q + ci < N) {
                                 const float gq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + ci], uq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + 32 + ci];
-                                const float y = (float)(bf16_t)act_apply_t<true>(gq, ACT);
                                 const float half = 0.5f * (float)(bf16_t)v[2 * q + jj][e];
-                                const float den = gq + ep.eps_g;
-                                C[(int64_t)gm * ldc + gcol + ci] = (TO)((den == 0.f) ? 0.f : half * uq * fdiv_small_t<true>(y, den));
-                                C[(int64_t)gm * ldc + gcol + 32 + ci] = (TO)(half * y * eps_ratio_t<true>(uq, 1.f, ep.eps_lin));
+                                float ag_, au_;
+                                gated_bwd_pair_bf16<LEAN, ACT>(gq, uq, half, ep.eps_g, ep.eps_lin, ACT, ag_, au_);
+                                C[(int64_t)gm * ldc + gcol + ci] = (TO)ag_;
+                                C[(int64_t)gm * ldc + gcol + 32 + ci] = (TO)au_;
                             }
                         }
                 }
@@ -454,6 +499,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             }
         }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
+    if (!has_next) break;
+    // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
+    // retire in issue order through vmcnt on gfx9; the counter has 6 bits).  Full bf16 tiles: 16 stores per wave (+ 8 of m in the gated forward);
+    // the fused gated backward's own gu loads were issued after the pieces and waited for by the compiler, only its last stores remain;
+    // ragged tiles and fp32 output (scalar / conditional stores): drain.
+    if (full && sizeof(TO) == 2) {
+        if constexpr (EPI == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if constexpr (EPI == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // (every LDS-DMA load was waited for inside the last K tile; the C stores may still be in flight when the wave ends)
 #if defined(PP_TIMELINE) || defined(PP_TAIL_WAIT)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -482,17 +538,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false>
+template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-    dim3 grid(tiles_m * tiles_n, splits), block(512);
+    int gx = tiles_m * tiles_n;
+#if PP_PERSIST && !defined(PP_TIMELINE)
+    if (splits == 1) {
+        const int ncu = lrp_num_cus();
+        if (gx > ncu) gx = ncu;
+    }
+#endif
+    dim3 grid(gx, splits), block(512);
 #ifdef PP_TIMELINE
     const size_t lds = 4 * (size_t)PP_OPND + 4096;
 #else
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
-    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK>;
+    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
                        ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
@@ -540,7 +603,19 @@ int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* g
                                  int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st) {
     PPEpi ep{};
     ep.gu = (const bf16_t*)gu; ep.ldgu = ldgu; ep.eps_g = eps_g; ep.eps_lin = eps_lin; ep.act = act;
-    if (act == LRP_ACT_SILU) return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
-    if (act == LRP_ACT_GELU_TANH) return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+    // lxt.efficient placement (eps_g = 1e-10, no Linear stabiliser): the lean form of the rule (common.hpp: gated_bwd_pair_bf16)
+#ifdef PP_NO_LEAN
+    const bool lean = false;                                            // A/B builds
+#else
+    const bool lean = eps_g >= 1e-30f && eps_lin == 0.f;
+#endif
+    if (act == LRP_ACT_SILU) {
+        if (lean) return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU, false, true>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+        return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+    }
+    if (act == LRP_ACT_GELU_TANH) {
+        if (lean) return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH, false, true>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+        return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
+    }
     return LRP_ESHAPE;
 }

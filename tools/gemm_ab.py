@@ -140,6 +140,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--m", type=int, default=8192, help="rows (B x S)")
+    ap.add_argument("--siglip", action="store_true", help="the SigLIP-So400m tower's GEMM shapes (4 images x 4096 patches, K = 1152 / 4352) instead")
     a_ = ap.parse_args()
     print(torch.cuda.get_device_name(0), torch.version.hip, flush=True)
     libs = []
@@ -155,7 +156,11 @@ if __name__ == "__main__":
             check(fn, name)
     libs = [(n, f) for (n, f) in libs if not n.startswith("tl")]
     res = {}
-    for (M, N, K, what) in [(a_.m, n_, k_, w_) for (_, n_, k_, w_) in SHAPES]:
+    shapes = [(a_.m, n_, k_, w_) for (_, n_, k_, w_) in SHAPES]
+    if a_.siglip:
+        shapes = [(16384, 3456, 1152, "qkv fwd"), (16384, 1152, 1152, "o fwd/bwd"), (16384, 4352, 1152, "fc1 fwd"), (16384, 1152, 4352, "fc2 fwd"),
+                  (8192, 2560, 10240, "g3 down fwd"), (8192, 10240, 2560, "g3 gate fwd")]
+    for (M, N, K, what) in shapes:
         a = torch.randn(M, K, device="cuda").bfloat16()
         b = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
