@@ -84,6 +84,43 @@ def gemma3_mm():
     return 0 if worst < 1e-4 else 1
 
 
+def gemma3_mm_4bdims():
+    """the drop-in path (HF Gemma3ForConditionalGeneration under lxt_amd.efficient.monkey_patch, autograd-driven) at the released 4B dimensions
+    against the fixture captured from the REAL reference at those dimensions (tests/golden/gemma3_mm_4bdims.npz), both attention semantics"""
+    import numpy as np
+    from transformers.models.gemma3 import modeling_gemma3
+    from lxt_amd.efficient import monkey_patch
+    from tests.golden.hf_models import build_gemma3_mm_fulldims, gemma3_mm_fulldims_inputs
+    fx = load("gemma3_mm_4bdims.npz")
+    monkey_patch(modeling_gemma3)
+    ids, tt, pv = gemma3_mm_fulldims_inputs()
+    assert np.array_equal(ids.numpy(), fx["ids"])
+    rows = t(fx["rows"]).long()
+    worst = 0.0
+    for impl in ("sdpa", "eager"):
+        model = build_gemma3_mm_fulldims(attn=impl)
+        assert abs(wsum(model) - float(fx["wsum"])) < 1e-6 * abs(float(fx["wsum"])), "weights did not reproduce"
+        for p in model.parameters():
+            p.requires_grad_(False)
+        model = model.cuda()
+        e = model.get_input_embeddings()(ids.cuda()).detach().requires_grad_()
+        px = pv.cuda().clone().requires_grad_()
+        last = model(inputs_embeds=e, pixel_values=px, token_type_ids=tt.cuda(), use_cache=False).logits[0, -1]
+        idx = int(last.argmax())
+        assert idx == int(fx[f"{impl}_idx"]), (idx, int(fx[f"{impl}_idx"]))
+        last[idx].backward()
+        Rt, Rp = (e * e.grad)[0].sum(-1), (px * px.grad)[0]
+        patch = Rp.reshape(3, 64, 14, 64, 14).sum((0, 2, 4))
+        errs = [nmax(Rt, fx[f"{impl}_R_tok"]), nmax(patch, fx[f"{impl}_R_patch"]),
+                float((Rp.double().cpu()[:, rows] - t(fx[f"{impl}_R_pix_rows"]).double()).abs().max() / float(fx[f"{impl}_R_pix_absmax"]))]
+        print(f"[gemma3_mm 4B dims / {impl}, drop-in fp32 vs the REFERENCE fp64] token {errs[0]:.2e} | patch {errs[1]:.2e} | pixel rows {errs[2]:.2e}")
+        worst = max(worst, *errs)
+        del model
+        torch.cuda.empty_cache()
+    print(f"WORST {worst:.3e}")
+    return 0 if worst < 1e-4 else 1
+
+
 def mini_vit():
     """ViT from torch.nn classes under lxt_amd's vit_torch cp_LRP map (explicit patch_map: torchvision is absent) against
     the pixel relevance captured from the reference's patches; the attention runs on the HIP CP path (only dV)"""
@@ -193,6 +230,8 @@ def main(which):
         return mini_vit()
     if which == "gemma3_mm":
         return gemma3_mm()
+    if which == "gemma3_mm_4bdims":
+        return gemma3_mm_4bdims()
     if which.endswith("_padded"):
         return padded(which)
     fx = load(f"hf_{which}.npz")

@@ -74,7 +74,7 @@ def test_gemma3_text_full_model_relevance():
         assert e1 < 1e-4 and e2 < 1e-4
 
 
-@pytest.mark.parametrize("which", ["llama_cp", "qwen2", "qwen3", "gpt2", "qwen2_padded", "gemma3_mm", "mini_vit"])
+@pytest.mark.parametrize("which", ["llama_cp", "qwen2", "qwen3", "gpt2", "qwen2_padded", "gemma3_mm", "gemma3_mm_4bdims", "mini_vit"])
 def test_model_family_maps(which):
     """CP-LRP map (llama) and the qwen2 / qwen3 / gpt2 AttnLRP maps against fixtures captured from the
     reference's own maps; one fresh process per family (class-level patches are process-global)."""
