@@ -180,6 +180,30 @@ def build_mini_vit(seed=31):
     return m
 
 
+def build_llama_from_weights(cfg, W, attn="eager", dtype=torch.float32):
+    """HF LlamaForCausalLM carrying the oracle-format weights W of config cfg (oracle/llama.py: random_weights) -- the model the Llama fixtures
+    (tests/golden/llama_*.npz) were captured on, as a user of the drop-in APIs would hold it"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    hc = LlamaConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["inter"], num_hidden_layers=cfg["n_layers"],
+                     num_attention_heads=cfg["n_heads"], num_key_value_heads=cfg["n_kv"], head_dim=cfg["head_dim"], vocab_size=cfg["vocab"],
+                     rms_norm_eps=cfg["rms_eps"], max_position_embeddings=4096,
+                     rope_parameters=dict(rope_type="default", rope_theta=cfg["rope_theta"]), tie_word_embeddings=False,
+                     attn_implementation=attn)
+    model = LlamaForCausalLM(hc).eval()
+    with torch.no_grad():
+        model.model.embed_tokens.weight.copy_(W["embed"])
+        model.model.norm.weight.copy_(W["norm"])
+        model.lm_head.weight.copy_(W["lm_head"])
+        for L, Lw in zip(model.model.layers, W["layers"]):
+            L.input_layernorm.weight.copy_(Lw["ln1"]); L.post_attention_layernorm.weight.copy_(Lw["ln2"])
+            L.self_attn.q_proj.weight.copy_(Lw["wq"]); L.self_attn.k_proj.weight.copy_(Lw["wk"])
+            L.self_attn.v_proj.weight.copy_(Lw["wv"]); L.self_attn.o_proj.weight.copy_(Lw["wo"])
+            L.mlp.gate_proj.weight.copy_(Lw["wg"]); L.mlp.up_proj.weight.copy_(Lw["wu"]); L.mlp.down_proj.weight.copy_(Lw["wd"])
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    return model.to(dtype)
+
+
 def build_llama(seed=5, attn="eager"):
     from transformers import LlamaConfig, LlamaForCausalLM
     torch.manual_seed(seed)

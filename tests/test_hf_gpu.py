@@ -191,3 +191,48 @@ def test_llama_8b_dims_dropin_fp32_parity_and_bf16_like_the_reference_in_bf16():
           f"cosine {c_d:.5f} | fused engine: {n_e:.2e}, cosine {c_e:.5f}")
     assert n_d <= 3 * n_r and (1 - c_d) <= 3 * (1 - c_r)
     assert n_e <= 2e-2 and c_e >= 0.9995, (n_e, c_e)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid", "d128"])
+@pytest.mark.parametrize("impl", ["eager", "sdpa"])
+def test_llama_explicit_composite_dropin(name, impl):
+    """SURVEY 8 row a16, explicit Llama as a DROP-IN: `lxt_amd.explicit.models.llama.attnlrp.register(hf_model)` (ref
+    lxt/explicit/models/llama.py:83-93 and the splice sites :226-260,:273-281,:379-391,:481-488) on an unmodified HF LlamaForCausalLM, the explicit
+    protocol of examples/paper/llama.py:45-46, against the relevance the reference's own Functions produced on the same weights
+    (tests/golden/llama_*.npz: head dims 16 / 32 / 128, GQA 2:1 / 4:1) -- < 1e-4 (instances the reference itself resolves in fp32: cond_gap < 5e-6).
+    remove() restores the plain model; cp_lrp (ref :95-105) puts no relevance on q / k and conserves it through V."""
+    _need_gpu()
+    from tests.golden.hf_models import build_llama_from_weights
+    from tests.util import llama_case
+    from lxt_amd.explicit.models import llama as xl
+    cfg, W, ids, fx = llama_case(name)
+    model = build_llama_from_weights(cfg, W, attn=impl).cuda()
+    with torch.no_grad():
+        plain = model(input_ids=ids[None].cuda(), use_cache=False).logits[0, -1].clone()
+    xl.attnlrp.register(model)
+    try:
+        e = model.get_input_embeddings()(ids[None].cuda()).detach().requires_grad_()
+        last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+        idx = int(last.argmax())
+        assert idx == int(fx["idx"]) and abs(float(last[idx]) - float(fx["logit"])) < 1e-4 and nmax(last.detach(), plain) < 1e-5
+        last[idx].backward(last[idx].detach())
+        R = e.grad[0].sum(-1)
+    finally:
+        xl.attnlrp.remove()
+    e64, e32 = nmax(R, fx["exp64_R_tok"]), nmax(R, fx["exp32_R_tok"])
+    print(f"[explicit Llama composite on HF / {name} / {impl}] token vs reference fp64 {e64:.2e} | vs reference fp32 {e32:.2e} "
+          f"(reference's own fp32 gap {float(fx['cond_gap']):.1e}); sum R {float(R.sum()):+.6f} vs {float(t(fx['exp64_R_tok']).sum()):+.6f}")
+    assert e64 < max(1e-4, 3 * float(fx["cond_gap"]))
+    with torch.no_grad():
+        again = model(input_ids=ids[None].cuda(), use_cache=False).logits[0, -1]
+    assert torch.equal(again, plain), "remove() must restore the plain model"
+    if name == "mid" and impl == "eager":
+        xl.cp_lrp.register(model)
+        try:
+            e = model.get_input_embeddings()(ids[None].cuda()).detach().requires_grad_()
+            last = model(inputs_embeds=e, use_cache=False).logits[0, -1]
+            last[idx].backward(last[idx].detach())
+            Rcp = e.grad[0].sum(-1)
+        finally:
+            xl.cp_lrp.remove()
+        assert torch.isfinite(Rcp).all() and nmax(Rcp, R) > 1e-3          # a different rule set, a different explanation

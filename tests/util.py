@@ -58,10 +58,17 @@ def ref_case(key):
                 gap=float(c[f"{key}/gap"]), gap64=float(c[f"{key}/gap64"]))
 
 
-def ref_bar(gap, floor=1e-4):
+def ref_bar(gap, floor=1e-4, prompt_set=None):
     """explicit-mode bar of one instance: 1e-4 (BASELINE.json) wherever the reference's own fp32 resolves the instance, else 3x the reference's
-    own fp32 gap on it"""
-    return max(floor, 3.0 * gap)
+    own fp32 gap on it.  One fp32 evaluation of one instance is one draw of a heavy-tailed quantity (poles of z/(z+eps)), so where the reference's
+    own fp32 gaps over a SET of instances of the same model are on file (`prompt_set`: bert_explicit_prompts.npz -- 16 prompts through the
+    reference's explicit BERT composite, 9e-6 ... 9e-2), the bar is never below their 75th percentile (the rule of
+    test_bert_engine_explicit_fp32_vs_reference_and_oracle; the distributional claim itself is test_bert_engine_explicit_prompt_set)."""
+    bar = max(floor, 3.0 * gap)
+    if prompt_set is not None:
+        import statistics
+        bar = max(bar, statistics.quantiles(sorted(float(x) for x in load(prompt_set)["ref_fp32_gap"]), n=4)[2])
+    return bar
 
 
 # ---- cached fp64 BERT oracle ----------------------------------------------------------------------------------------------------------
