@@ -86,7 +86,7 @@ def test_function_rules_rewrite_the_traced_graph():
     assert isinstance(traced, torch.fx.GraphModule)
     out = traced(x)
     assert torch.allclose(out, ref, atol=1e-6) and calls == {"add": 1, "matmul": 2, "softmax": 1}
-    assert "replaced" in comp.function_summary["_Net"].values()
+    assert "replaced" in comp.function_summary["Root"].values()            # functions called in the root forward (ref: "Root")
     with pytest.raises(ValueError):
         Composite({torch.add: my_add}).register(_Net())                 # function rules need dummy_inputs
     comp.remove()
