@@ -68,6 +68,77 @@ class GatedActFn(Function):
         return Ag.view(shp), Au.view(shp), None
 
 
+class FusedGatedMLPFn(Function):
+    """The whole gated MLP of a decoder layer on the fused-epilogue GEMMs (bf16; the sequence lxt_amd.engine.LlamaLRP issues): gate/up GEMM over the
+    INTERLEAVED fused weight with m = act(g) (*) u formed in its epilogue, down GEMM; backward: the down-projection dgrad with the gated rule
+    (identity rule on act, uniform rule on the product: G_g = 1/2 G_m u act(g)/(g + 1e-10), G_u = 1/2 G_m act(g)) in its epilogue, then ONE gate/up
+    dgrad over the fused weight.  ref: lxt/efficient/patches.py:145-157.  Wgu: ops.interleave_gate_up(gate.weight, up.weight); Wd: down.weight or a
+    pitch-padded view of a copy (patches._fused_mlp_weights).  Long-K operands m [M, I] and Agu [M, 2 I] get a row pitch that is no multiple of
+    4 KiB (engine.pitch_pad: +5 ... 14 % on those GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, x, Wgu, Wd, act):
+        from ..engine import pitch_pad
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.stride(-1) != 1 or x2.stride(0) != x2.shape[1]:
+            x2 = x2.contiguous()
+        M, I = x2.shape[0], Wd.shape[1]
+        es = x2.element_size()
+        gu = torch.empty(M, 2 * I, device=x.device, dtype=x.dtype)
+        m = torch.empty(M, I + pitch_pad(I, es), device=x.device, dtype=x.dtype)[:, :I]
+        ops.gemm_gated_fwd(x2, Wgu, gu, m, act)
+        y = ops.linear_fwd(m, Wd, out=torch.empty(M, Wd.shape[0], device=x.device, dtype=x.dtype))
+        ctx.save_for_backward(Wgu, Wd, gu)
+        ctx.act = act
+        return y.view(*shp[:-1], Wd.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ..engine import pitch_pad
+        Wgu, Wd, gu = ctx.saved_tensors
+        shp = gy.shape
+        g2 = gy.reshape(-1, shp[-1])
+        if g2.stride(-1) != 1 or g2.stride(0) != g2.shape[1]:
+            g2 = g2.contiguous()
+        M, I2 = gu.shape
+        Agu = torch.empty(M, I2 + pitch_pad(I2, gu.element_size()), device=gu.device, dtype=gu.dtype)[:, :I2]
+        ops.gemm_gated_bwd(g2, Wd, gu, Agu, 1e-10, 0.0, ctx.act)
+        gx = ops.linear_dgrad(Agu, Wgu, out=torch.empty(M, Wgu.shape[1], device=gu.device, dtype=gu.dtype))
+        return gx.view(*shp[:-1], Wgu.shape[1]), None, None, None
+
+
+class RopeFn(Function):
+    """HF's apply_rotary_pos_emb on ONE tensor x [B, H, S, d] (a transposed view of the token-major projection output) as one launch of
+    lrp_rope_fwd, its ordinary gradient as one launch of lrp_rope_bwd (lxt.efficient leaves RoPE un-patched: constant cos / sin, plain gradient;
+    HF's eager form is ~8 element-wise ATen launches each way).  cos / sin: fp32 [B*S, d], one row per token (patches._rope_tables)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        B, H, S, d = x.shape
+        xt = x.transpose(1, 2)
+        if not xt.is_contiguous():
+            xt = xt.contiguous()
+        x2 = xt.view(B * S, H * d)
+        out = torch.empty_like(x2)
+        ops.rope_fwd(x2, out, cos, sin, B * S, H, d)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (B, H, S, d)
+        return out.view(B, S, H, d).transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        B, H, S, d = ctx.meta
+        gt = g.transpose(1, 2)
+        if not gt.is_contiguous():
+            gt = gt.contiguous()
+        g2 = gt.view(B * S, H * d)
+        A = torch.empty_like(g2)
+        ops.rope_bwd(g2, None, None, A, cos, sin, B * S, H, d, 0.0, 0.0)
+        return A.view(B, S, H, d).transpose(1, 2), None, None
+
+
 class LinearFn(Function):
     """K1 (efficient form, eps = 0): z = x W^T + b, backward G_x = G_z W -- both from the STORED weight [out, in] (ops.linear_fwd /
     ops.linear_dgrad pick the kernel by row count and dtype; bf16 never makes a W^T copy).  `weight_t` is accepted for callers of the

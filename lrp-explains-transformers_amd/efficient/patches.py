@@ -10,7 +10,7 @@ from warnings import warn
 import torch
 
 from .rules import stop_gradient, divide_gradient, identity_rule_implicit, _act_name
-from .functions import RMSNormFn, LayerNormFn, GatedActFn, LinearFn, AttentionFn
+from .functions import RMSNormFn, LayerNormFn, GatedActFn, LinearFn, AttentionFn, FusedGatedMLPFn, RopeFn
 
 
 def check_already_patched(target_fn, new_fn):
@@ -169,13 +169,97 @@ def conv2d_patch_forward(self, x):
     return y.view(B, gh, gw, self.out_channels).permute(0, 3, 1, 2)
 
 
+FUSE_MLP = True           # module attribute (no environment knob): False = three GEMMs + the element-wise rule kernel, for A/B measurements
+
+
+def _fused_mlp_weights(mlp):
+    """-> (Wgu interleaved [2 I, H], Wd [H, I]) of an ADOPTED bf16 gated MLP, built once and kept on the module (rebuilt when a weight is replaced
+    or written): the fused-epilogue GEMMs want gate and up as one operand with its rows in blocks of [32 gate | 32 up] (ops.interleave_gate_up),
+    and the long-K down weight with a row pitch that is no multiple of 4 KiB (engine.pitch_pad).  Costs a second copy of the MLP weights
+    (Llama-3-8B: 11 GB); None where the fused kernels do not apply (fp32, biases, I % 32, trainable or foreign modules)."""
+    from .. import ops
+    from ..engine import pitch_pad
+    g, u, dn = mlp.gate_proj, mlp.up_proj, mlp.down_proj
+    if not (FUSE_MLP and all(isinstance(t, torch.nn.Linear) and _owned(t) and t.bias is None and not t.weight.requires_grad for t in (g, u, dn))):
+        return None
+    wg, wu, wd = g.weight, u.weight, dn.weight
+    if not (wg.is_cuda and wg.dtype == torch.bfloat16 and wu.dtype == wd.dtype == wg.dtype and wg.shape == wu.shape and wg.shape[0] % ops.GATED_IL == 0
+            and wd.shape == (wg.shape[1], wg.shape[0])):
+        return None
+    key = tuple((t.data_ptr(), t._version) for t in (wg, wu, wd))
+    hit = mlp.__dict__.get("_lrp_fused_mlp")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        Wgu = ops.interleave_gate_up(wg.detach(), wu.detach())
+        pad = pitch_pad(wd.shape[1], wd.element_size())
+        Wd = wd.detach()
+        if pad:
+            buf = torch.empty(wd.shape[0], wd.shape[1] + pad, device=wd.device, dtype=wd.dtype)
+            Wd = buf[:, : wd.shape[1]]
+            Wd.copy_(wd)
+    mlp.__dict__["_lrp_fused_mlp"] = (key, Wgu, Wd)
+    return Wgu, Wd
+
+
 def gated_mlp_forward(self, x):
-    """identity rule on the activation, uniform rule on the product (ref: patches.py:145-157)"""
+    """identity rule on the activation, uniform rule on the product (ref: patches.py:145-157).  Adopted bf16 models: the whole MLP on the
+    fused-epilogue GEMMs (FusedGatedMLPFn: 4 launches per layer and direction instead of 3 GEMMs + the rule kernel, bit-identical rule
+    arithmetic -- tests/test_kernels_gpu.py::test_gemm_gated_fused_epilogues)"""
     act = _act_name(self.act_fn)
     if act is None:      # unknown activation: compose from the primitives
         gate = identity_rule_implicit(self.act_fn, self.gate_proj(x))
         return self.down_proj(divide_gradient(gate * self.up_proj(x), 2))
+    if x.is_cuda and x.dtype == torch.bfloat16 and act in ("silu", "gelu_tanh"):
+        fused = _fused_mlp_weights(self)
+        if fused is not None:
+            return FusedGatedMLPFn.apply(x, fused[0], fused[1], act)
     return self.down_proj(GatedActFn.apply(self.gate_proj(x), self.up_proj(x), act))
+
+
+_ROPE_TABLES = {}
+
+
+def _rope_tables(cos, sin, B, S, d):
+    """HF's cos / sin [1 or B, S, d] (model dtype) -> fp32 [B*S, d] contiguous, cached by tensor identity (one pair per forward, shared by all
+    layers; the entry keeps the source alive, at most two are held)"""
+    key = (cos.data_ptr(), sin.data_ptr(), tuple(cos.shape), cos.dtype, cos._version, B)
+    hit = _ROPE_TABLES.get(key)
+    if hit is not None:
+        return hit[0], hit[1]
+    c, s_ = (t.detach().expand(B, S, d).reshape(B * S, d).float().contiguous() for t in (cos, sin))
+    if len(_ROPE_TABLES) >= 2:
+        _ROPE_TABLES.pop(next(iter(_ROPE_TABLES)))
+    _ROPE_TABLES[key] = (c, s_, cos, sin)
+    return c, s_
+
+
+def _make_rotary(original):
+    def apply_rotary_pos_emb(q, k, cos, sin, *args, unsqueeze_dim=1, **kwargs):
+        """HF's RoPE on the HIP row kernels for the layout its decoder layers use (q / k [B, H, S, d] transposed views, cos / sin [B, S, d]);
+        anything else runs HF's own function.  Un-patched semantics (the reference leaves RoPE alone): plain gradient."""
+        ok = (not args and not kwargs and unsqueeze_dim == 1 and q.is_cuda and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3
+              and q.dtype in (torch.float32, torch.bfloat16) and k.dtype == q.dtype and cos.shape[-1] == q.shape[-1] == k.shape[-1]
+              and q.shape[-1] % 2 == 0 and cos.shape[1] == q.shape[2] == k.shape[2] and cos.shape[0] in (1, q.shape[0])
+              and not cos.requires_grad and not sin.requires_grad)
+        if not ok:
+            return original(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kwargs)
+        B, _, S, d = q.shape
+        c, s_ = _rope_tables(cos, sin, B, S, d)
+        return RopeFn.apply(q, c, s_), RopeFn.apply(k, c, s_)
+    apply_rotary_pos_emb.__wrapped__ = original
+    return apply_rotary_pos_emb
+
+
+def patch_rotary(module):
+    """replace the modeling module's apply_rotary_pos_emb (a module-level function its attention forwards look up at call time)"""
+    orig = getattr(module, "apply_rotary_pos_emb", None)
+    if orig is None:
+        return False
+    if getattr(orig, "__module__", None) == __name__:
+        return False
+    module.apply_rotary_pos_emb = _make_rotary(orig)
+    return True
 
 
 def mlp_forward(self, x):
@@ -278,6 +362,7 @@ def cp_wrap_attention_forward(forward_fn):
 
 def _patch_attention(module, cp):
     patch_ownership(module)
+    patch_rotary(module)
     new_forward = _make_attention_forward(cp)
     if hasattr(module, "eager_attention_forward"):
         if check_already_patched(module.eager_attention_forward, new_forward):

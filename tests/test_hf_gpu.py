@@ -236,3 +236,47 @@ def test_llama_explicit_composite_dropin(name, impl):
         finally:
             xl.cp_lrp.remove()
         assert torch.isfinite(Rcp).all() and nmax(Rcp, R) > 1e-3          # a different rule set, a different explanation
+
+
+def test_dropin_fused_mlp_and_hip_rope_match_the_unfused_dropin():
+    """The bf16 drop-in path of an adopted decoder runs its gated MLP on the fused-epilogue GEMMs (patches._fused_mlp_weights / FusedGatedMLPFn) and
+    HF's apply_rotary_pos_emb on the HIP RoPE kernels (patches.patch_rotary): same explanation as the un-fused drop-in (three GEMMs + rule kernel,
+    HF's eager RoPE) up to bf16 rounding of the one differently-ordered sum (gate / up dgrads), and both agree with the fp32 drop-in; fp32 never
+    takes the fused path (bit-identical to before)."""
+    _need_gpu()
+    from transformers.models.llama import modeling_llama
+    from lxt_amd.efficient import monkey_patch
+    import lxt_amd.efficient.patches as P
+    from oracle import llama as ol
+    from tests.golden.hf_models import build_llama_from_weights
+    cfg = dict(hidden=1024, inter=2816, n_layers=3, n_heads=8, n_kv=2, head_dim=128, vocab=512, rope_theta=5e5, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=77)
+    ids = torch.randint(0, 512, (2, 384), generator=torch.Generator().manual_seed(5)).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_llama)
+    hip_rope = modeling_llama.apply_rotary_pos_emb
+    assert hip_rope.__module__ == P.__name__
+
+    def run(dtype, fuse, rope):
+        model = build_llama_from_weights(cfg, W, attn="sdpa", dtype=dtype).cuda()
+        P.FUSE_MLP, modeling_llama.apply_rotary_pos_emb = fuse, (hip_rope if rope else hip_rope.__wrapped__)
+        try:
+            e = model.get_input_embeddings()(ids).detach().requires_grad_()
+            last = model(inputs_embeds=e, use_cache=False).logits[:, -1]
+            idx = last.argmax(-1)
+            last[torch.arange(2), idx].sum().backward()
+            fused_used = any("_lrp_fused_mlp" in m.__dict__ for m in model.modules())
+            return idx.cpu(), (e * e.grad).float().sum(-1).double().cpu(), fused_used
+        finally:
+            P.FUSE_MLP, modeling_llama.apply_rotary_pos_emb = True, hip_rope
+    i32, R32, f32_fused = run(torch.float32, True, True)
+    _, R32b, _ = run(torch.float32, False, False)
+    assert not f32_fused and nmax(R32, R32b) < 1e-5          # fp32: no fused MLP; the HIP RoPE is the same arithmetic as HF's eager form
+    ia, Ra, used = run(torch.bfloat16, True, True)
+    ib, Rb, unused = run(torch.bfloat16, False, False)
+    assert used and not unused and torch.equal(ia, ib)
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))   # noqa: E731
+    print(f"[drop-in bf16, fused MLP + HIP RoPE vs un-fused] nmax {nmax(Ra, Rb):.2e} cos {cos(Ra, Rb):.6f} | vs fp32 drop-in: fused {nmax(Ra, R32):.2e} "
+          f"(cos {cos(Ra, R32):.6f}), un-fused {nmax(Rb, R32):.2e} (cos {cos(Rb, R32):.6f})")
+    assert cos(Ra, Rb) > 0.999 and cos(Ra, R32) > 0.995 and nmax(Ra, R32) < 3 * max(nmax(Rb, R32), 1e-2)
