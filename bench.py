@@ -33,13 +33,16 @@ LLAMA3_8B = dict(hidden=4096, inter=14336, n_layers=32, n_heads=32, n_kv=8, head
                  rope_theta=500000.0, rms_eps=1e-5, act="silu")
 
 
-def synth_weights(cfg, device, dtype, seed=0):
+def synth_weights(cfg, device, dtype, seed=0, allocate_only=False):
     """HF-default-style random init N(0, 0.02), generated directly on the device (no checkpoint,
-    no network); same seed on every rank."""
+    no network).  allocate_only: the same tensors UNINITIALISED -- what every rank but 0 of a multi-GPU run holds before the broadcast
+    delivers rank 0's replica (nothing is synthesised twice)."""
     g = torch.Generator(device=device).manual_seed(seed)
     H, I, d, nq, nk, V = cfg["hidden"], cfg["inter"], cfg["head_dim"], cfg["n_heads"], cfg["n_kv"], cfg["vocab"]
 
     def rn(*s):
+        if allocate_only:
+            return torch.empty(*s, device=device, dtype=dtype)
         return (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * 0.02).to(dtype)
 
     W = dict(embed=rn(V, H), norm=torch.ones(H, device=device, dtype=dtype), lm_head=rn(V, H), layers=[])
@@ -50,35 +53,64 @@ def synth_weights(cfg, device, dtype, seed=0):
     return W
 
 
-def cpu_baseline(cfg, S, budget_s=30.0):
-    """time the oracle (CPU port) on ONE decoder layer + head of the same shape on all host cores and extrapolate to the full depth:
-    fp32 (the oracle's parity dtype; `value`) and bf16 (the dtype the reference's own CPU number in BASELINE.md was taken in, and the
-    GPU line's dtype; `bf16`).  Bounded: a single timed pass after one warm-up if it fits the budget."""
-    from oracle import llama as ol
-    c1 = dict(cfg, n_layers=1)
-    W = ol.random_weights(c1, seed=0)
-    ids = torch.randint(0, c1["vocab"], (S,), generator=torch.Generator().manual_seed(1234))
-    cores = torch.get_num_threads()
-
-    def one(dt, budget):
-        t0 = time.time()
-        ol.explain(c1, W, ids=ids, mode="efficient", dtype=dt)
-        t_first = time.time() - t0
-        if t_first < budget / 2:
-            t0 = time.time()
-            ol.explain(c1, W, ids=ids, mode="efficient", dtype=dt)
-            return time.time() - t0
-        return t_first
-    t32 = one(torch.float32, budget_s * 0.6)
-    out = dict(value=1.0 / (t32 * cfg["n_layers"]), unit="explanations/s", cores=cores, kind="port",
-               sample=f"oracle/llama.py, 1 of {cfg['n_layers']} decoder layers + last-token head at S={S}, fp32, "
-                      f"{t32:.2f} s measured, extrapolated x{cfg['n_layers']}")
+def pin_host(local_rank, world):
+    """One process per GPU: give every rank its own contiguous block of the host's logical CPUs and size torch's intra-op pool to it (N ranks
+    would otherwise each start a pool of ALL cores and migrate over the box while each issues ~1500 launches per explanation).  No-op for a
+    single process.  -> {"cpus": logical CPUs visible to this rank, "threads": torch.get_num_threads()}"""
     try:
-        t16 = one(torch.bfloat16, budget_s * 0.4)
-        out["bf16"] = dict(value=1.0 / (t16 * cfg["n_layers"]), unit="explanations/s",
-                           sample=f"same sample in bf16 (torch CPU bf16 matmuls), {t16:.2f} s measured, extrapolated x{cfg['n_layers']}")
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    if world > 1 and len(avail) >= world:
+        k = len(avail) // world
+        mine = avail[local_rank * k: (local_rank + 1) * k]
+        try:
+            os.sched_setaffinity(0, mine)
+        except (AttributeError, OSError):
+            mine = avail
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+        avail = mine
+    return {"cpus": len(avail), "threads": torch.get_num_threads()}
+
+
+def cpu_baseline(cfg, S, layers=4):
+    """the oracle (CPU port of the reference's op sequence: oracle/llama.py, pinned against the imported reference) timed on the host cores:
+    `layers` decoder layers + the last-token head of the same shape, forward and LRP backward timed separately, in bf16 (the GPU line's dtype and
+    the dtype of the reference's own CPU number) after a one-layer warm-up; extrapolated to the full depth (every layer costs the same).  fp32
+    (the oracle's parity dtype) on one layer beside it.  About 30 s of CPU work.  Also carried: what the REAL `lxt.efficient` measured in the
+    build container (8 vCPU, bf16) -- the reference itself does not travel to the GPU box."""
+    from oracle import llama as ol
+    L = cfg["n_layers"]
+    cL = dict(cfg, n_layers=min(layers, L))
+    W = ol.random_weights(cL, seed=0)
+    ids = torch.randint(0, cL["vocab"], (S,), generator=torch.Generator().manual_seed(1234))
+    threads = torch.get_num_threads()
+
+    def timed(c, dt):
+        Wd = ol.cast_weights(dict(W, layers=W["layers"][: c["n_layers"]]), dt)
+        t0 = time.time()
+        cache = ol.forward(c, Wd, Wd["embed"][ids])
+        t1 = time.time()
+        ol.backward(c, Wd, cache, int(cache["logits_last"].argmax()), "efficient")
+        return t1 - t0, time.time() - t1
+    out = dict(unit="explanations/s", cores=threads, host_logical_cpus=os.cpu_count(), kind="port",
+               reference_measured_in_build_container=dict(value=0.0275, unit="explanations/s", cores=8, dtype="bf16",
+                                                          what="the real lxt.efficient (monkey_patch(modeling_llama), sdpa) on the Llama-3-8B "
+                                                               "shape at S=2048, median of 3 warm runs, 8 vCPU Xeon 2.1 GHz (BASELINE.md section 2)"))
+    try:
+        timed(dict(cL, n_layers=1), torch.bfloat16)                              # warm-up
+        f, bk = timed(cL, torch.bfloat16)
+        k = L / cL["n_layers"]
+        out.update(value=1.0 / ((f + bk) * k), dtype="bf16",
+                   sample=f"oracle/llama.py, {cL['n_layers']} of {L} decoder layers + last-token head at S={S}, bf16 (torch CPU bf16 matmuls), "
+                          f"{threads} threads: forward {f:.2f} s + LRP backward {bk:.2f} s measured, extrapolated x{k:g}")
     except Exception as e:  # noqa: BLE001  (a CPU build without bf16 kernels for some op)
-        out["bf16"] = dict(value=None, note=f"bf16 oracle pass failed on this host: {type(e).__name__}")
+        out.update(value=None, note=f"bf16 oracle pass failed on this host: {type(e).__name__}")
+    f32, b32 = timed(dict(cL, n_layers=1), torch.float32)
+    out["fp32"] = dict(value=1.0 / ((f32 + b32) * L), unit="explanations/s",
+                       sample=f"1 of {L} layers + head in fp32 (the oracle's parity dtype): forward {f32:.2f} s + backward {b32:.2f} s, extrapolated x{L}")
+    if out.get("value") is None:
+        out["value"] = out["fp32"]["value"]
     return out
 
 
@@ -377,8 +409,9 @@ def dry_run(args):
     what torch.distributed.run + this script must get right before any kernel matters"""
     import lxt_amd.dist as D
     import torch.distributed as dist
-    rank, world, _ = D.init(backend="gloo")
+    rank, world, local = D.init(backend="gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    host = pin_host(local, world)
     B, S = args.batch, min(args.seq, 64)
     n_total = world * B
     ids_all = torch.randint(0, 1000, (n_total * (args.steps + args.warmup), S), generator=torch.Generator().manual_seed(1234))
@@ -406,12 +439,19 @@ def dry_run(args):
     elapsed = time.perf_counter() - t0
     last = ids_all[(args.warmup + args.steps - 1) * n_total: (args.warmup + args.steps) * n_total]
     assert R.shape == (n_total, S) and torch.equal(R, fake(last)), "gathered relevance is not in global prompt order"
+    per_rank = None
     if world > 1:
+        mine = torch.tensor([elapsed, 0.0, float(host["threads"])], dtype=torch.float64)       # the same per-rank gather as the real run
+        allr = torch.empty(world * 3, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": e / args.steps * 1e3, "host_issue_frac": h / max(e, 1e-12), "host_threads": int(t)}
+                    for r, (e, h, t) in enumerate(allr.view(-1, 3).tolist())]
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     if rank == 0:
         print(json.dumps({"metric": "explanations/sec (full AttnLRP backward) Llama-3-8B seq=2048", "value": None, "unit": "explanations/s",
+                          "host": host, "per_rank": per_rank,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "dry_run": True, "config": {"workload": "dry run: control flow only, no kernels", "global_batch": n_total,
@@ -463,6 +503,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    host = pin_host(local, world)
     # dev (a 1-GPU box): --single-rank-collectives sends the ONE-rank run through the N > 1 code path below -- an `nccl` process group of
     # world size 1, the world == 1 short cuts of lxt_amd.dist switched off: the same RCCL calls, buffers and dtypes as the 8-rank job
     coll = world > 1
@@ -475,7 +516,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = dict(LLAMA3_8B, n_layers=args.layers)
 
-    W = synth_weights(cfg, dev, dtype, seed=0)
+    W = synth_weights(cfg, dev, dtype, seed=0, allocate_only=(coll and rank != 0))
     eng = E.LlamaLRP(cfg, W, dtype=dtype, device=dev, mode=args.mode, max_seq=max(args.seq, 4096), sparse_top=not args.dense_top)
     del W
     torch.cuda.empty_cache()
@@ -495,8 +536,10 @@ def main():
         sums = D.check_replicas([eng.flat])
         D.check_gather_order(world * args.batch * args.steps, args.seq, dev)
         eng.build_transposes()
-        selfcheck = {"broadcast_bytes": eng.flat.numel() * eng.flat.element_size(), "broadcast_s": t_b, "replica_checksums_equal": True,
-                     "checksum": sums[0] & 0xFFFFFFFF, "gather_order_checked": True}
+        nbytes = eng.flat.numel() * eng.flat.element_size()
+        selfcheck = {"broadcast_bytes": nbytes, "broadcast_s": t_b, "broadcast_GBps": nbytes / max(t_b, 1e-9) / 1e9,
+                     "replica_checksums_equal": True, "checksum": sums[0] & 0xFFFFFFFF, "gather_order_checked": True,
+                     "replicas_other_than_rank0": "allocated uninitialised, zeroed, then filled by the broadcast only"}
 
     B, S = args.batch, args.seq
     n_total = world * B
@@ -521,8 +564,11 @@ def main():
     per_step = []
     done = []                                               # one marker event per step
     shards = []
+    host_issue = 0.0                                        # seconds this rank's host thread spent ISSUING (inside explain(): ~1500 launches per step)
     for i in range(args.steps):
+        t_i = time.perf_counter()
         shards.append(step(args.warmup + i))
+        host_issue += time.perf_counter() - t_i
         ev = torch.cuda.Event()
         ev.record()
         done.append(ev)
@@ -543,7 +589,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.GEMM_TIMER = None
     assert R.shape[0] == n_total * args.steps and torch.isfinite(R).all()
+    per_rank = None
     if coll:
+        # per-rank diagnostics for the first real N > 1 run: every rank's own wall time over the timed region and the share
+        # of it its host thread spent issuing launches (8 ranks share the box's host cores: the survey's predicted bottleneck)
+        mine = torch.tensor([elapsed, host_issue, float(host["threads"])], device=dev, dtype=torch.float64)
+        allr = torch.empty(dist.get_world_size() * 3, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": e / args.steps * 1e3, "host_issue_frac": h / max(e, 1e-12), "host_threads": int(t)}
+                    for r, (e, h, t) in enumerate(allr.view(-1, 3).tolist())]
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
@@ -590,8 +644,11 @@ def main():
                          "with_fused_epilogue_launches": {"launches": n_all, "TFLOPs": flops_all / secs_all / 1e12,
                                                           "frac": flops_all / secs_all / 1e12 / peak, **fused}},
         }
+        line["host"] = dict(host, host_issue_frac_of_step=host_issue / max(elapsed, 1e-12))
         if selfcheck is not None:
             line["multi_gpu_selfcheck"] = selfcheck
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if not args.no_smallm:
             line["roofline_linear_eps_smallm"] = smallm_roofline(ops, dtype, dev, cfg, B)
         if not args.no_config5 and args.layers == 32 and dtype == torch.bfloat16 and world == 1:

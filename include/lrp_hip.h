@@ -90,8 +90,9 @@ int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* 
  * MFMA's W operand is gathered by ds_read_b64_tr_b16.  splits > 1 (few column blocks, e.g. Kout = 4096) writes fp32 slabs into `ws`
  * (lrp_linear_stream_dgrad_ws BYTES, caller-allocated) that a second small kernel sums in slab order; otherwise the result is written directly.
  * z (optional, [M,N] with pitch ldz; NULL = none): the Linear's forward output -- the eps-rule's stabiliser is then formed on the fly,
- * s' = s z / (z + eps) (s = incoming gradient) or, relevance_in = 1, s / (z + eps) (s = incoming relevance), rounded to bf16 as lrp_eps_scale
- * would store it: one launch for  R/(z+eps) -> (.) W  (ref lxt/explicit/functional.py:355-358).
+ * s' = s z / (z + eps) (s = incoming gradient) or, relevance_in = 1, s / (z + eps) (s = incoming relevance), rounded to bf16 (v_rcp_f32 quotient:
+ * may differ from lrp_eps_scale's exact division in the last bf16 bit): one launch for  R/(z+eps) -> (.) W  (ref
+ * lxt/explicit/functional.py:355-358).  z with eps == 0 -> LRP_EINVAL (no stabiliser: pass z = NULL).
  * bf16 operands, out bf16 / fp32, N a multiple of 128, Kout of 64; lrp_linear_stream_dgrad_ok = 1 when the kernel applies and fills the chip.
  * ref: lxt/explicit/functional.py:355-364 (`relevance_norm @ weight`), lxt/explicit/rules.py:206-222. */
 int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds, int64_t ldw);

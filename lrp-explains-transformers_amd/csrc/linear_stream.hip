@@ -241,8 +241,10 @@ constexpr int LD_D = 4;        // tiles in flight per wave
 #define LS_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // SC: the eps-rule's stabiliser formed on the fly -- the operand is g (incoming gradient or relevance) and z (the Linear's forward output)
-// travels beside it: s = g z / (z + eps) (gradient form) or g / (z + eps) (relevance form, rel_in), rounded to bf16 like the stand-alone
-// lrp_eps_scale would store it: no separate launch, no s round trip (ref lxt/explicit/functional.py:355-358).
+// travels beside it: s = g z / (z + eps) (gradient form) or g / (z + eps) (relevance form, rel_in), rounded to bf16: no separate launch, no s
+// round trip (ref lxt/explicit/functional.py:355-358).  The quotient uses v_rcp_f32 (1 ulp of fp32, then the bf16 rounding) where the stand-alone
+// lrp_eps_scale divides exactly: the two can differ in the last bf16 bit of an element.  z with eps = 0 is refused (the factor is exactly 1: pass
+// z = NULL; with a relevance operand the value at z = 0 is undefined).
 template <typename TO, int MBMAX, bool SC>
 __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
     const bf16_t* __restrict__ sm, const bf16_t* __restrict__ zm, const bf16_t* __restrict__ W, TO* __restrict__ c, int M, int N, int Kout,
@@ -488,6 +490,7 @@ extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
 extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
                                        int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream) {
     if (!sm || !W || !c || M < 0 || N < 0 || Kout < 0) return LRP_EINVAL;
+    if (z && eps == 0.f) return LRP_EINVAL;                            // g z rcp(z) is 0 * inf at z = 0: eps = 0 means "no stabiliser", i.e. z = NULL
     if (zm && ((reinterpret_cast<uintptr_t>(zm) & 15) || (ldz % 8) || ldz < N || (int64_t)M * ldz >= (1ll << 30))) return LRP_EALIGN;
     if (M == 0 || Kout == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;

@@ -60,29 +60,47 @@ def broadcast_weights(tensors, src=0):
         dist.broadcast(t, src=src)
 
 
-def checksum(t, chunk=1 << 27):
-    """exact integer checksum of a tensor's BYTES (sum of its 16-bit words as int64, in chunks: no 4x-sized temporary for a 16-GB
-    weight buffer), reduced modulo 2^62 -> non-negative python int; equal bytes <=> equal checksum up to collisions, independent of device
-    and dtype"""
-    v = t.detach().contiguous().view(-1).view(torch.int16)
+_CK_MOD = (1 << 61) - 1
+
+
+def checksum(t, chunk=1 << 26):
+    """exact, POSITION-SENSITIVE integer checksum of a tensor's BYTES: sum over its 16-bit words w_i (taken as unsigned) of w_i * (1 + i mod 65521)
+    in int64, chunk by chunk (no 4x-sized temporary for a 16-GB weight buffer), modulo 2^61 - 1 -> non-negative python int.  A plain word sum
+    (round 4) is blind to words or whole chunks delivered in the wrong order and to offsetting errors; the index weight is not.  Tensors of an
+    odd number of bytes get a zero byte appended.  Independent of device and dtype."""
+    b = t.detach().contiguous().view(-1).view(torch.uint8)
+    if b.numel() % 2:
+        b = torch.cat([b, b.new_zeros(1)])
+    v = b.view(torch.int16)
     tot = 0
     for i in range(0, v.numel(), chunk):
-        tot += int(v[i: i + chunk].to(torch.int64).sum())
-    return tot & ((1 << 62) - 1)
+        w = v[i: i + chunk].to(torch.int64) & 0xFFFF
+        idx = (torch.arange(i, i + w.numel(), device=w.device, dtype=torch.int64) % 65521) + 1
+        tot = (tot + int((w * idx).sum())) % _CK_MOD           # < 2^16 * 2^16 * 2^26 = 2^58 per chunk: no int64 overflow
+    return tot
+
+
+def checksum_list(tensors):
+    """the tensors of a list in ORDER: each tensor's checksum enters with its position (a broadcast that filled the wrong tensor of the list
+    changes it); 0 for an empty list"""
+    tot = 0
+    for k, t in enumerate(tensors):
+        tot = (tot * 1000003 + checksum(t) + k + 1) % _CK_MOD
+    return tot
 
 
 def check_replicas(tensors):
     """after broadcast_weights: every rank's copy of `tensors` carries rank 0's bytes -- one all-gather of the per-rank checksums,
     AssertionError on every rank if any replica differs.  Returns the checksum list (one entry per rank)."""
-    if _collectives_off():
-        return [sum(checksum(t) for t in tensors)]
+    mine = checksum_list(tensors)                            # non-negative, < 2^61
+    if _collectives_off() or not tensors:
+        return [mine]
     dev = tensors[0].device
-    # (an int64 does not survive a float reduction; split into two 31-bit halves carried as int64 through all_gather)
-    mine = sum(checksum(t) for t in tensors)                 # non-negative (each term < 2^62)
-    loc = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF, (mine >> 62) & 0x7FFFFFFF], dtype=torch.int64, device=dev)
-    allc = torch.empty(dist.get_world_size() * 3, dtype=torch.int64, device=dev)
+    # (an int64 does not survive a float reduction; split into 31-bit halves carried as int64 through all_gather)
+    loc = torch.tensor([mine & 0x7FFFFFFF, (mine >> 31) & 0x7FFFFFFF], dtype=torch.int64, device=dev)
+    allc = torch.empty(dist.get_world_size() * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allc, loc)
-    sums = [int(a) | (int(b) << 31) | (int(c) << 62) for a, b, c in allc.view(-1, 3).tolist()]
+    sums = [int(a) | (int(b) << 31) for a, b in allc.view(-1, 2).tolist()]
     assert all(x == sums[0] for x in sums), f"weight replicas differ after the broadcast: per-rank checksums {sums}"
     return sums
 

@@ -250,11 +250,19 @@ class Gemma3MMLRP:
                    SiglipLRP.from_hf(model, dtype=dtype, device=device, vision_attn_rule=vision_attn_rule))
 
     @torch.no_grad()
-    def explain(self, input_ids, pixel_values, token_type_ids=None, target=None):
+    def explain(self, input_ids, pixel_values, token_type_ids=None, target=None, attention_mask=None, lengths=None):
+        """Prompts of ONE length only: this driver builds its masks from the image-token positions alone (causal text, bidirectional image blocks),
+        so a padded batch would attend to its pad tokens -- refused loudly (use one call per length, or the drop-in path
+        lxt_amd.efficient.monkey_patch(modeling_gemma3), which takes HF's padding masks).  Also unlike LlamaLRP / Gemma3LRP: no workspace arena and
+        no hipGraph capture yet -- the tower allocates its stashes per call (visible as host_issue_frac in bench.py's config4 image+text line)."""
         tx, vi = self.text, self.vision
         dev = tx.device
         ids = input_ids.to(dev)
         B, S = ids.shape
+        if lengths is not None and any(int(n) != S for n in lengths):
+            raise NotImplementedError("Gemma3MMLRP.explain: padded image + text batches are not supported (every prompt must fill the batch's sequence length)")
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
+            raise NotImplementedError("Gemma3MMLRP.explain: padded image + text batches are not supported (attention_mask has masked positions)")
         is_img = ids == self.image_token_id
         tt = is_img if token_type_ids is None else torch.as_tensor(token_type_ids).to(dev).bool()
         rows = is_img.reshape(-1).nonzero()[:, 0]                                # flat positions of the image tokens, in order

@@ -212,10 +212,17 @@ def workspace(nbytes, ref):
 
 def gemm_skinny(a, b, out, nn=False, bias=None):
     """out[M,N] = a[M,K] @ b[N,K]^T (nn=False) or a[M,K] @ b[K,N] (nn=True) for M <= 256 rows: split-K over the CUs, the weight
-    streamed exactly once; fp32 partial slabs in a stream-local workspace"""
+    streamed exactly once; fp32 partial slabs in a stream-local workspace.  The library addresses the activation through ONE 32-bit buffer
+    resource (no row chunks, unlike lrp_gemm_nt / _nn): problems with M * row pitch >= 2^30 elements (possible only on the many-row tail /
+    half-empty-chip uses of this path) are issued here in row chunks, each its own split-K problem"""
     M, K = a.shape
     N = b.shape[1] if nn else b.shape[0]
     same(a, b)
+    if M * a.stride(0) >= 2 ** 30:
+        step = max(256, ((2 ** 30 - 1) // a.stride(0)) // 256 * 256)
+        for m0 in range(0, M, step):
+            gemm_skinny(a[m0: m0 + step], b, out[m0: m0 + step], nn=nn, bias=bias)
+        return out
     ws = workspace(lib.lrp_gemm_skinny_ws(M, N, K), a)
     ev = GEMM_TIMER.span(2.0 * M * N * K, "splitk") if (GEMM_TIMER is not None and M > SKINNY_MAX) else None
     if ev:
@@ -751,6 +758,10 @@ def linear_stream_dgrad(s2, W, out=None, out_dtype=None, z=None, eps=0.0, releva
     same(s2, W, z)
     if z is not None and (z.stride(1) != 1 or tuple(z.shape) != (M, N)):
         raise ValueError("linear_stream_dgrad: z must be [M, N] with contiguous rows")
+    if z is not None and eps == 0.0:
+        if relevance_in:
+            raise ValueError("linear_stream_dgrad: a relevance operand needs eps != 0 (s / (z + 0) has no defined value at z = 0)")
+        z = None                    # eps = 0: the stabiliser z / (z + 0) is exactly 1 (lxt.efficient) -- never formed as g * z * rcp(z)
     if out is None:
         out = torch.empty(M, Kout, device=s2.device, dtype=out_dtype or s2.dtype)
     need = lib.lrp_linear_stream_dgrad_ws(M, N, Kout)

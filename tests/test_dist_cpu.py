@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo run of the prompt sharding / relevance all-gather /
+"""N>1 path on CPU: world_size-2 and -4 gloo runs of the prompt sharding / relevance all-gather /
 weight broadcast (lxt_amd.dist).  The per-prompt work is replaced by a pure function of the
 ids so the test pins exactly what the collectives must preserve: global prompt order and
 rank-sharded == single-process results."""
@@ -7,6 +7,7 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
 import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -17,9 +18,9 @@ WORKER = textwrap.dedent("""
     import lxt_amd.dist as D
     import torch.distributed as dist
     rank, world, _ = D.init(backend="gloo")
-    assert world == 2
+    assert world == int(sys.argv[1])
     g = torch.Generator().manual_seed(0)
-    ids = torch.randint(0, 1000, (7, 16), generator=g)          # 7 prompts: uneven shards (4 + 3)
+    ids = torch.randint(0, 1000, (7, 16), generator=g)          # 7 prompts: uneven shards (4 + 3 / 2 + 2 + 2 + 1)
     fake = lambda x: (x.float() * 0.5 + x.float().cumsum(1))     # stands in for engine.explain
     R = D.explain_sharded(fake, ids, batch=2)
     assert R.shape == (7, 16) and torch.equal(R, fake(ids)), "sharded != single-process"
@@ -27,13 +28,28 @@ WORKER = textwrap.dedent("""
     D.broadcast_weights(w, src=0)
     assert torch.equal(w[0], torch.full((5, 3), 1.0)) and torch.equal(w[1], torch.arange(4.0))
     lo, hi = D.shard_range(7, rank, world)
-    assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+    assert (lo, hi) == ({2: [(0, 4), (4, 7)], 4: [(0, 2), (2, 4), (4, 6), (6, 7)]}[world][rank])
+    # replica self-check: equal replicas pass; a replica whose words arrived in another ORDER (same multiset: the round-4 plain sum could not
+    # tell) fails on every rank
+    flat = torch.arange(4096, dtype=torch.float32).to(torch.bfloat16)
+    assert len(set(D.check_replicas([flat, flat[:7]]))) == 1
+    bad = flat.flip(0) if rank == world - 1 else flat
+    try:
+        D.check_replicas([bad])
+        raise SystemExit("a permuted replica went unnoticed")
+    except AssertionError:
+        pass
+    D.check_gather_order(7, 16, "cpu")
     dist.barrier()
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ok_rank%%d" %% rank), "w").write("ok")   # (stdout of two ranks interleaves)
 """) % ROOT
 
 
-def test_sharding_gloo_world2(tmp_path):
+
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharding_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     import socket
@@ -42,13 +58,13 @@ def test_sharding_gloo_world2(tmp_path):
         with socket.socket() as sk:                       # a free port: a fixed one collides with TIME_WAIT leftovers
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), str(script)]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script), str(world)]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         if r.returncode == 0 or "sharded != single-process" in (r.stdout + r.stderr):
             break                                         # success, or a REAL failure of the thing under test
     assert r.returncode == 0, r.stdout + r.stderr
-    assert (tmp_path / "ok_rank0").exists() and (tmp_path / "ok_rank1").exists(), r.stdout + r.stderr
+    assert all((tmp_path / f"ok_rank{k}").exists() for k in range(world)), r.stdout + r.stderr
 
 
 def test_shard_range_partitions():
@@ -87,5 +103,20 @@ def test_bench_launch_contract_dry_run():
                 "data", "config"):
         assert key in d
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True
+    # per-rank diagnostics of the N > 1 line: one entry per rank, each rank pinned to its own share of the host's CPUs
+    assert [e["rank"] for e in d["per_rank"]] == [0, 1] and all(e["ms_per_step"] >= 0 and e["host_threads"] >= 1 for e in d["per_rank"])
+    assert d["host"]["cpus"] >= 1
     r1 = subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--dry-run"], capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_checksum_is_position_sensitive():
+    import lxt_amd.dist as D
+    a = torch.arange(10000, dtype=torch.float32).to(torch.bfloat16)
+    assert D.checksum(a) == D.checksum(a.clone()) and D.checksum(a) != D.checksum(a.flip(0))
+    b = a.clone()
+    b[[3, 4]] = b[[4, 3]]
+    assert D.checksum(a) != D.checksum(b)                                   # two words swapped: same multiset of words
+    assert D.checksum_list([a, b]) != D.checksum_list([b, a])               # the right bytes in the wrong tensor of the list
+    assert D.check_replicas([]) == [0]
+    assert D.checksum(torch.tensor([1, 2, 3], dtype=torch.uint8)) == D.checksum(torch.tensor([1, 2, 3, 0], dtype=torch.uint8))

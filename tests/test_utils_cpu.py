@@ -74,7 +74,10 @@ def test_gemma3_config_rope_under_both_transformers_schemas():
     import torch
     from transformers import Gemma3TextConfig
     from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
-    import lxt_amd.engine_gemma3 as e
+    try:                                # the engine module loads liblrp_hip.so (a built artefact): without it this check has nothing to import
+        import lxt_amd.engine_gemma3 as e
+    except (ImportError, OSError, RuntimeError) as exc:     # _lib.LrpLibraryError is a RuntimeError
+        pytest.skip(f"liblrp_hip.so is not built here: {exc}")
     cfg = Gemma3TextConfig(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                            head_dim=32, layer_types=["sliding_attention", "full_attention"],
                            rope_parameters={"sliding_attention": {"rope_type": "default", "rope_theta": 10000.0},
