@@ -490,7 +490,7 @@ extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
 extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
                                        int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream) {
     if (!sm || !W || !c || M < 0 || N < 0 || Kout < 0) return LRP_EINVAL;
-    if (z && eps == 0.f) return LRP_EINVAL;                            // g z rcp(z) is 0 * inf at z = 0: eps = 0 means "no stabiliser", i.e. z = NULL
+    if (zm && eps == 0.f) return LRP_EINVAL;                           // g z rcp(z) is 0 * inf at z = 0: eps = 0 means "no stabiliser", i.e. z = NULL
     if (zm && ((reinterpret_cast<uintptr_t>(zm) & 15) || (ldz % 8) || ldz < N || (int64_t)M * ldz >= (1ll << 30))) return LRP_EALIGN;
     if (M == 0 || Kout == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
