@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 4 (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 5 (round 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -99,6 +99,15 @@ int lrp_linear_stream_dgrad_ok(int M, int N, int Kout, int64_t lds, int64_t ldw)
 int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout);
 int lrp_linear_stream_dgrad(const void* s, const void* z, const void* W, void* c, int M, int N, int Kout, int64_t lds, int64_t ldz,
                             int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream);
+/* lrp_linear_stream_dgrad_tk (ABI 5): the same with the contraction splits reduced INSIDE the launch -- every split's workgroup publishes its fp32
+ * partial tile into `ws` write-through and takes a ticket of its 64-column block; the last arriver sums the slabs in slab order (deterministic)
+ * and writes c.  `tickets`: lrp_linear_stream_dgrad_tickets(M, N, Kout) 32-bit words, ZERO-INITIALISED ONCE by the caller, private to one stream
+ * and never written by anything else (the last arriver of a launch re-arms its word to 0: no host-side reset, hipGraph-replayable); NULL = the
+ * two-launch form. */
+int lrp_linear_stream_dgrad_tickets(int M, int N, int Kout);
+int lrp_linear_stream_dgrad_tk(const void* s, const void* z, const void* W, void* c, int M, int N, int Kout, int64_t lds, int64_t ldz,
+                               int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* tickets,
+                               void* stream);
 
 /* lrp_gemm_skinny: the same two products with SPLIT-K, for problems whose 256 x 256 tile count alone leaves CUs idle: 1 <= M <= 256 rows
  * (the HBM-bound regime of the Linear eps-rule, SURVEY.md 8d: arithmetic

@@ -248,7 +248,8 @@ constexpr int LD_D = 4;        // tiles in flight per wave
 template <typename TO, int MBMAX, bool SC>
 __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
     const bf16_t* __restrict__ sm, const bf16_t* __restrict__ zm, const bf16_t* __restrict__ W, TO* __restrict__ c, int M, int N, int Kout,
-    int64_t lds_, int64_t ldz, int64_t ldw, int64_t ldc, int tiles_per_split, int64_t slab_stride, float eps, int rel_in) {
+    int64_t lds_, int64_t ldz, int64_t ldw, int64_t ldc, int tiles_per_split, int64_t slab_stride, float eps, int rel_in,
+    unsigned* __restrict__ tickets, void* __restrict__ fin, int64_t ldf, int fin_f32) {
     constexpr int OPS = 4 + (SC ? 2 : 1) * MBMAX;        // VMEM operations per tile and wave
     constexpr int WSLOT = 4096, SSLOT = MBMAX * 1024, SLOT = WSLOT + (SC ? 2 : 1) * SSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
     const int cb = blockIdx.x, sp = blockIdx.y;
     const int n_beg = sp * tiles_per_split * 128;
     const int nt = tiles_per_split;
+    TO* const c0 = c;                                   // slab 0 (in-kernel reduction)
     c += (int64_t)sp * slab_stride;
     int nb = (M + 15) >> 4;
     nb = nb > MBMAX ? MBMAX : nb;
@@ -392,6 +394,15 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
 #pragma unroll
             for (int w2 = 1; w2 < 4; ++w2) v += red[((w2 * MBMAX + i) * 4 + wave) * 64 + lane];
             TO* dst = c + (int64_t)m * ldc + col;
+            if constexpr (sizeof(TO) == 4) {
+                if (tickets != nullptr) {                // slab of the in-kernel reduction: agent-scope stores (write-through: visible to the last
+                    uint64_t* d8 = reinterpret_cast<uint64_t*>(dst);        // arriver's agent-scope loads whatever XCD it runs on)
+                    const f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                    __hip_atomic_store(d8, __builtin_bit_cast(uint64_t, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d8 + 1, __builtin_bit_cast(uint64_t, hi2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
+            }
             if (col + 3 < Kout && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c) & 15) == 0) {
                 if constexpr (sizeof(TO) == 4) *reinterpret_cast<f32x4*>(dst) = v;
                 else {
@@ -402,6 +413,48 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (col + e < Kout) dst[e] = from_f32<TO>(v[e]);
+            }
+        }
+    }
+    // ---- in-kernel reduction of the contraction splits (round 5; replaces the second launch: ~1.5 us of kernel boundary + 3.4-5.6 us of reduce kernel
+    // for 1-5 MB of slabs).  Every split's workgroup publishes its fp32 partial tile write-through (sc0 sc1 stores, drained), takes a ticket of
+    // its column block; the LAST arriver (ticket == splits - 1; it re-arms the word to 0 for the next launch) sums the slabs in
+    // slab order -- its own from memory as well, so the result does not depend on who arrives last -- and writes the output.  Other workgroups'
+    // slabs are read with sc0 sc1 loads: lines this workgroup's XCD never held in this launch (MI355X_MICROARCH.md: "sc0 sc1 stores and loads both
+    // sides" is a valid inter-workgroup form on non-coherent per-XCD L2s).
+    if constexpr (sizeof(TO) == 4) {
+        if (tickets != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                              // every wave's slab stores have left; `red` is no longer read
+            unsigned* tk = reinterpret_cast<unsigned*>(smem);
+            if (threadIdx.x == 0) tk[0] = __hip_atomic_fetch_add(tickets + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned nsp = gridDim.y;
+            if (tk[0] != nsp - 1) return;
+            if (threadIdx.x == 0) __hip_atomic_store(tickets + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals of this launch are in: re-arm
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i) {
+                const int m = 16 * i + i16;
+                if (i < nb && m < M) {
+                    // (compiler-visible agent-scope loads, NOT inline asm: an asm load's destination registers are unprotected until one's own
+                    // wait -- the register allocator re-used them for the next address while the load was in flight: a memory fault on the box)
+                    const float* src = reinterpret_cast<const float*>(c0) + (int64_t)m * ldc + col;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < (int)nsp) {
+                            uint64_t* s8 = reinterpret_cast<uint64_t*>(const_cast<float*>(src + (int64_t)k * slab_stride));
+                            const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const f32x2 hi2 = __builtin_bit_cast(f32x2, __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const f32x4 pk = {lo[0], lo[1], hi2[0], hi2[1]};
+                            v = (k == 0) ? pk : v + pk;
+                        }
+                    if (fin_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(fin) + (int64_t)m * ldf + col) = v;
+                    else {
+                        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(fin) + (int64_t)m * ldf + col) = o;
+                    }
+                }
             }
         }
     }
@@ -487,8 +540,9 @@ extern "C" int64_t lrp_linear_stream_dgrad_ws(int M, int N, int Kout) {
     return sp > 1 ? (int64_t)sp * M * Kout * 4 : 0;
 }
 
-extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
-                                       int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream) {
+extern "C" int lrp_linear_stream_dgrad_tk(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
+                                          int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* tickets_,
+                                          void* stream) {
     if (!sm || !W || !c || M < 0 || N < 0 || Kout < 0) return LRP_EINVAL;
     if (zm && eps == 0.f) return LRP_EINVAL;                           // g z rcp(z) is 0 * inf at z = 0: eps = 0 means "no stabiliser", i.e. z = NULL
     if (zm && ((reinterpret_cast<uintptr_t>(zm) & 15) || (ldz % 8) || ldz < N || (int64_t)M * ldz >= (1ll << 30))) return LRP_EALIGN;
@@ -504,31 +558,51 @@ extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const voi
     const size_t lds = 4 * (size_t)LD_D * (4096 + (zm ? 2 : 1) * mb * 1024);
     dim3 grid(Kout / 64, sp), block(256);
     const int64_t slab = (int64_t)M * Kout;
-#define LS_LAUNCH_DGRAD(TO, MB, OUT, LDO)                                                                                          \
+#define LS_LAUNCH_DGRAD(TO, MB, OUT, LDO, TK)                                                                                        \
     {                                                                                                                               \
         if (zm) {                                                                                                                   \
             auto kern = linear_stream_dgrad_kernel<TO, MB, true>;                                                                   \
             LRP_SET_MAX_LDS(kern, lds);                                                                                             \
             hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)zm, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, ldz, \
-                               ldw, (int64_t)(LDO), tps, slab, eps, relevance_in);                                                  \
+                               ldw, (int64_t)(LDO), tps, slab, eps, relevance_in, TK, c, ldc, (int)(out_dtype == LRP_F32));        \
         } else {                                                                                                                    \
             auto kern = linear_stream_dgrad_kernel<TO, MB, false>;                                                                  \
             LRP_SET_MAX_LDS(kern, lds);                                                                                             \
             hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)sm, (const bf16_t*)nullptr, (const bf16_t*)W, (TO*)(OUT), M, N, Kout, lds_, \
-                               (int64_t)0, ldw, (int64_t)(LDO), tps, slab, 0.f, 0);                                                 \
+                               (int64_t)0, ldw, (int64_t)(LDO), tps, slab, 0.f, 0, TK, c, ldc, (int)(out_dtype == LRP_F32));        \
         }                                                                                                                           \
     }
+    unsigned* const no_tk = nullptr;
     if (sp > 1) {
-        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, ws, Kout) else LS_LAUNCH_DGRAD(float, 4, ws, Kout)
+        // in-kernel reduction when the caller handed a ticket array (one zero-initialised 32-bit word per 64-column block, private to the stream and
+        // NEVER written by anything else: the last arriver of a launch re-arms its word) and the output takes 16- / 8-byte row segments; else fp32 slabs + reduce launch
+        unsigned* tk = reinterpret_cast<unsigned*>(tickets_);
+        const int osz = out_dtype == LRP_F32 ? 4 : 2;
+        if (tk && sp <= 8 && (ldc % 4) == 0 && (reinterpret_cast<uintptr_t>(c) % (4 * osz)) == 0) {
+            if (mb == 2) LS_LAUNCH_DGRAD(float, 2, ws, Kout, tk) else LS_LAUNCH_DGRAD(float, 4, ws, Kout, tk)
+            return lrp_check_launch();
+        }
+        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, ws, Kout, no_tk) else LS_LAUNCH_DGRAD(float, 4, ws, Kout, no_tk)
         int rc = lrp_check_launch();
         if (rc != LRP_OK) return rc;
         return lrp_launch_splitk_reduce((const float*)ws, c, M, Kout, Kout, ldc, sp, slab, out_dtype, st);
     }
     if (out_dtype == LRP_F32) {
-        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, c, ldc) else LS_LAUNCH_DGRAD(float, 4, c, ldc)
+        if (mb == 2) LS_LAUNCH_DGRAD(float, 2, c, ldc, no_tk) else LS_LAUNCH_DGRAD(float, 4, c, ldc, no_tk)
     } else {
-        if (mb == 2) LS_LAUNCH_DGRAD(bf16_t, 2, c, ldc) else LS_LAUNCH_DGRAD(bf16_t, 4, c, ldc)
+        if (mb == 2) LS_LAUNCH_DGRAD(bf16_t, 2, c, ldc, no_tk) else LS_LAUNCH_DGRAD(bf16_t, 4, c, ldc, no_tk)
     }
 #undef LS_LAUNCH_DGRAD
     return lrp_check_launch();
+}
+
+extern "C" int lrp_linear_stream_dgrad(const void* sm, const void* zm, const void* W, void* c, int M, int N, int Kout, int64_t lds_, int64_t ldz,
+                                       int64_t ldw, int64_t ldc, float eps, int relevance_in, int dtype, int out_dtype, void* ws, void* stream) {
+    return lrp_linear_stream_dgrad_tk(sm, zm, W, c, M, N, Kout, lds_, ldz, ldw, ldc, eps, relevance_in, dtype, out_dtype, ws, nullptr, stream);
+}
+
+// 32-bit ticket words lrp_linear_stream_dgrad_tk needs for the problem (0: the problem is not split, or the kernel does not apply)
+extern "C" int lrp_linear_stream_dgrad_tickets(int M, int N, int Kout) {
+    if (M < 1 || N < 1 || Kout < 64) return 0;
+    return dgrad_splits(N, Kout) > 1 ? Kout / 64 : 0;
 }

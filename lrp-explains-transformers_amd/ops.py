@@ -210,6 +210,24 @@ def workspace(nbytes, ref):
     return ws
 
 
+_TK = {}
+STREAM_DGRAD_INKERNEL_REDUCE = True      # module attribute (A/B measurements): False = fp32 slabs + the reduce launch
+
+
+def tickets(n, ref):
+    """the zero-initialised 32-bit arrival counters of the in-kernel split reduction (lrp_linear_stream_dgrad_tk): one array per (device, stream),
+    allocated once and never written by anything but that kernel (whose last arriver re-arms each word), grown by re-allocation; under hipGraph
+    capture a fresh zeroed array per call (the memset is captured with the launch)"""
+    if torch.cuda.is_current_stream_capturing():        # as ops.workspace: a fresh array in the graph's private pool, zeroed by a captured memset
+        return torch.zeros(max(int(n), 16), device=ref.device, dtype=torch.int32)
+    key = (ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+    t = _TK.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(int(n), 4096), device=ref.device, dtype=torch.int32)
+        _TK[key] = t
+    return t
+
+
 def gemm_skinny(a, b, out, nn=False, bias=None):
     """out[M,N] = a[M,K] @ b[N,K]^T (nn=False) or a[M,K] @ b[K,N] (nn=True) for M <= 256 rows: split-K over the CUs, the weight
     streamed exactly once; fp32 partial slabs in a stream-local workspace.  The library addresses the activation through ONE 32-bit buffer
@@ -766,8 +784,10 @@ def linear_stream_dgrad(s2, W, out=None, out_dtype=None, z=None, eps=0.0, releva
         out = torch.empty(M, Kout, device=s2.device, dtype=out_dtype or s2.dtype)
     need = lib.lrp_linear_stream_dgrad_ws(M, N, Kout)
     ws = workspace(need, s2) if need else None
-    check(lib.lrp_linear_stream_dgrad(p(s2), p(z), p(W), p(out), M, N, Kout, s2.stride(0), z.stride(0) if z is not None else 0, W.stride(0),
-                                      out.stride(0), eps, int(relevance_in), dt(s2), _DT[out.dtype], p(ws), stream()), "lrp_linear_stream_dgrad")
+    ntk = lib.lrp_linear_stream_dgrad_tickets(M, N, Kout) if STREAM_DGRAD_INKERNEL_REDUCE else 0
+    check(lib.lrp_linear_stream_dgrad_tk(p(s2), p(z), p(W), p(out), M, N, Kout, s2.stride(0), z.stride(0) if z is not None else 0, W.stride(0),
+                                         out.stride(0), eps, int(relevance_in), dt(s2), _DT[out.dtype], p(ws), p(tickets(ntk, s2) if ntk else None),
+                                         stream()), "lrp_linear_stream_dgrad_tk")
     return out
 
 

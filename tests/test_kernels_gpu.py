@@ -161,6 +161,18 @@ def test_linear_stream_dgrad(ops, M):
             out2 = torch.empty_like(out)
             ops.linear_stream_dgrad(s_, W, out=out2)
             assert torch.equal(out, out2)
+            # contraction splits (Kout = 4096: 4): the in-kernel last-arriver reduction (round 5) sums the fp32 slabs in slab order like the
+            # reduce launch it replaces -- same bits, whichever workgroup arrives last, call after call
+            ops.STREAM_DGRAD_INKERNEL_REDUCE = False
+            try:
+                two_launch = ops.linear_stream_dgrad(s_, W, out=torch.empty_like(out))
+            finally:
+                ops.STREAM_DGRAD_INKERNEL_REDUCE = True
+            assert torch.equal(out, two_launch)
+            for _ in range(20):
+                out2.fill_(float("nan"))
+                ops.linear_stream_dgrad(s_, W, out=out2)
+                assert torch.equal(out, out2)
         if M > 1:
             assert torch.equal(ops.linear_stream_dgrad(s_[: M - 1], W), out[: M - 1])
         if M <= 32:
