@@ -49,6 +49,17 @@ LRP_DEVICE bool xcd_group_decode(int L, int ngroups, int per_group, int& group, 
     return group < ngroups;
 }
 inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
+// the same grid walked ITEM-major within a XCD: all groups' item 0 first, then item 1, ... -- for the dK / dV kernel, whose items (key blocks of a
+// head) differ 8 : 1 in work (causal) and whose 128-KiB workgroups run ONE per CU: with the group-major order the last head's heaviest key
+// block starts when the other CUs are already draining (list-scheduling simulation of 16 heads x 8 key blocks on a XCD's 32 CUs: makespan 88 tile
+// steps against an ideal of 72; item-major -- heaviest first over ALL heads -- reaches 72).  Price: a head's key blocks no longer run at the same
+// time on one XCD, so its Q / Gho tiles are re-read from the Infinity Cache instead of the XCD's L2.
+LRP_DEVICE bool xcd_item_major_decode(int L, int ngroups, int per_group, int& group, int& item) {
+    const int xcd = L & 7, i = L >> 3, gpx = (ngroups + 7) >> 3;
+    item = i / gpx;
+    group = xcd + 8 * (i % gpx);
+    return group < ngroups;
+}
 
 // stage a [64 rows][256 B] tile of a token-major operand: 16 one-KiB groups of 4 rows, 16 / NWV per wave.
 // A32_BUFFER_STAGING (default): buffer_load_dwordx4 .. lds -- ONE per-lane byte offset (row (l >> 4) of the group, swizzled chunk; the
@@ -65,6 +76,10 @@ inline int xcd_group_grid(int ngroups, int per_group) { return ((ngroups + 7) / 
 #endif
 #ifndef A32_DKV_EW
 #define A32_DKV_EW 1
+#endif
+// A32_DKV_ORDER = 1: workgroups walk the (head, key block) grid key-block-major within a XCD (heaviest key blocks of ALL heads first)
+#ifndef A32_DKV_ORDER
+#define A32_DKV_ORDER 1
 #endif
 
 // Head dims below 128: a lane whose source chunk lies past the head (chunk >= DH / 8) gets an offset beyond num_records -- the buffer
@@ -700,7 +715,11 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bh, kblk;
+#if A32_DKV_ORDER
+    if (!xcd_item_major_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+#else
     if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+#endif
     const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
     const int k0 = kblk * BK, kw = k0 + wave * 32, ki = kw + l31;
     const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * DH;
@@ -950,6 +969,8 @@ __global__ __launch_bounds__(512, 2) void dkv_kernel(
             A32_FENCE();
             elementwise(IC<0>{});
             elementwise(IC<1>{});
+            // (Measured and not kept, round 5: the second group's element-wise work BETWEEN the first group's dV / dK steps, so that the wave's own
+            // asynchronous MFMAs run under its exp2 / dS instructions: 412 vs 410 us -- nothing.)
             if constexpr (ND32 == 4) {
                 A32_TS(2);                                              // 2: element-wise
                 A32_TRG(1, 0, 1);
@@ -1439,7 +1460,11 @@ __global__ __launch_bounds__(NW2 * 64, 1) void dkv256_kernel(
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bh, kblk;
+#if A32_DKV_ORDER
+    if (!xcd_item_major_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;       // heaviest key blocks of all heads first (see above)
+#else
     if (!xcd_group_decode(blockIdx.x, B * Hq, (S + BK - 1) / BK, bh, kblk)) return;
+#endif
     const int b = bh / Hq, h = bh % Hq, hk = h / (Hq / Hkv);
     const int k0 = kblk * BK, kw = k0 + wave * 32, ki = kw + l31;
     const bf16_t* qb_ = q + (int64_t)b * S * ldq + (int64_t)h * D2;

@@ -351,7 +351,7 @@ def test_single_rank_job_through_rccl(tmp_path):
         D.SINGLE_RANK_COLLECTIVES = True
         cfg, W, ids, fx = llama_case("mid")
         eng = E.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="efficient", max_seq=512, device="cuda:0")
-        before = D.checksum(eng.flat)
+        before = D.checksum_list([eng.flat])
         D.broadcast_weights([eng.flat], src=0)
         sums = D.check_replicas([eng.flat])
         assert sums == [before], (sums, before)
