@@ -263,17 +263,39 @@ LRP_DEVICE void load_row_frags(bf16x8* f, const bf16_t* base, int64_t ld, int ro
     }
 }
 // out^T accumulators -> token-major rows: lane (row, hi) holds head-dim columns db*32 + 8 i + 4 hi + 0..3
+// Round 5: 16-byte stores.  A row's 8-column groups are split between its two lanes (hi = 0: columns 8 i .. + 3, hi = 1: 8 i + 4 .. + 7), so the
+// natural store is 4 x 8 bytes per 32-column block and lane -- 32 store instructions per lane for dK + dV, and the store tail of a workgroup is
+// ISSUE-bound (MI355X_MICROARCH.md: ~9.3k cycles per 16 dwordx2 stores; cdna_hip_programming.md T21).  v_permlane32_swap between the packed
+// registers of groups i and i + 1 gives the lower lane columns 8 i .. 8 i + 7 and the upper lane 8 (i + 1) .. + 7: one dwordx4 store per pair.
 template <int DH>
 LRP_DEVICE void store_rows(bf16_t* base, int64_t ld, int row, int S, const f32x16* acc, float mul, int hi) {
-    if (row >= S) return;
+    const bool wide = (((reinterpret_cast<uintptr_t>(base) | (uintptr_t)(ld * 2)) & 15) == 0);        // wave-uniform (kernel arguments)
+    if (!wide) {
+        if (row >= S) return;
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[db][4 * i + e] * mul);
+                *reinterpret_cast<bf16x4*>(base + (int64_t)row * ld + db * 32 + 8 * i + 4 * hi) = v;
+            }
+        return;
+    }
+    bf16_t* const rb = base + (int64_t)row * ld + 8 * hi;               // upper lane: the second 8-column half of a pair
 #pragma unroll
     for (int db = 0; db < DH / 32; ++db)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 v;
+        for (int i = 0; i < 4; i += 2) {
+            bf16x4 va, vb;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[db][4 * i + e] * mul);
-            *reinterpret_cast<bf16x4*>(base + (int64_t)row * ld + db * 32 + 8 * i + 4 * hi) = v;
+            for (int e = 0; e < 4; ++e) { va[e] = (bf16_t)(acc[db][4 * i + e] * mul); vb[e] = (bf16_t)(acc[db][4 * (i + 1) + e] * mul); }
+            u32x2 a = __builtin_bit_cast(u32x2, va), b = __builtin_bit_cast(u32x2, vb);
+            auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);      // every lane takes part (rows >= S only skip the store)
+            auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+            const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+            if (row < S) *reinterpret_cast<u32x4*>(rb + db * 32 + 8 * i) = o;
         }
 }
 
@@ -1120,16 +1142,7 @@ LRP_DEVICE void load_row_frags2(bf16x8* f, const bf16_t* base, int64_t ld, int r
     }
 }
 LRP_DEVICE void store_rows2(bf16_t* base, int64_t ld, int row, int S, const f32x16* acc, float mul, int hi) {
-    if (row >= S) return;
-#pragma unroll
-    for (int db = 0; db < ND2; ++db)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[db][4 * i + e] * mul);
-            *reinterpret_cast<bf16x4*>(base + (int64_t)row * ld + db * 32 + 8 * i + 4 * hi) = v;
-        }
+    attn32::store_rows<D2>(base, ld, row, S, acc, mul, hi);           // the 16-byte-store form of the d <= 128 kernels (same register layout)
 }
 // one unit = the 8 transpose reads (4 head-dim blocks x 2 halves) of 16-row group J, head-dim blocks 4 DBH .. 4 DBH + 3, tile byte offset OFF
 #define A2_UNIT(dst, a0, a1, J, DBH, OFF)                                                                            \
