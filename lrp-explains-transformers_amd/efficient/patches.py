@@ -178,7 +178,7 @@ def _fused_mlp_weights(mlp):
     and the long-K down weight with a row pitch that is no multiple of 4 KiB (engine.pitch_pad).  Costs a second copy of the MLP weights
     (Llama-3-8B: 11 GB); None where the fused kernels do not apply (fp32, biases, I % 32, trainable or foreign modules)."""
     from .. import ops
-    from ..engine import pitch_pad
+    from ..engine import pitch_pad, weight_pitch_pad
     g, u, dn = mlp.gate_proj, mlp.up_proj, mlp.down_proj
     if not (FUSE_MLP and all(isinstance(t, torch.nn.Linear) and _owned(t) and t.bias is None and not t.weight.requires_grad for t in (g, u, dn))):
         return None
@@ -191,7 +191,9 @@ def _fused_mlp_weights(mlp):
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     with torch.no_grad():
-        Wgu = ops.interleave_gate_up(wg.detach(), wu.detach())
+        wpad = weight_pitch_pad(wg.shape[1], wg.element_size(), 2 * wg.shape[0])      # NN (dgrad) reads stride over the rows: pitch off the 4-KiB grid
+        Wgu = ops.interleave_gate_up(wg.detach(), wu.detach(),
+                                     out=torch.empty(2 * wg.shape[0], wg.shape[1] + wpad, device=wg.device, dtype=wg.dtype)[:, : wg.shape[1]])
         pad = pitch_pad(wd.shape[1], wd.element_size())
         Wd = wd.detach()
         if pad:
@@ -373,6 +375,11 @@ def _patch_attention(module, cp):
         for key, value in list(registry.items()):
             if check_already_patched(value, new_forward):
                 return False
+            # HF's OWN attention functions (eager / sdpa / flash / flex ...) are replaced by the HIP kernel; an entry somebody else registered
+            # under a name of their own (a user's custom attention, the tests' CPU oracle) is not ours to take over -- the registry is one
+            # process-wide object, and overriding it would reroute every other model that selects that name
+            if not str(getattr(value, "__module__", "")).startswith("transformers"):
+                continue
             registry[key] = new_forward
     return True
 

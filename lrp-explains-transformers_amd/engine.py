@@ -108,6 +108,19 @@ def pitch_pad(cols, elem_size):
     return 128 // elem_size if (nbytes >= 16384 and nbytes % 4096 == 0) else 0
 
 
+def weight_pitch_pad(cols, elem_size, rows=0):
+    """extra elements per ROW of a stored weight W [out, in] that is larger than the chip's caches: the dgrad c = s W reads it in the NN form --
+    512-byte segments of consecutive contraction ROWS, i.e. with the weight's row pitch as the stride -- and a pitch that is a multiple of 4 KiB
+    (in = 4096 in bf16) puts a column block of every row on the same memory channels.  Measured on MI355X, M = 8192 (tools/nn_pitch_probe.py,
+    profiles/r05_gemm_experiments.txt): the [28672, 4096] gate/up weight 1418 -> 1274 us with 128 bytes of padding per row, 1237 us (1357 -> 1555
+    TFLOP/s) with 256; the [6144, 4096] qkv weight 271 -> 267 us; the cache-resident [4096, 4096] o weight and the [4096, 14336] down weight:
+    nothing.  256 bytes where the pitch is a multiple of 4 KiB and the weight is at least 32 MB."""
+    nbytes = cols * elem_size
+    if not PITCH_PAD or nbytes % 4096 != 0 or rows * nbytes < (32 << 20):
+        return 0
+    return 256 // elem_size
+
+
 class LlamaLRP:
     """Device-resident weights (each ONCE, forward layout, one flat buffer) + explain()."""
 
@@ -130,7 +143,8 @@ class LlamaLRP:
         nqkv = (nq + 2 * nk) * hd
         up = lambda n: (n + 63) // 64 * 64                                   # noqa: E731  (every view starts 128-byte aligned)
         es = torch.empty(0, dtype=dtype).element_size()
-        per_layer = 2 * up(H) + up(nqkv * H) + up(H * nq * hd) + up(2 * I * H) + up(H * (I + pitch_pad(I, es)))
+        per_layer = (2 * up(H) + up(nqkv * (H + weight_pitch_pad(H, es, nqkv))) + up(H * nq * hd) + up(2 * I * (H + weight_pitch_pad(H, es, 2 * I)))
+                     + up(H * (I + pitch_pad(I, es))))
         total = 2 * up(V * H) + up(H) + len(W["layers"]) * per_layer
         self.flat = torch.empty(total, device=dev, dtype=dtype)
         cursor = [0]
@@ -146,6 +160,11 @@ class LlamaLRP:
         def take_rows(rows, cols):
             # [rows, cols] view with a row pitch that is not a multiple of 4 KiB (pitch_pad): the K-contiguous operand of a long-K GEMM
             pad = pitch_pad(cols, es)
+            return take(rows, cols + pad)[:, :cols]
+
+        def take_weight(rows, cols):
+            # stored weight whose NN (dgrad) reads stride over its rows: row pitch off the 4-KiB grid (weight_pitch_pad)
+            pad = weight_pitch_pad(cols, es, rows)
             return take(rows, cols + pad)[:, :cols]
 
         def put(dst, *srcs):
@@ -166,8 +185,8 @@ class LlamaLRP:
         self.layers = []
         for L in W["layers"]:
             self.layers.append(dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
-                                    wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
-                                    wgu=put_gu(take(2 * I, H), L["wg"], L["wu"]), wd=put(take_rows(H, I), L["wd"])))
+                                    wqkv=put(take_weight(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
+                                    wgu=put_gu(take_weight(2 * I, H), L["wg"], L["wu"]), wd=put(take_rows(H, I), L["wd"])))
         self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)

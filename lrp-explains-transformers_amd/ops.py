@@ -398,7 +398,7 @@ def interleave_gate_up(wg, wu, out=None):
         raise ValueError(f"intermediate size {I} is not a multiple of {GATED_IL}")
     if out is None:
         out = torch.empty(2 * I, H, device=wg.device, dtype=wg.dtype)
-    v = out.view(I // GATED_IL, 2, GATED_IL, H)
+    v = out.unflatten(0, (I // GATED_IL, 2, GATED_IL))          # (out may be a row-pitch-padded view: engine.weight_pitch_pad)
     v[:, 0].copy_(wg.view(I // GATED_IL, GATED_IL, H))
     v[:, 1].copy_(wu.view(I // GATED_IL, GATED_IL, H))
     return out
