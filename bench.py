@@ -492,6 +492,8 @@ def main():
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     ap.add_argument("--unfused-gated", action="store_true", help="A/B knob: gated-MLP rules as separate kernels (ops.GATED_FUSION = False)")
+    ap.add_argument("--norm-fusion-parts", default="", help="A/B knob: comma-separated subset of fwd,bwd_qkv,bwd_gu (ops.NORM_FUSION as a set)")
+    ap.add_argument("--no-norm-fusion", action="store_true", help="A/B knob: RMSNorm / residual sums as stand-alone kernels (ops.NORM_FUSION = False)")
     ap.add_argument("--no-pitch-pad", action="store_true", help="A/B knob: no row-pitch padding of the long-K GEMM operands (engine.PITCH_PAD = False)")
     ap.add_argument("--graph", action="store_true", help="replay each step as one hipGraph (LlamaLRP.explain(graph=True)); pays at small batch")
     ap.add_argument("--dry-run", action="store_true",
@@ -508,6 +510,10 @@ def main():
 
     ops.GATED_FUSION = not args.unfused_gated
     E.PITCH_PAD = not args.no_pitch_pad
+    if args.no_norm_fusion:
+        ops.NORM_FUSION = False
+    if args.norm_fusion_parts:
+        ops.NORM_FUSION = frozenset(x for x in args.norm_fusion_parts.split(",") if x)
     rank, world, local = D.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
@@ -617,7 +623,8 @@ def main():
         # dominant kernel = the plain instantiations of the ping-pong GEMM; the two launches per layer that carry a gated-MLP rule in
         # their epilogue are different kernels (other template instantiations, separate rows in the rocprof summary) and are reported
         # beside it: their duration includes the rule's own HBM traffic (gu read + Agu written: 0.94 GB per down-dgrad launch)
-        n_launch, flops, secs = timer.summary("plain")
+        n_launch, flops, secs = timer.summary(("plain", "plain_norm"))
+        n_norm, flops_norm, secs_norm = timer.summary("plain_norm")
         n_all, flops_all, secs_all = timer.summary()
         traffic, traffic_note = pmc_traffic()
         peak = 2500.0 if dtype == torch.bfloat16 else 157.3
@@ -626,7 +633,7 @@ def main():
             flops_all, secs_all, n_all = 0.0, float("nan"), 0
         achieved = flops / secs / 1e12
         fused = {}
-        for tag in ("gated_fwd", "gated_bwd", "splitk"):
+        for tag in ("gated_fwd", "gated_bwd", "splitk", "plain_norm"):
             n_t, f_t, s_t = timer.summary(tag)
             if n_t and s_t > 0.0:
                 fused[tag] = {"launches": n_t, "avg_launch_us": s_t / n_t * 1e6, "gemm_TFLOPs_incl_rule": f_t / s_t / 1e12}
@@ -642,8 +649,10 @@ def main():
                        "activation_policy": "stash: every Linear output z, q/k before and after RoPE, o, lse and the residual sums are kept in HBM "
                                             "by the forward (~0.3 GB per layer and prompt); the backward recomputes no GEMM (DESIGN.md section 3)",
                        "parallelism": f"dp{world} (prompt sharding, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<bf16, NT | NN, EPI 0> (8-wave ping-pong GEMM: Linear forward z = x W^T and "
-                                                    "eps-rule dgrad c = s W from the stored weight), 6 launches per layer",
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<bf16, NT | NN, EPI 0 | 3 | 4> (8-wave ping-pong GEMM: Linear forward z = x W^T and "
+                                                    "eps-rule dgrad c = s W from the stored weight), 6 launches per layer"
+                                                    + (f"; {n_norm} of the {n_launch} launches carry a K1n epilogue (RMSNorm's row scale / residual add / "
+                                                       "row sums of squares: +67 MB per launch)" if n_norm else ""),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches": n_launch, "avg_launch_us": secs / max(n_launch, 1) * 1e6,
                          "gemm_time_frac_of_step": secs_all / elapsed, "traffic": traffic, "traffic_note": traffic_note,

@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 5 (round 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -229,6 +229,40 @@ int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M,
 int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype);
 int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
                        int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1n  Llama-type RMSNorm FOLDED INTO THE LINEARS AROUND IT (round 5; M = B S rows, bf16, the 256 x 256 ping-pong kernel only).
+ *   ref: lxt/efficient/patches.py:111-123 (rms_norm_forward: y = w * x * rsqrt(mean x^2 + eps) with the variance DETACHED = the identity
+ *   rule, so its backward is the row scale G_x = G_y * w * rstd), HF modeling_llama's residual sums h = h + attn(..), h = h + mlp(..)
+ *   (explicit form: lf.add2, lxt/explicit/models/llama.py:481,488 -- with eps = 0 a plain sum), and the Linears of
+ *   lxt/explicit/functional.py:345-364 on both sides.
+ *   The norm's weight w is folded into the consuming Linear by the host (W' = W diag(w): (w (.) x rstd) W^T = rstd (x W'^T)), after which
+ *     forward :  h1 = h + o Wo^T            and the sums of squares of h1's rows      -> lrp_gemm_res_ssq  (+ lrp_rms_rstd: rstd from the partials)
+ *                gu = rstd (.) (h1 W'gu^T), m = act(g) (*) u                          -> lrp_gemm_gated_fwd_rs
+ *                qkv = rstd (.) (h W'qkv^T)                                           -> lrp_gemm_nt_rs
+ *     backward:  G_h = rstd (.) (A W') + G_res  (norm's identity rule + residual add) -> lrp_gemm_nn_rs_res
+ *   i.e. the stand-alone lrp_add_rmsnorm_fwd / lrp_rmsnorm_bwd_add2 launches (4 x 67 MB round trips per layer at M = 8192, H = 4096) become
+ *   16-byte residual loads and 8 row scales in the GEMM epilogues; the normalised activations are never written.
+ *   lrp_gemm_norm_fused_ok(M, N, K, lda, ldb, nn, dtype) -> 1 when the entry points take the problem (bf16, N % 256 == 0, K % 64 == 0, at
+ *   least 190 output tiles, operands within 32-bit byte offsets); they return LRP_ESHAPE otherwise (no fallback: the caller keeps the
+ *   stand-alone kernels for such shapes).
+ *   lrp_gemm_res_ssq : out[M,N] = bf16(res + x W^T), W [N,K];  ssq [N / 64][ldssq] fp32: ssq[p][m] = sum over columns 64 p .. 64 p + 63 of the
+ *                      ROUNDED out[m][.]^2  (ldssq >= M; every entry of rows < M is written)
+ *   lrp_rms_rstd     : rstd[m] = rsqrt(sum_p ssq[p][m] / H + eps)  (partials summed in order: deterministic)
+ *   lrp_gemm_nt_rs   : out[M,N] = bf16(rs[m] * (x W^T))
+ *   lrp_gemm_gated_fwd_rs : as lrp_gemm_gated_fwd with the accumulators scaled by rs[m] first (gu is the scaled product)
+ *   lrp_gemm_nn_rs_res    : out[M,N] = bf16(rs[m] * (s W) + res), W [K,N] as stored (the dgrad form of lrp_gemm_nn); out may alias res
+ * --------------------------------------------------------------------------------------- */
+int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype);
+int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx, int64_t ldw,
+                     int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream);
+int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);
+int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout,
+                   int dtype, void* stream);
+int lrp_gemm_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                          int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
+int lrp_gemm_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds, int64_t ldw,
+                       int64_t ldres, int64_t ldout, int dtype, void* stream);
 
 /* stand-alone activation identity rule (BERT/GPT-2 mlp_forward, ref: patches.py:160-168):
  * forward y = act(x); backward A = Gy * act(x)/(x+eps_g)                                  */

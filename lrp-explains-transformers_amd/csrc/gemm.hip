@@ -21,6 +21,15 @@ int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, void* gu, void*
 int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
                                  int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st);
 
+int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
+                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st);
+int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw,
+                             int64_t ldout, hipStream_t st);
+int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
+                                    int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st);
+int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
+                                 int64_t ldw, int64_t ldres, int64_t ldout, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, KB = 128;     // KB: bytes of K per stage and per row
@@ -605,3 +614,79 @@ extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* 
     return lrp_gated_act_bwd_il(ws, gu, Agu, M, I, I, ldgu, ldagu, eps_g, eps_lin, act, dtype, stream);
 }
 
+
+// =================================================================================================
+// K1n: Llama-type RMSNorm folded into the GEMMs around it (include/lrp_hip.h)
+// =================================================================================================
+namespace {
+bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+extern "C" int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype) {
+    if (dtype != LRP_BF16 || M <= 0 || N <= 0 || K <= 0 || (N % 256) || (lda % 8) || (ldb % 8)) return 0;
+    const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256);
+    return (tiles >= 190 && pp_ok(M, N, K, lda, ldb, nn)) ? 1 : 0;
+}
+
+extern "C" int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
+                                int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream) {
+    if (!x || !W || !res || !out || !ssq || M < 0 || N < 0 || K < 0 || ldssq < M) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (!lrp_gemm_norm_fused_ok(M, N, K, ldx, ldw, 0, dtype)) return LRP_ESHAPE;
+    if (!a16(x) || !a16(W) || (ldout % 8) || (ldres % 8)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(ldx);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_res_ssq((const char*)x + (int64_t)m0 * ldx * 2, W, (const char*)res + (int64_t)m0 * ldres * 2,
+                                                  (char*)out + (int64_t)m0 * ldout * 2, ssq + m0, M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw,
+                                                  ldres, ldout, ldssq, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw,
+                              int64_t ldout, int dtype, void* stream) {
+    if (!x || !W || !rs || !out || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (!lrp_gemm_norm_fused_ok(M, N, K, ldx, ldw, 0, dtype)) return LRP_ESHAPE;
+    if (!a16(x) || !a16(W) || (ldout % 8)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(ldx);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_nt_rs((const char*)x + (int64_t)m0 * ldx * 2, W, rs + m0, (char*)out + (int64_t)m0 * ldout * 2,
+                                                M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw, ldout, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
+                                     int64_t ldw, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
+    if (!x || !Wgu || !rs || !gu || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    if ((I % LRP_GATED_IL) || !lrp_gemm_norm_fused_ok(M, 2 * I, K, ldx, ldw, 0, dtype) || !gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act)) return LRP_ESHAPE;
+    if (!a16(x) || !a16(Wgu)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(ldx);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_gated_fwd_rs((const char*)x + (int64_t)m0 * ldx * 2, Wgu, rs + m0, (char*)gu + (int64_t)m0 * ldgu * 2,
+                                                       (char*)m + (int64_t)m0 * ldm * 2, M - m0 < chunk ? M - m0 : chunk, I, K, ldx, ldw, ldgu,
+                                                       ldm, act, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
+                                  int64_t ldw, int64_t ldres, int64_t ldout, int dtype, void* stream) {
+    if (!s || !W || !rs || !res || !out || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (!lrp_gemm_norm_fused_ok(M, N, K, lds_, ldw, 1, dtype)) return LRP_ESHAPE;
+    if (!a16(s) || !a16(W) || (ldout % 8) || (ldres % 8)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(lds_);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_nn_rs_res((const char*)s + (int64_t)m0 * lds_ * 2, W, rs + m0, (const char*)res + (int64_t)m0 * ldres * 2,
+                                                    (char*)out + (int64_t)m0 * ldout * 2, M - m0 < chunk ? M - m0 : chunk, N, K, lds_, ldw, ldres,
+                                                    ldout, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}

@@ -61,6 +61,9 @@
 #ifndef PP_PERSIST
 #define PP_PERSIST 1
 #endif
+#ifndef PP_EARLY_GU
+#define PP_EARLY_GU 1
+#endif
 
 namespace {
 
@@ -94,12 +97,21 @@ struct PPEpi {
     int64_t ldgu;
     float eps_g, eps_lin;
     int act;
+    // round 5, RMSNorm folded into the GEMMs around it (lrp_gemm_*_rs / _res entry points below):
+    const float* rs;       // RS: per-row scale of the accumulators (rstd of the consumer's input row), applied before everything else
+    const bf16_t* res;     // EPI 3 / 4: residual [M, N] added to the (scaled) accumulators
+    int64_t ldres;
+    float* ssq;            // EPI 3: partial sums of squares of the bf16-rounded output rows, [N / 64][ldssq] (one 64-column block per wave)
+    int64_t ldssq;
 };
 
 // SK ("skinny"): the problem has ONE row of tiles and fewer than 241 rows (the HBM-bound regime of the Linear eps-rule, M <~ 160): 16-row
 // blocks of the 256-row tile that lie past M are not multiplied -- the full tile's 2 x 256 x 256 x 64 FLOP per K tile would make a
 // 16-row problem MATRIX-pipe-bound (13.7 us per workgroup for a [14336, 4096] weight) under the 15-us weight stream it serves.
-template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false>
+// EPI 3: C = bf16(acc + res), ssq partials (the residual add + the sum of squares of RMSNorm in the producing GEMM);  EPI 4: C = bf16(rs acc + res)
+// (RMSNorm's identity-rule backward + the residual gradient in the dgrad GEMM);  RS with EPI 0 / 1: acc scaled by rs[row] first (the norm's
+// 1 / rms applied to the consumer's OUTPUT rows: (rstd x) W^T = rstd (x W^T); the norm's weight is folded into W by the host).
+template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
     int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
@@ -221,6 +233,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // persistent walk: one iteration per tile (PP_PERSIST 0, split-K slabs and the timeline build: exactly one)
     for (;;) {
+    const int em0 = m0, en0 = n0;                                     // this tile = the epilogue's tile (m0 / n0 move on to the next one after the K loop)
+    // epilogue coordinates.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
+    const int mrow = em0 + g * 128 + (lane & 15);
+    const int ncol = en0 + wc * 64;
+    bool full = (em0 + 256 <= M) && (en0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    if constexpr (EPI == 1) full = full && ((ep.ldc2 & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.c2) & 15) == 0);
+    if constexpr (EPI == 2) full = full && ((ep.ldgu & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.gu) & 15) == 0);
+    if constexpr (EPI == 3 || EPI == 4) full = full && ((ep.ldres & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.res) & 15) == 0);
+    // the epilogue's first operand loads go out NOW, a whole K loop ahead of their use: the row scales (8 registers) and, EPI 3 / 4, the residual
+    // of the first two row blocks (16 registers).  Requested at the start of the epilogue they cost their full latency per tile (~2 us, measured
+    // +29 us on the 14-tile-per-CU gate/up forward); behind the next tile's staging pieces they would not return before those have landed.
+    float rsv[8];
+    auto load_rs = [&]() {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int gm = mrow + (b >> 2) * 64 + (b & 3) * 16;
+            rsv[b] = gm < M ? ep.rs[gm] : 0.f;
+        }
+    };
+    if constexpr (RS && EPI != 4) load_rs();
+    const int epoff = 16 * (hi & 1) + 8 * (hi >> 1);
+    u32x4 rpre[4][2];                                                  // residual of row block k in rpre[k & 3]
+    auto issue_res = [&](int b, u32x4 (&d)[2]) {
+        const bf16_t* p = ep.res + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldres + ncol + epoff;
+        d[0] = *reinterpret_cast<const u32x4*>(p);
+        d[1] = *reinterpret_cast<const u32x4*>(p + 32);
+    };
+    if constexpr (EPI == 3) {
+        if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -305,7 +347,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #endif
     // ---- the next tile of this workgroup: its first staging units go out NOW, ahead of the epilogue's memory traffic
     bool has_next = false;
-    const int em0 = m0, en0 = n0;                                     // the epilogue's tile
+    // the epilogue's first operands were requested at the top of the tile (below); make them architecturally "used" HERE, ahead of the next
+    // tile's staging pieces: every load of the K loop has been waited for by now, so the compiler's own wait at this point is free, and
+    // none is left to place behind the pieces
+    if constexpr (RS && EPI != 4) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(rsv[b]));
+    }
+    if constexpr (EPI == 3) {
+        asm volatile("" : "+v"(rpre[0][0]), "+v"(rpre[0][1]), "+v"(rpre[1][0]), "+v"(rpre[1][1]));
+    }
+    // EPI 2: the gu loads of the first two row blocks, likewise ahead of the staging pieces (PP_EARLY_GU 0: behind them, the round-4 order)
+    u32x4 gpre[2][4];
+    auto issue_gu = [&](int b, u32x4 (&d)[4]) {
+        const bf16_t* p = ep.gu + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldgu + 2 * (int64_t)ncol + epoff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u32x4*>(p + 32 * k);        // q0 gate, q0 up, q1 gate, q1 up
+    };
+#if PP_EARLY_GU
+    if constexpr (EPI == 2) {
+        if (full) issue_gu(0, gpre[0]);                           // (both blocks: 32 registers more than the kernel has at this point -- spills)
+    }
+#endif
+    if constexpr (EPI == 4) {       // (NN form: no 24 registers to spare across the K loop -- requested here, ahead of the staging pieces; two tiles per CU)
+        load_rs();
+        if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
+    }
 #if PP_PERSIST && !defined(PP_TIMELINE)
     tile += gridDim.x;
     has_next = tile < ntiles;
@@ -319,12 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     }
 #endif
 
-    // ---- epilogue.  D = mfma(Bfrag, Afrag): lane l holds C[m = .. + 16 i + (l & 15)][n = .. + 16 j + 4 (l >> 4) + e] in acc[a][i][j][e]
-    const int mrow = em0 + g * 128 + (lane & 15);
-    const int ncol = en0 + wc * 64;
-    bool full = (em0 + 256 <= M) && (en0 + 256 <= N) && ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-    if constexpr (EPI == 1) full = full && ((ep.ldc2 & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.c2) & 15) == 0);
-    if constexpr (EPI == 2) full = full && ((ep.ldgu & 7) == 0) && ((reinterpret_cast<uintptr_t>(ep.gu) & 15) == 0);
+    // ---- epilogue
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     bool done = false;
     if constexpr (EPI == 2) {
@@ -335,15 +397,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         // stores, into the registers block b just released -- 8 loads in flight per wave.  (Written as one load pair per (i, q) inside
         // the generic loop below, hipcc waits vmcnt(0) after every pair: 2 KiB in flight per wave, 1.9 TB/s over the epilogue.)
         if (full) {
-            const int off = 16 * (hi & 1) + 8 * (hi >> 1);
-            const bf16_t* gsrc = ep.gu + (int64_t)mrow * ep.ldgu + 2 * (int64_t)ncol + off;
+            const int off = epoff;
             bf16_t* adst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + 2 * (int64_t)ncol + off;
-            u32x4 pre[2][4];
-            auto issue = [&](int b, u32x4 (&d)[4]) {
-                const bf16_t* p = gsrc + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ep.ldgu;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u32x4*>(p + 32 * k);        // q0 gate, q0 up, q1 gate, q1 up
-            };
+            auto& pre = gpre;
+            auto& issue = issue_gu;
             auto unswz = [&](const u32x4& o, f32x4 (&t)[2]) {
                 auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
@@ -359,7 +416,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
                 return u32x4{s0[0], s1[0], s0[1], s1[1]};
             };
+#if !PP_EARLY_GU
             issue(0, pre[0]);
+#endif
             issue(1, pre[1]);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -392,6 +451,63 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             done = true;
         }
     }
+    if constexpr (EPI == 3 || EPI == 4) {
+        // ---- residual add (+ row scale: EPI 4; + sum of squares of the rounded row: EPI 3), full tiles, pipelined like the block above but
+        // DEEPER as the accumulators drain: blocks 0, 1 were requested ahead of the K loop / the staging pieces; behind block 0's stores go the
+        // loads of blocks 2 AND 3 (into the registers block 0's accumulators and residual just released), behind block 1's those of 4 and 5,
+        // then one per block: four blocks = 8 x 16 B per lane in flight where two (the first version) left the epilogue latency-bound
+        // (4 KiB per wave in flight: +15 ... +37 us per launch for 67 MB).  The residual arrives in the STORE layout (8 consecutive
+        // columns per lane after the v_permlane16_swap pairing of column tiles 2 jj, 2 jj + 1) and is un-paired by the same swap.
+        if (full) {
+            bf16_t* cdst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + ncol + epoff;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float sq = 0.f;
+                u32x4 out[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const u32x4 o = rpre[b & 3][jj];
+                    auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+                    const bf16x2 a0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[0]), a1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[0]);
+                    const bf16x2 b0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[1]), b1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[1]);
+                    const f32x4 r0 = {(float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1]};
+                    const f32x4 r1 = {(float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
+                    f32x4 v0 = acc[b >> 2][b & 3][2 * jj], v1 = acc[b >> 2][b & 3][2 * jj + 1];
+                    if constexpr (RS) { v0 *= rsv[b]; v1 *= rsv[b]; }
+                    v0 += r0; v1 += r1;
+                    bf16x2 x0 = {(bf16_t)v0[0], (bf16_t)v0[1]}, x1 = {(bf16_t)v0[2], (bf16_t)v0[3]};
+                    bf16x2 y0 = {(bf16_t)v1[0], (bf16_t)v1[1]}, y1 = {(bf16_t)v1[2], (bf16_t)v1[3]};
+                    if constexpr (EPI == 3) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float q0 = (float)x0[e], q1 = (float)x1[e], q2 = (float)y0[e], q3 = (float)y1[e];
+                            sq += q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+                        }
+                    }
+                    auto t0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
+                    out[jj] = u32x4{t0[0], t1[0], t0[1], t1[1]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16_t* dst = cdst + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ldc;
+                *reinterpret_cast<u32x4*>(dst) = out[0];
+                *reinterpret_cast<u32x4*>(dst + 32) = out[1];
+                if constexpr (EPI == 3) {
+                    // this wave's 64 columns of row gm: the four 16-lane rows hold 16 columns each
+                    sq += __shfl_xor(sq, 16);
+                    sq += __shfl_xor(sq, 32);
+                    if (hi == 0) ep.ssq[(int64_t)(ncol >> 6) * ep.ldssq + mrow + (b >> 2) * 64 + (b & 3) * 16] = sq;
+                }
+                if (b == 0) { issue_res(2, rpre[2]); issue_res(3, rpre[3]); }
+                else if (b == 1) { issue_res(4, rpre[0]); issue_res(5, rpre[1]); }
+                else if (b == 2) issue_res(6, rpre[2]);
+                else if (b == 3) issue_res(7, rpre[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = true;
+        }
+    }
     if (!done)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -402,6 +518,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = acc[a][i][j];
+                if constexpr (RS) v[j] *= rsv[a * 4 + i];
+                if constexpr (EPI == 3 || EPI == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gn = ncol + j * 16 + 4 * hi + e;
+                        if (gm < M && gn < N) v[j][e] += to_f32(ep.res[(int64_t)gm * ep.ldres + gn]);
+                    }
+                }
                 if (bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -439,6 +563,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                             if (2 * ci < N) ep.c2[(int64_t)gm * ep.ldc2 + ci] = (bf16_t)mv[jj][e];
                         }
                 }
+            }
+            if constexpr (EPI == 3) {
+                // ragged tiles: the wave's 64-column partial of row gm (columns past N contribute nothing; rows past M are not written)
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float q = (float)(bf16_t)v[j][e];
+                        if (ncol + j * 16 + 4 * hi + e < N) sq += q * q;
+                    }
+                sq += __shfl_xor(sq, 16);
+                sq += __shfl_xor(sq, 32);
+                if (hi == 0 && gm < M && ncol < N) ep.ssq[(int64_t)(ncol >> 6) * ep.ldssq + gm] = sq;
             }
             if constexpr (EPI == 2) {
                 // ragged tiles of the gated backward rule (the full tiles took the pipelined path above): element-wise, bounds-checked
@@ -538,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false>
+template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false, bool RS = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
@@ -555,7 +693,7 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 #else
     const size_t lds = 4 * (size_t)PP_OPND;
 #endif
-    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN>;
+    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
                        ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
@@ -618,4 +756,38 @@ int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* g
         return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
     }
     return LRP_ESHAPE;
+}
+
+// ---- RMSNorm folded into the GEMMs around it (round 5; include/lrp_hip.h "K1n").  Same kernel, three more epilogue forms.
+// out = res + x W^T (NT) and the partial sums of squares of out's rows, one per 64-column block: ssq [N / 64][ldssq]
+int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
+                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st) {
+    PPEpi ep{};
+    ep.res = (const bf16_t*)res; ep.ldres = ldres; ep.ssq = ssq; ep.ldssq = ldssq;
+    return launch_pp_t<bf16_t, false, 3>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
+}
+// out = rs (.) (x W^T) (NT), rs [M] fp32
+int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw,
+                             int64_t ldout, hipStream_t st) {
+    PPEpi ep{};
+    ep.rs = rs;
+    return launch_pp_t<bf16_t, false, 0, 0, false, false, true>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
+}
+// gate/up forward on the un-normalised rows: gu = rs (.) (x Wgu^T), m = act(g) (*) u
+int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
+                                    int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st) {
+    PPEpi ep{};
+    ep.c2 = (bf16_t*)m; ep.ldc2 = ldm; ep.act = act; ep.rs = rs;
+    if (act == LRP_ACT_SILU)
+        return launch_pp_t<bf16_t, false, 1, LRP_ACT_SILU, false, false, true>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
+    if (act == LRP_ACT_GELU_TANH)
+        return launch_pp_t<bf16_t, false, 1, LRP_ACT_GELU_TANH, false, false, true>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
+    return LRP_ESHAPE;
+}
+// out = rs (.) (s W) + res (NN: W [K, N] as stored)
+int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
+                                 int64_t ldw, int64_t ldres, int64_t ldout, hipStream_t st) {
+    PPEpi ep{};
+    ep.rs = rs; ep.res = (const bf16_t*)res; ep.ldres = ldres;
+    return launch_pp_t<bf16_t, true, 4, 0, false, false, true>(s, W, out, nullptr, M, N, K, lds_, ldw, ldout, 1, K / PP_KT, 0, ep, st);
 }

@@ -431,6 +431,30 @@ extern "C" int lrp_add_rmsnorm_fwd(const void* h, const void* branch, const void
     return lrp_check_launch();
 }
 
+// K1n: rstd[m] = rsqrt(sum_p ssq[p][m] / H + eps) from the per-64-column partial sums of squares lrp_gemm_res_ssq's epilogue wrote.
+// 256 threads per 64 rows: wave q sums the partials p = q, q + 4, ... of row (lane) -- consecutive lanes read consecutive rows of a partial
+// (coalesced), every wave keeps parts / 4 independent loads in flight (one thread per row walking 64 strided partials: 24 us for 2 MB) -- and the
+// four sums meet in LDS in wave order: the same summation tree for every row, whatever M (deterministic; batch-size independent).
+__global__ __launch_bounds__(256) void rms_rstd_kernel(const float* __restrict__ ssq, int parts, int64_t ldssq, int M, float inv_h, float eps,
+                                                       float* __restrict__ rstd) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (m < M)
+        for (int p = q; p < parts; p += 4) s += ssq[(int64_t)p * ldssq + m];
+    red[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && m < M) rstd[m] = rsqrtf(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * inv_h + eps);
+}
+
+extern "C" int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream) {
+    if (!ssq || !rstd || parts < 1 || M < 0 || H < 1 || ldssq < M) return LRP_EINVAL;
+    if (M == 0) return LRP_OK;
+    hipLaunchKernelGGL(rms_rstd_kernel, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, ssq, parts, ldssq, M, 1.f / (float)H, eps, rstd);
+    return lrp_check_launch();
+}
+
 extern "C" int lrp_rmsnorm_bwd_add2(const void* Gres, const void* Gx, const void* w, const float* rstd,
                                     const void* hsum, const void* branch, void* Gs_out, void* A_out,
                                     float* rel_out, int M, int H, float w_offset, float eps_add, float eps_lin,

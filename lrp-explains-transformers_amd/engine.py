@@ -124,7 +124,7 @@ def weight_pitch_pad(cols, elem_size, rows=0):
 class LlamaLRP:
     """Device-resident weights (each ONCE, forward layout, one flat buffer) + explain()."""
 
-    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096, sparse_top=True):
+    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", mode="efficient", max_seq=4096, sparse_top=True, fold_norm=None):
         if not torch.cuda.is_available():
             raise RuntimeError("LlamaLRP needs a HIP device: the LRP kernels have no CPU fallback")
         self.cfg, self.dtype, self.device = dict(cfg), dtype, torch.device(device)
@@ -135,6 +135,12 @@ class LlamaLRP:
         self.sparse_top = bool(sparse_top)
         self.act = cfg.get("act", "silu")
         dev = self.device
+        # fold_norm (default: the bf16 engine): the weights of the two per-layer RMSNorms are multiplied into the COLUMNS of the Linears that
+        # consume them (W'qkv = Wqkv diag(w1), W'gu = Wgu diag(w2)) and replaced by ones -- the same network (w (.) x rstd) W^T = (x rstd) W'^T,
+        # and the same relevance under every rule of both placements: a contribution x_i w_ji of the eps-rule is unchanged, the norm's
+        # identity rule does not see its weight.  What it buys: the norm is then a pure row scale, which commutes with the Linear --
+        # rstd (.) (h W'^T) -- so for M = B S rows the efficient placement runs it inside the GEMM epilogues (K1n, _norm_fused below).
+        self.folded = bool(dtype == torch.bfloat16 if fold_norm is None else fold_norm)
 
         # ONE flat device buffer holds every weight in its forward layout (embedding, norms, LM head, per layer the fused
         # [q;k;v] and [gate;up] matrices, o, down): the tensors below are views into it, so the multi-GPU start-up is a
@@ -183,10 +189,25 @@ class LlamaLRP:
         self.norm = put(take(H), W["norm"])
         self.lm_head_t = None                        # [H, V] copy, made on the first dense-seed explanation
         self.layers = []
+
+        def fold(w, ln):
+            # W' = W diag(ln): product in fp32, ONE rounding to the storage dtype, block by block (no 4-byte copy of a whole weight)
+            lnf = ln.to(device=dev, dtype=torch.float32)
+            for r0 in range(0, w.shape[0], 4096):
+                blk = w[r0: r0 + 4096]
+                blk.copy_((blk.float() * lnf).to(dtype))
+            return w
+
         for L in W["layers"]:
-            self.layers.append(dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
-                                    wqkv=put(take_weight(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
-                                    wgu=put_gu(take_weight(2 * I, H), L["wg"], L["wu"]), wd=put(take_rows(H, I), L["wd"])))
+            Lw = dict(ln1=put(take(H), L["ln1"]), ln2=put(take(H), L["ln2"]),
+                      wqkv=put(take_weight(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * hd), L["wo"]),
+                      wgu=put_gu(take_weight(2 * I, H), L["wg"], L["wu"]), wd=put(take_rows(H, I), L["wd"]))
+            if self.folded:
+                fold(Lw["wqkv"], L["ln1"])
+                fold(Lw["wgu"], L["ln2"])
+                Lw["ln1"].fill_(1.0)
+                Lw["ln2"].fill_(1.0)
+            self.layers.append(Lw)
         self.attn_t = ops.attn_needs_transposed(self.embed, cfg["head_dim"])
         d = cfg["head_dim"]
         inv = cfg.get("inv_freq")                    # scaled rope types: HF's own frequencies (config_from_hf)
@@ -208,6 +229,33 @@ class LlamaLRP:
 
     def _lin_bwd(self, A, W, out):
         return ops.linear_dgrad(A, W, out=out)
+
+    def _norm_fused(self, M):
+        """K1n applies: folded norm weights, efficient placement (no stabiliser on the residual add / the Linears: eps = 0), and every GEMM on
+        both sides of the two norms is a problem the ping-pong kernel's fused epilogues take (bf16, >= 190 tiles, N % 256 == 0)"""
+        if not (self.folded and self.mode == "efficient" and ops.NORM_FUSION):
+            return False
+        key = ("nf", M)
+        hit = self._nf_cache.get(key) if hasattr(self, "_nf_cache") else None
+        if hit is None:
+            c = self.cfg
+            H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
+            nqkv = (nq + 2 * nk) * d
+            L0 = self.layers[0] if self.layers else None
+            ok = L0 is not None
+            if ok:
+                ldm = I + pitch_pad(I, 2)
+                ok = all(ops.norm_fused_ok(*a, self.dtype) for a in (
+                    (M, H, nq * d, nq * d, L0["wo"].stride(0), False),              # h1 = h + o Wo^T
+                    (M, H, I, ldm, L0["wd"].stride(0), False),                      # h' = h1 + m Wd^T
+                    (M, nqkv, H, H, L0["wqkv"].stride(0), False),                   # qkv = rstd (h W'qkv^T)
+                    (M, 2 * I, H, H, L0["wgu"].stride(0), False),                   # gu = rstd (h1 W'gu^T)
+                    (M, H, nqkv, nqkv, L0["wqkv"].stride(0), True),                 # G_h = rstd (Aqkv W'qkv) + G_res
+                    (M, H, 2 * I, 2 * I + pitch_pad(2 * I, 2), L0["wgu"].stride(0), True)))
+            if not hasattr(self, "_nf_cache"):
+                self._nf_cache = {}
+            self._nf_cache[key] = hit = bool(ok)
+        return hit
 
     def build_transposes(self):
         """kept for callers of the round-2 API (bench.py, dist tests): the bf16 engine holds no W^T copies any more; the fp32 parity
@@ -281,17 +329,25 @@ class LlamaLRP:
         stash = []
         h_prev, branch = emb, None
         last = torch.arange(B, device=dev) * S + (S - 1)
+        nf = self._norm_fused(M) and ops.norm_fusion_part("fwd")          # K1n: the two norms + residual sums of a layer inside the GEMM epilogues around them
+        ready = None                      # (h, rstd1) of this layer, left by the previous layer's down-projection epilogue
+        nL = len(self.layers)
         for li, Lw in enumerate(self.layers):
             st = {}
-            top = self.sparse_top and li == len(self.layers) - 1
-            x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
-            if branch is None:
-                st["h"] = h_prev
-                ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"], y=x, rstd=st["rstd1"])
+            top = self.sparse_top and li == nL - 1
+            if ready is not None:
+                st["h"], st["rstd1"] = ready
+                ready = None
+                qkv = ops.gemm_nt_rs(st["h"], Lw["wqkv"], st["rstd1"], new(("qkv", li), M, nqkv))
             else:
-                st["h"] = new(("h", li), M, H)
-                ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"], y=x, rstd=st["rstd1"])
-            qkv = self._lin_fwd(x, Lw["wqkv"], new(("qkv", li), M, nqkv))
+                x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
+                if branch is None:
+                    st["h"] = h_prev
+                    ops.add_rmsnorm_fwd(h_prev, None, Lw["ln1"], c["rms_eps"], y=x, rstd=st["rstd1"])
+                else:
+                    st["h"] = new(("h", li), M, H)
+                    ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"], y=x, rstd=st["rstd1"])
+                qkv = self._lin_fwd(x, Lw["wqkv"], new(("qkv", li), M, nqkv))
             qkr = ops.rope_fwd(qkv, new(("qkr", li), M, nqk), self.cos, self.sin, S, nq + nk, d)
             v = qkv[:, nqk:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
@@ -310,6 +366,25 @@ class LlamaLRP:
                 h_prev, branch = h1_l, dn_l
                 break
             ops.attn_fwd(qkr[:, : nq * d], qkr[:, nq * d:], v, v_t, o, lse, B, S, nq, nk, d, scale, True, 0, row_iv=row_iv)
+            if nf:
+                # h1 = h + o Wo^T and its rows' sums of squares in ONE launch; the gate/up GEMM reads the un-normalised h1 and scales its output
+                # rows by rstd2; the down projection leaves the next layer's input sum and ITS statistics the same way (the last layer's keeps
+                # the stand-alone form: the tail below wants h1 and dn of the explained rows separately)
+                h1, ssq = new(("h1", li), M, H), ar.get("ssq", (H // 64, M), torch.float32)
+                ops.gemm_res_ssq(o, Lw["wo"], st["h"], h1, ssq)
+                st["rstd2"] = ops.rms_rstd(ssq, M, H, c["rms_eps"], f32(("rstd2", li), M))
+                gu, m = ops.gemm_gated_fwd_rs(h1, Lw["wgu"], st["rstd2"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
+                st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=None, h1=h1, gu=gu, dn=None)
+                stash.append(st)
+                if li + 1 < nL:
+                    hn = new(("h", li + 1), M, H)
+                    ops.gemm_res_ssq(m, Lw["wd"], h1, hn, ssq)
+                    ready = (hn, ops.rms_rstd(ssq, M, H, c["rms_eps"], f32(("rstd1", li + 1), M)))
+                    h_prev, branch = hn, None
+                else:
+                    st["dn"] = self._lin_fwd(m, Lw["wd"], new(("dn", li), M, H))
+                    h_prev, branch = h1, st["dn"]
+                continue
             a = self._lin_fwd(o, Lw["wo"], new(("a", li), M, H))
             h1 = new(("h1", li), M, H)
             x2, st["rstd2"] = new("x2", M, H), f32(("rstd2", li), M)
@@ -366,6 +441,7 @@ class LlamaLRP:
             Adn = zeros(("Adn", len(self.layers) & 1), M, H).index_copy_(0, last, A_last)
         layer_R = [rel_last] if layer_relevance else None
         plain_add = E["add"] == 0.0 and E["lin"] == 0.0          # efficient placement: add2 / Linear eps factors are exactly 1
+        nfb = plain_add and self._norm_fused(M)                  # K1n in the backward (independent of what the forward ran: both need only rstd)
 
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
@@ -394,14 +470,17 @@ class LlamaLRP:
                 gu = st["gu"]
                 # ---- MLP
                 Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
-                Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
                 Gs1 = new("Gs1", M, H)
-                if plain_add:         # no stabiliser on the add / the branch's Linear: the branch gradient IS the residual gradient
-                    ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], None, None, Gs1, None, None, 0.0, 0.0, 0.0)
-                    Aa = Gs1
+                if nfb and ops.norm_fusion_part("bwd_gu"):               # K1n: Gs1 = rstd2 (.) (Agu W'gu) + Gs in the dgrad GEMM's epilogue
+                    Aa = ops.gemm_nn_rs_res(Agu, Lw["wgu"], st["rstd2"], Gs, Gs1)
                 else:
-                    Aa = new("Aa", M, H)
-                    ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
+                    Gx2 = self._lin_bwd(Agu, Lw["wgu"], new("Gx2", M, H))
+                    if plain_add:     # no stabiliser on the add / the branch's Linear: the branch gradient IS the residual gradient
+                        ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], None, None, Gs1, None, None, 0.0, 0.0, 0.0)
+                        Aa = Gs1
+                    else:
+                        Aa = new("Aa", M, H)
+                        ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
                 # ---- attention
                 Gof = self._lin_bwd(Aa, Lw["wo"], new("Gof", M, nq * d))
                 Gho = new("Gho", M, nq * d)
@@ -428,9 +507,14 @@ class LlamaLRP:
                 dv = ops.gqa_reduce(dv_h, new("dv", M, nk * d), M, nk, rep, d)
                 ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
                 ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
+            rel = f32(("rel", li), M) if layer_relevance else None
+            if nfb and not layer_relevance and ops.norm_fusion_part("bwd_qkv"):
+                # K1n: Gs = rstd1 (.) (Aqkv W'qkv) + Gs1 -- the input norm's identity rule and the residual add in the qkv dgrad's epilogue
+                Gs = ops.gemm_nn_rs_res(Aqkv, Lw["wqkv"], st["rstd1"], Gs1, new(("Gs", li & 1), M, H))
+                Adn = Gs
+                continue
             Gx = self._lin_bwd(Aqkv, Lw["wqkv"], new("Gx", M, H))
             # ---- input norm + the residual add below (or the embedding)
-            rel = f32(("rel", li), M) if layer_relevance else None
             if li > 0:
                 prev = fw["stash"][li - 1]
                 Gs = new(("Gs", li & 1), M, H)

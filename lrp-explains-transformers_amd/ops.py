@@ -123,8 +123,9 @@ class KernelTimer:
 
     def summary(self, tag=None):
         """-> (launches, total_flops, total_seconds) of the launches with this tag (None: all); call after a device synchronise.
-        Tags: "plain" = GEMM only; "gated_fwd" / "gated_bwd" = the launches that carry a gated-MLP rule in their epilogue"""
-        recs = [r for r in self.records if tag is None or r[3] == tag]
+        Tags: "plain" = GEMM only; "plain_norm" = the same kernel with a K1n epilogue (row scale / residual add / row sums of squares);
+        "gated_fwd" / "gated_bwd" = the launches that carry a gated-MLP rule in their epilogue; a tuple selects several"""
+        recs = [r for r in self.records if tag is None or r[3] == tag or (isinstance(tag, tuple) and r[3] in tag)]
         tot_f = sum(r[0] for r in recs)
         tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
         return len(recs), tot_f, tot_t
@@ -487,6 +488,85 @@ def rope_bwd(Gr, xr, x, A, cos, sin, seq, n_heads, d, eps_rope, eps_lin):
 
 
 # ---------------------------------------------------------------------------------------- row ops
+# ---- K1n: RMSNorm folded into the GEMMs around it (include/lrp_hip.h; ref lxt/efficient/patches.py:111-123 + the residual sums of HF modeling_llama)
+# module attribute: False = the stand-alone add_rmsnorm_fwd / rmsnorm_bwd_add2 launches (A/B measurements, equality tests); True = every part;
+# a set of {"fwd", "bwd_qkv", "bwd_gu"} = the named parts.  Default: everything but the gate/up dgrad -- its residual epilogue costs more than
+# the stand-alone kernel it replaces (tools/k1n_shapes.py at M = 8192: 1312 us fused against 1258 + 31 us; the other five GEMMs gain 13-34 us each)
+NORM_FUSION = frozenset({"fwd", "bwd_qkv"})
+
+
+def norm_fusion_part(part):
+    return NORM_FUSION is True or (isinstance(NORM_FUSION, (set, frozenset)) and part in NORM_FUSION)
+
+
+def norm_fused_ok(M, N, K, lda, ldb, nn, dtype):
+    """the K1n entry points take this problem (bf16, N % 256 == 0, K % 64 == 0, >= 190 output tiles of the ping-pong kernel)"""
+    return bool(NORM_FUSION and dtype == torch.bfloat16 and lib.lrp_gemm_norm_fused_ok(M, N, K, lda, ldb, 1 if nn else 0, _DT[dtype]))
+
+
+def _timed(flops, tag, fn, name):
+    ev = GEMM_TIMER.span(flops, tag) if GEMM_TIMER is not None else None
+    if ev:
+        ev[0].record()
+    rc = fn()
+    if ev:
+        ev[1].record()
+    check(rc, name)
+
+
+def gemm_res_ssq(x, W, res, out, ssq):
+    """out = res + x @ W^T (bf16 rounding once) and ssq[p, m] = sum of out[m, 64 p : 64 p + 64]^2 -- the residual add and RMSNorm's sum of
+    squares in the producing GEMM's epilogue; ssq [N / 64, >= M] fp32"""
+    M, K = x.shape
+    N = W.shape[0]
+    same(x, W, res, out)
+    f32(ssq)
+    assert ssq.shape[0] * 64 == N and ssq.stride(0) >= M and ssq.stride(1) == 1
+    _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_res_ssq(p(x), p(W), p(res), p(out), p(ssq), M, N, K, x.stride(0), W.stride(0),
+                                                                       res.stride(0), out.stride(0), ssq.stride(0), dt(x), stream()), "lrp_gemm_res_ssq")
+    return out
+
+
+def rms_rstd(ssq, M, H, eps, rstd):
+    f32(ssq, rstd)
+    check(lib.lrp_rms_rstd(p(ssq), ssq.shape[0], ssq.stride(0), M, H, eps, p(rstd), stream()), "lrp_rms_rstd")
+    return rstd
+
+
+def gemm_nt_rs(x, W, rs, out):
+    """out = rs[:, None] * (x @ W^T): the consumer of a folded RMSNorm (W carries the norm's weight, rs = rstd of x's rows)"""
+    M, K = x.shape
+    N = W.shape[0]
+    same(x, W, out)
+    f32(rs)
+    _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_nt_rs(p(x), p(W), p(rs), p(out), M, N, K, x.stride(0), W.stride(0), out.stride(0),
+                                                                     dt(x), stream()), "lrp_gemm_nt_rs")
+    return out
+
+
+def gemm_gated_fwd_rs(x, Wgu, rs, gu, m, act="silu"):
+    M, K = x.shape
+    I = m.shape[1]
+    same(x, Wgu, gu, m)
+    f32(rs)
+    _timed(2.0 * M * 2 * I * K, "gated_fwd", lambda: lib.lrp_gemm_gated_fwd_rs(p(x), p(Wgu), p(rs), p(gu), p(m), M, I, K, x.stride(0), Wgu.stride(0),
+                                                                               gu.stride(0), m.stride(0), ACT[act], dt(x), stream()),
+           "lrp_gemm_gated_fwd_rs")
+    return gu, m
+
+
+def gemm_nn_rs_res(s, W, rs, res, out):
+    """out = rs[:, None] * (s @ W) + res from the STORED weight W [K, N]: RMSNorm's identity-rule backward (row scale; the norm's weight sits in
+    W) and the residual gradient in the dgrad GEMM's epilogue; out may alias res"""
+    M, K = s.shape
+    N = W.shape[1]
+    same(s, W, res, out)
+    f32(rs)
+    _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_nn_rs_res(p(s), p(W), p(rs), p(res), p(out), M, N, K, s.stride(0), W.stride(0),
+                                                                         res.stride(0), out.stride(0), dt(s), stream()), "lrp_gemm_nn_rs_res")
+    return out
+
+
 def add_rmsnorm_fwd(h, branch, w, eps, w_offset=0.0, hsum_out=None, y=None, rstd=None):
     M, H = h.shape
     y = torch.empty_like(h) if y is None else y

@@ -52,6 +52,58 @@ def test_llama_batch_equals_single(eng_mod):
         assert torch.equal(one["R_tok"][0], both["R_tok"][b]) and int(one["idx"][0]) == int(both["idx"][b])
 
 
+def test_llama_bf16_norm_folded_into_gemms(eng_mod):
+    """K1n (round 5): the bf16 engine folds the per-layer RMSNorm weights into the consuming Linears (same network, same relevance under every
+    rule) and, for M = B S rows in the efficient placement, runs the norms and residual sums inside the GEMM epilogues
+    (ref lxt/efficient/patches.py:111-123; HF modeling_llama's h + attn, h + mlp).  A shape wide enough for the fused epilogues
+    (>= 190 tiles per GEMM), NON-TRIVIAL norm weights: (1) fused and stand-alone flows agree to bf16 rounding, (2) both against the fp32
+    engine on the UNFOLDED weights within the bf16 bar, (3) the explicit placement runs on the folded weights (stand-alone kernels, norm
+    weight = 1) and agrees with the fp32 explicit engine the same way, (4) fused flow == itself under a hipGraph, batched == single."""
+    import lxt_amd.ops as ops
+    cfg = dict(hidden=2048, inter=5632, n_layers=3, n_heads=16, n_kv=4, head_dim=128, vocab=1024, rope_theta=1e4, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=77)
+    g = torch.Generator().manual_seed(78)
+    for L in W["layers"]:
+        L["ln1"] = (0.25 + 1.5 * torch.rand(cfg["hidden"], generator=g))
+        L["ln2"] = (0.25 + 1.5 * torch.rand(cfg["hidden"], generator=g))
+    B, S = 3, 2048
+    ids = torch.randint(0, cfg["vocab"], (B, S), generator=g)
+    ref = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="efficient", max_seq=S).explain(ids)
+    tgt = ref["idx"]
+    for sparse_top in (True, False):
+        eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="efficient", max_seq=S, sparse_top=sparse_top)
+        assert eng.folded and eng._norm_fused(B * S) and not eng._norm_fused(S // 2)
+        assert all(bool((Lw["ln1"] == 1).all()) and bool((Lw["ln2"] == 1).all()) for Lw in eng.layers)
+        keep = ops.NORM_FUSION
+        ops.NORM_FUSION = True                                   # every part, also the gate/up dgrad epilogue the default leaves out
+        try:
+            fused = eng.explain(ids, target=tgt)
+            ops.NORM_FUSION = False
+            plain = eng.explain(ids, target=tgt)
+        finally:
+            ops.NORM_FUSION = keep
+        e_f, e_p = nmax(fused["R_tok"], ref["R_tok"]), nmax(plain["R_tok"], ref["R_tok"])
+        d_fp = nmax(fused["R_tok"], plain["R_tok"])
+        print(f"[K1n sparse_top={sparse_top}] vs the fp32 engine: fused {e_f:.2e}, stand-alone {e_p:.2e}; fused vs stand-alone {d_fp:.2e}")
+        assert torch.isfinite(fused["R_tok"]).all() and e_f < 5e-2 and e_p < 5e-2 and d_fp < 5e-2
+        if sparse_top:
+            fused = eng.explain(ids, target=tgt)                 # the default parts
+            assert nmax(fused["R_tok"], ref["R_tok"]) < 5e-2
+            again = eng.explain(ids, target=tgt, graph=True)
+            again = eng.explain(ids, target=tgt, graph=True)
+            assert torch.equal(again["R_tok"], fused["R_tok"])
+            six = eng.explain(torch.cat([ids, ids.flip(0)]), target=torch.cat([tgt, tgt.flip(0)]))       # prompts are independent rows of the GEMMs
+            assert torch.equal(six["R_tok"][:B], fused["R_tok"]) and torch.equal(six["R_tok"][B:].flip(0), fused["R_tok"])
+        del eng
+    ref_x = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode="explicit", max_seq=S).explain(ids[:1], target=tgt[:1])
+    eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="explicit", max_seq=S)
+    out_x = eng.explain(ids[:1], target=tgt[:1])
+    unf = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode="explicit", max_seq=S, fold_norm=False).explain(ids[:1], target=tgt[:1])
+    e_x, e_u = nmax(out_x["R_tok"], ref_x["R_tok"]), nmax(unf["R_tok"], ref_x["R_tok"])
+    print(f"[K1n explicit on folded weights] vs the fp32 explicit engine {e_x:.2e} (unfolded bf16 engine: {e_u:.2e})")
+    assert e_x < max(5e-2, 3 * e_u)
+
+
 @pytest.mark.parametrize("mode", ["explicit", "efficient"])
 def test_llama_bf16(eng_mod, mode):
     """bf16 engine against the fp64 oracle on the bf16-rounded weights.  Efficient placement: <= 5e-2.  Explicit placement in bf16 is

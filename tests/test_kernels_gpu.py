@@ -343,6 +343,67 @@ def test_gemm_gated_fused_epilogues(ops, M, I, K, act):
         assert nmax(Gm, f64(Adn) @ f64(Wd)) < 2e-2
 
 
+@pytest.mark.parametrize("M,H,K,I", [(2304, 5632, 512, 2816), (2100, 5632, 256, 3072)])
+def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
+    """K1n (include/lrp_hip.h): Llama-type RMSNorm (ref lxt/efficient/patches.py:111-123, variance detached = identity rule) and the residual
+    sums around it folded into the epilogues of the ping-pong GEMM -- full and ragged row tiles.  Each entry point against fp64 on the same
+    bf16 operands; where a stand-alone kernel pair computes the same thing, against that pair to one bf16 rounding."""
+    g_ = torch.Generator().manual_seed(M + H)
+    bf = torch.bfloat16
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g_) * sc).to(bf).cuda()      # noqa: E731
+    x, res = mk(M, K), mk(M, H)
+    W = mk(H, K, sc=K ** -0.5)
+    assert ops.norm_fused_ok(M, H, K, K, K, False, bf) and not ops.norm_fused_ok(300, H, K, K, K, False, bf)
+    assert not ops.norm_fused_ok(M, H + 64, K, K, K, False, bf) and not ops.norm_fused_ok(M, H, K, K, K, False, torch.float32)
+    # ---- out = res + x W^T, partial sums of squares of the rounded rows, rstd from the partials
+    out = torch.full((M, H), float("nan"), dtype=bf, device="cuda")
+    ssq = torch.full((H // 64, M), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm_res_ssq(x, W, res, out, ssq)
+    ref = f64(res) + f64(x) @ f64(W).T
+    assert not torch.isnan(out).any() and not torch.isnan(ssq).any()
+    assert nmax(out, ref) < 1e-2
+    assert (out.double() - ref).abs().max() <= (ref.abs().max() * 2.0 ** -8)          # one bf16 rounding of the fp32 sum
+    ssq_ref = (out.double() ** 2).view(M, H // 64, 64).sum(-1).T                       # from the STORED rows: exact up to fp32 summation
+    assert torch.allclose(ssq.double(), ssq_ref, rtol=1e-5, atol=1e-6)
+    eps = 1e-5
+    rstd = ops.rms_rstd(ssq, M, H, eps, torch.empty(M, dtype=torch.float32, device="cuda"))
+    rstd_ref = torch.rsqrt((out.double() ** 2).mean(-1) + eps)
+    assert torch.allclose(rstd.double(), rstd_ref, rtol=1e-5)
+    _, rstd_k = ops.add_rmsnorm_fwd(out, None, torch.ones(H, dtype=bf, device="cuda"), eps)      # the stand-alone kernel's statistic
+    assert torch.allclose(rstd, rstd_k, rtol=1e-5)
+    # ---- consumer: rows scaled after the product, (rstd x) W^T = rstd (x W^T)
+    N2 = 2 * I
+    W2 = mk(N2, H, sc=H ** -0.5)
+    y = torch.full((M, N2), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_nt_rs(out, W2, rstd, y)
+    y_ref = rstd.double()[:, None] * (f64(out) @ f64(W2).T)
+    assert not torch.isnan(y).any() and nmax(y, y_ref) < 1e-2
+    # ---- gate/up consumer with the gated rule behind the row scale: gu = the scaled product, m = act(g) (*) u from the stored gu
+    wg, wu = mk(I, H, sc=H ** -0.5), mk(I, H, sc=H ** -0.5)
+    Wgu = ops.interleave_gate_up(wg, wu)
+    gu, m = torch.full((M, N2), float("nan"), dtype=bf, device="cuda"), torch.full((M, I), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_gated_fwd_rs(out, Wgu, rstd, gu, m, "silu")
+    gu_ref = rstd.double()[:, None] * (f64(out) @ f64(Wgu).T)
+    assert not torch.isnan(gu).any() and nmax(gu, gu_ref) < 1e-2
+    m2 = torch.empty_like(m)
+    ops.gated_act_fwd_il(gu, m2, "silu")
+    assert torch.equal(m, m2)
+    # ---- backward: G_h = rstd (.) (A W) + G_res from the stored weight (NN), also in place on the residual gradient
+    A = mk(M, N2)
+    Gres = mk(M, H)
+    Gh = torch.full((M, H), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_nn_rs_res(A, W2, rstd, Gres, Gh)
+    Gh_ref = rstd.double()[:, None] * (f64(A) @ f64(W2)) + f64(Gres)
+    assert not torch.isnan(Gh).any() and nmax(Gh, Gh_ref) < 1e-2
+    Gx = ops.linear_dgrad(A, W2)                                                      # stand-alone pair: dgrad, then the norm's backward kernel
+    Gh2 = torch.empty_like(Gh)
+    ops.rmsnorm_bwd_add2(Gres, Gx, torch.ones(H, dtype=bf, device="cuda"), rstd, None, None, Gh2, None, None, 0.0, 0.0, 0.0)
+    assert nmax(Gh, Gh2) < 1e-2                                                        # (the pair rounds Gx to bf16 first: one rounding apart)
+    inpl = Gres.clone()
+    ops.gemm_nn_rs_res(A, W2, rstd, inpl, inpl)
+    assert torch.equal(inpl, Gh)
+
+
 def test_gemm_batched_and_f32_out(ops):
     a, b = rnd(3, 70, 96, seed=4), rnd(3, 50, 96, seed=5)
     assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).transpose(1, 2)) < 2e-5
