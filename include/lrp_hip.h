@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- and lrp_set_gemm_scratch / lrp_gemm_scratch_bytes; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -254,6 +254,15 @@ int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* A
  *   lrp_gemm_nn_rs_res    : out[M,N] = bf16(rs[m] * (s W) + res), W [K,N] as stored (the dgrad form of lrp_gemm_nn); out may alias res
  * --------------------------------------------------------------------------------------- */
 int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype);
+/* De-phased tile walk of the 256 x 256 ping-pong GEMM (every entry point that launches it: lrp_gemm_nt / _nn, lrp_gemm_gated_*, the K1n family).
+ * With scratch registered for the launching stream a workgroup computes its first tile in two sittings -- K tiles [0, phi) at the start, the
+ * partial sums parked in the scratch in fp32, K tiles [phi, nkt) at the very end: the same summation order as one sitting, results identical bit
+ * for bit -- with phi a function of the XCD it runs on, so that the eight XCDs' epilogues no longer coincide (the fused epilogues' HBM traffic
+ * then runs under other XCDs' K loops instead of as chip-wide bursts).  The memory stays the caller's: lrp_gemm_scratch_bytes() bytes (256 KiB
+ * per CU), 16-byte aligned, one region per stream that launches GEMMs concurrently; p = NULL drops the registration.  Nothing is registered by
+ * default (one sitting per tile). */
+int lrp_set_gemm_scratch(void* p, int64_t bytes, void* stream);
+int64_t lrp_gemm_scratch_bytes(void);
 int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx, int64_t ldw,
                      int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream);
 int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);

@@ -57,6 +57,8 @@
 // (workgroups starting up to 17 us apart to de-phase the CUs' epilogue bursts) changed nothing and was removed: the fused epilogues are bound by
 // their own VALU issue (see gated_bwd_pair_bf16 in common.hpp), not by a shared HBM burst.
 #include "common.hpp"
+#include <mutex>
+#include <vector>
 
 #ifndef PP_PERSIST
 #define PP_PERSIST 1
@@ -114,7 +116,8 @@ struct PPEpi {
 template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep,
+    int phi_mult, f32x4* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,17 +125,43 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // this workgroup's range of K tiles (split-K: blockIdx.y), host guarantees >= 2 tiles per split
     const int nkt_all = K / PP_KT;
     const int kt0 = blockIdx.y * kt_per_split;
-    const int nkt = min(kt_per_split, nkt_all - kt0);
+    const int nkt_full = min(kt_per_split, nkt_all - kt0);
+    int nkt = nkt_full;                                                // K tiles of the running segment (a whole tile, or one part of a split one)
     C += (int64_t)blockIdx.y * slab_stride;
     const int ntiles = tiles_m * tiles_n;
     int tile = blockIdx.x;
     int m0, n0;                                                        // the tile whose K loop runs / ran last (epilogue coordinates)
+    // ---- DE-PHASED WORKGROUPS (round 5).  Left alone, the 256 CUs run in lock step: they reach the epilogue together (the fused epilogues' HBM
+    // traffic -- 0.94 GB per down-projection dgrad -- comes as 7 chip-wide bursts during which no CU multiplies) and start every K loop with all
+    // staging requests at once.  With scratch registered for the stream (lrp_set_gemm_scratch) a workgroup computes its FIRST tile in two
+    // sittings: K tiles [0, phi) at the start, the accumulators parked in the scratch (fp32, exact); K tiles [phi, nkt) at the very end, on top
+    // of the reloaded accumulators -- the same summation order as one sitting, bit for bit -- which shifts all its other tiles, hence its
+    // epilogues, by phi K tiles.  phi is a function of the XCD the workgroup runs on (HW_REG_XCC_ID): the 32 workgroups of an XCD stay in
+    // step with each other -- they share operand panels through the XCD's L2, and tiles walking K out of step re-fetch them (a per-tile phase
+    // cost 5 % on the whole step) -- while the eight XCDs, which share nothing but HBM, are spread evenly over a tile's K loop.
+    // MEASURED NEGATIVE (profiles/r05_gemm_experiments.txt, section K; the host leaves it off: ops.GEMM_DEPHASE): results bit-identical, but the
+    // 8-layer judged step goes 43.56 -> 44.47 ms -- parking and reloading one tile per CU costs ~25 us per launch, and the epilogues were not
+    // waiting for HBM bandwidth to begin with.
+    int rot = 0;                                                       // first K tile of the running segment
+    int mode = 0;                                                      // 0: whole tile; 1: first sitting of a split tile (park); 2: second sitting (reload)
+    bool split = false, second_done = false;
     {
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * 256; n0 = tn * 256;
+#if PP_PERSIST && !defined(PP_TIMELINE)
+        if (scratch != nullptr && gridDim.y == 1) {
+            unsigned xcc;                                              // the XCD this workgroup REALLY runs on (the dispatcher's round robin does not
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));      // restart at XCD 0 with every launch)
+            const int phi = (int)(xcc & 7u) * nkt_all / 8;
+            if (phi >= 2 && phi <= nkt_all - 2) { split = true; mode = 1; nkt = phi; }      // (both sittings need the two K tiles the prologue stages)
+        }
+#endif
     }
-
+    const int m00 = m0, n00 = n0, phi0 = nkt;
+    // parked accumulators: [workgroup][32 accumulator quads][512 threads] fp32 x 4 (lane-linear: 16 bytes per lane, 1 KiB per wave instruction).
+    // Written as inline asm: left to the compiler, the 32 addresses become 64 live registers and the kernel spills.
+    f32x4* const park = scratch + (size_t)blockIdx.x * (32 * 512) + tid;
     // ---- staging (buffer_load_dwordx4 .. lds, 1 KiB per wave instruction; rows / columns past the operand read as zero)
     // A (both forms): piece = 8 rows x 128 B; lane l -> row (l >> 3), LDS position (l & 7), source chunk position ^ (row & 7).  A pieces of
     // this wave: rows g*128 + a*64 + wc*16 + 8 p (a = unit half, p = 0, 1).
@@ -172,17 +201,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const int bstep = NN ? (int)(PP_KT * ldb * 2) : 128;                // bytes per K tile along B
     char* const ldsA = smem + (g * 128 + wc * 16) * 128;               // + buf*PP_OPND + a*8192 + p*1024
     char* const ldsB = smem + 2 * PP_OPND + (NN ? wave * 8 * 512 : wave * 32 * 128);      // + buf*PP_OPND + p*1024
+    // (running K-tile index + the segment's first K tile, written out in both staging lambdas: a helper lambda called from them makes the HOST
+    // pass of hipcc drop the kernel's stub without a diagnostic)
     auto stage_A = [&](int a, int kt, int buf) {
+        const int kr = kt + rot;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, voA,
-                                                     soA[a][p] + kt * 128, 0, 0);
+                                                     soA[a][p] + kr * 128, 0, 0);
     };
     auto stage_B = [&](int kt, int buf) {
+        const int kr = kt + rot;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (pp_lds_ptr_t)(ldsB + buf * PP_OPND + p * 1024), 16, voB[p & 1],
-                                                     soB[p] + kt * bstep, 0, 0);
+                                                     soB[p] + kr * bstep, 0, 0);
     };
 
     // ---- fragment addresses.  A (and NT B): row (l & 15) of a 16-row block, chunk (4 ks + (l >> 4)) ^ (l & 7).
@@ -263,12 +296,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     if constexpr (EPI == 3) {
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
+    if (mode == 2) {                                                   // second sitting: continue on the parked partial sums
+        uint64_t pa = reinterpret_cast<uint64_t>(park);               // ONE running address (made opaque per step: hoisted, the 32 addresses spill)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[q >> 4][(q >> 2) & 3][q & 3]) : "v"(pa) : "memory");
+            pa += 8192;
+            asm volatile("" : "+v"(pa));
+        }
+        // (the loads are invisible to the compiler's own wait insertion: the values pass through the wait as operands, 8 quads per statement)
+#define PP_TIE8(A, I) "+v"(acc[A][I][0]), "+v"(acc[A][I][1]), "+v"(acc[A][I][2]), "+v"(acc[A][I][3]), \
+                      "+v"(acc[A][I + 1][0]), "+v"(acc[A][I + 1][1]), "+v"(acc[A][I + 1][2]), "+v"(acc[A][I + 1][3])
+        asm volatile("s_waitcnt vmcnt(0)" : PP_TIE8(0, 0) :: "memory");
+        asm volatile("" : PP_TIE8(0, 2));
+        asm volatile("" : PP_TIE8(1, 0));
+        asm volatile("" : PP_TIE8(1, 2));
+#undef PP_TIE8
+    } else {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                          // the half-phase offset between the two groups
 
@@ -373,19 +424,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         load_rs();
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
+    const int emode = mode;                                           // what to do with the accumulators of the segment that just ran
 #if PP_PERSIST && !defined(PP_TIMELINE)
-    tile += gridDim.x;
-    has_next = tile < ntiles;
-    if (has_next) {
+    if (tile + (int)gridDim.x < ntiles) {
+        tile += gridDim.x;
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * 256; n0 = tn * 256;
+        rot = 0; nkt = nkt_full; mode = 0;
+        has_next = true;
+    } else if (split && !second_done) {                                // the parked first tile: its K tiles [phi, nkt)
+        m0 = m00; n0 = n00;
+        rot = phi0; nkt = nkt_all - phi0; mode = 2;
+        second_done = true;
+        has_next = true;
+    }
+    if (has_next) {
         set_soA(m0);
         set_soB(n0);
         issue_prologue();
     }
 #endif
 
+    if (emode == 1) {
+        // ---- first sitting of a split tile: park the partial sums (fp32, lane-linear: 16 bytes per lane, 8 KiB per wave store)
+        uint64_t pa = reinterpret_cast<uint64_t>(park);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            // (s_nop: a store of more than 8 bytes reads its data registers one wait state after issue, and the compiler -- which re-uses the
+            // just-stored accumulator registers for the next address -- does not see hazards of inline asm)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(pa), "v"(acc[q >> 4][(q >> 2) & 3][q & 3]) : "memory");
+            pa += 8192;
+            asm volatile("" : "+v"(pa));
+        }
+    } else {
     // ---- epilogue
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     bool done = false;
@@ -636,13 +708,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     }
             }
         }
+    }   // emode != 1
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
     if (!has_next) break;
     // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
     // retire in issue order through vmcnt on gfx9; the counter has 6 bits).  Full bf16 tiles: 16 stores per wave (+ 8 of m in the gated forward);
     // the fused gated backward's own gu loads were issued after the pieces and waited for by the compiler, only its last stores remain;
     // ragged tiles and fp32 output (scalar / conditional stores): drain.
-    if (full && sizeof(TO) == 2) {
+    if (emode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (once per launch: the parked sums drain)
+    else if (full && sizeof(TO) == 2) {
         if constexpr (EPI == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else if constexpr (EPI == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -676,6 +750,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
+// caller-owned scratch for the parked accumulators of the de-phased walk, registered per stream (the library allocates nothing)
+struct PPScratch { hipStream_t st; void* p; int64_t bytes; };
+std::mutex pp_scratch_mu;
+std::vector<PPScratch> pp_scratch;
+
+void* pp_scratch_for(hipStream_t st, int64_t need) {
+    std::lock_guard<std::mutex> lk(pp_scratch_mu);
+    for (const auto& e : pp_scratch)
+        if (e.st == st) return e.bytes >= need ? e.p : nullptr;
+    return nullptr;
+}
+
 template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false, bool RS = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
@@ -695,12 +781,34 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
 #endif
     auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS>;
     LRP_SET_MAX_LDS(kern, lds);
+    // de-phased walk: when the stream has scratch for one parked tile per workgroup and every workgroup has at least two tiles
+    const int phi_mult = 0;                                           // (unused: a per-tile rotated K order was measured and dropped, see the kernel)
+    void* scratch = nullptr;
+#if PP_PERSIST && !defined(PP_TIMELINE) && !defined(PP_NO_DEPHASE)
+    if (splits == 1 && !SK && tiles_m * tiles_n >= 2 * gx) scratch = pp_scratch_for(st, (int64_t)gx * 32 * 512 * 16);
+#endif
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
-                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
+                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep, phi_mult, (f32x4*)scratch);
     return lrp_check_launch();
 }
 
 }  // namespace
+
+// register (p != NULL) or drop (p == NULL) the scratch of a stream: bytes >= workgroups x 256 KiB (lrp_gemm_scratch_bytes()) enables the de-phased
+// walk for the launches on that stream; the memory stays the caller's
+extern "C" int lrp_set_gemm_scratch(void* p, int64_t bytes, void* stream) {
+    if (p != nullptr && (bytes <= 0 || (reinterpret_cast<uintptr_t>(p) & 15))) return LRP_EINVAL;
+    std::lock_guard<std::mutex> lk(pp_scratch_mu);
+    for (size_t i = 0; i < pp_scratch.size(); ++i)
+        if (pp_scratch[i].st == (hipStream_t)stream) {
+            if (p) { pp_scratch[i].p = p; pp_scratch[i].bytes = bytes; }
+            else pp_scratch.erase(pp_scratch.begin() + i);
+            return LRP_OK;
+        }
+    if (p) pp_scratch.push_back(PPScratch{(hipStream_t)stream, p, bytes});
+    return LRP_OK;
+}
+extern "C" int64_t lrp_gemm_scratch_bytes(void) { return (int64_t)lrp_num_cus() * 32 * 512 * 16; }
 
 // Host entry used by the dispatchers of gemm.hip.  bf16 operands; K a multiple of 64, >= 128 per split; every operand below 2^30 elements
 // (32-bit buffer offsets).  nn = 0: B is [N, K] (ldb = row pitch of B); nn = 1: B is [K, N].  splits > 1: C must be fp32 slabs

@@ -535,6 +535,7 @@ class LlamaLRP:
     # ---------------------------------------------------------------------------------------------
     def _run(self, input_ids, emb, B, S, row_iv, idx, layer_relevance, return_G, seed):
         """forward + backward + read-out on the current stream: library launches only, no host synchronisation (capturable)"""
+        ops.ensure_gemm_scratch(self.device)      # de-phased GEMM tile walk: the current stream's scratch for the parked accumulators (once per stream)
         if emb is None:
             emb = self.embed.index_select(0, input_ids.reshape(-1))
         fw = self.forward(emb, B, S, row_iv)

@@ -488,6 +488,32 @@ def rope_bwd(Gr, xr, x, A, cos, sin, seq, n_heads, d, eps_rope, eps_lin):
 
 
 # ---------------------------------------------------------------------------------------- row ops
+# ---- de-phased tile walk of the ping-pong GEMM (include/lrp_hip.h: lrp_set_gemm_scratch): one caller-owned scratch region per (device, stream)
+# module attribute.  True = register the scratch (de-phased walk); False (default) = one sitting per tile, the lock-step walk -- same results bit
+# for bit.  OFF because it measured NEGATIVE in situ (profiles/r05_gemm_experiments.txt, section K): 8-layer judged step 43.56 -> 44.47 ms; the
+# fused down-projection dgrad 808 -> 835 us, gate/up forward 1370 -> 1383 us, plain launches 0.594 -> 0.576 of peak: parking and reloading one
+# tile per CU (2 x 64 MB per launch) costs ~25 us per launch and the epilogues it spreads out were not waiting for HBM in the first place
+# (they are bound by their own instruction issue and load latency per CU).
+GEMM_DEPHASE = False
+_gemm_scratch = {}
+
+
+def ensure_gemm_scratch(device=None):
+    """register the parked-accumulator scratch of the CURRENT stream with the library (idempotent; call once per explain / per capture)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, st)
+    want = bool(GEMM_DEPHASE)
+    have = _gemm_scratch.get(key)
+    if want and have is None:
+        buf = torch.empty(int(lib.lrp_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)
+        check(lib.lrp_set_gemm_scratch(buf.data_ptr(), buf.numel(), st), "lrp_set_gemm_scratch")
+        _gemm_scratch[key] = buf
+    elif not want and have is not None:
+        check(lib.lrp_set_gemm_scratch(None, 0, st), "lrp_set_gemm_scratch")
+        del _gemm_scratch[key]
+
+
 # ---- K1n: RMSNorm folded into the GEMMs around it (include/lrp_hip.h; ref lxt/efficient/patches.py:111-123 + the residual sums of HF modeling_llama)
 # module attribute: False = the stand-alone add_rmsnorm_fwd / rmsnorm_bwd_add2 launches (A/B measurements, equality tests); True = every part;
 # a set of {"fwd", "bwd_qkv", "bwd_gu"} = the named parts.  Default: everything but the gate/up dgrad -- its residual epilogue costs more than

@@ -404,6 +404,62 @@ def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     assert torch.equal(inpl, Gh)
 
 
+def test_gemm_dephased_walk_is_bitwise_the_lockstep_walk(ops):
+    """lrp_set_gemm_scratch (include/lrp_hip.h): with scratch registered for the stream a workgroup of the ping-pong GEMM computes its first
+    tile in two sittings -- K tiles [0, phi) at the start, the partial sums parked in fp32, [phi, nkt) at the very end -- the SAME summation
+    order as one sitting, so every instantiation must return the same bits with and without the scratch.  Shapes with 2 ... 14 tiles per CU,
+    ragged rows, short K (phi must leave two K tiles per sitting; K = 192 has 3 K tiles: no split possible)."""
+    bf = torch.bfloat16
+    g_ = torch.Generator().manual_seed(99)
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g_) * sc).to(bf).cuda()      # noqa: E731
+    keep = ops.GEMM_DEPHASE
+
+    def run_all():
+        out = {}
+        for (M, N, K) in ((8192, 4096, 1024), (4200, 8192, 256), (8192, 4096, 192)):
+            x, W, Wn = mk(M, K), mk(N, K, sc=K ** -0.5), mk(K, N, sc=K ** -0.5)
+            out[("nt", M, N, K)] = (ops.linear_fwd(x, W), x, W)
+            out[("nn", M, N, K)] = (ops.linear_dgrad(x, Wn), x, Wn)
+            res, rs = mk(M, N), torch.rand(M, generator=g_).cuda() + 0.5
+            o, ssq = torch.empty(M, N, dtype=bf, device="cuda"), torch.empty(N // 64, M, device="cuda")
+            ops.gemm_res_ssq(x, W, res, o, ssq)
+            out[("res", M, N, K)] = (o, ssq)
+            o2 = torch.empty(M, N, dtype=bf, device="cuda")
+            ops.gemm_nn_rs_res(x, Wn, rs, res, o2)
+            out[("nnres", M, N, K)] = (o2,)
+        M, I, K = 4096, 7168, 512
+        x = mk(M, K)
+        Wgu = ops.interleave_gate_up(mk(I, K, sc=K ** -0.5), mk(I, K, sc=K ** -0.5))
+        gu, m = torch.empty(M, 2 * I, dtype=bf, device="cuda"), torch.empty(M, I, dtype=bf, device="cuda")
+        ops.gemm_gated_fwd(x, Wgu, gu, m, "silu")
+        Adn, Wd = mk(M, K), mk(K, I, sc=K ** -0.5)
+        Agu = torch.empty(M, 2 * I, dtype=bf, device="cuda")
+        ops.gemm_gated_bwd(Adn, Wd, gu, Agu, 1e-10, 0.0, "silu")
+        out["gated"] = (gu, m, Agu)
+        return out
+
+    try:
+        ops.GEMM_DEPHASE = False
+        ops.ensure_gemm_scratch()
+        g_.manual_seed(99)
+        lock = run_all()
+        ops.GEMM_DEPHASE = True
+        ops.ensure_gemm_scratch()
+        g_.manual_seed(99)
+        deph = run_all()
+    finally:
+        ops.GEMM_DEPHASE = keep
+        ops.ensure_gemm_scratch()
+    for key, vals in lock.items():
+        for a, b in zip(vals, deph[key]):
+            assert not torch.isnan(b.float()).any() and torch.equal(a, b), key
+    for key, vals in deph.items():
+        if key[0] == "nt":
+            assert nmax(vals[0], f64(vals[1]) @ f64(vals[2]).T) < 2e-2, key
+        if key[0] == "nn":
+            assert nmax(vals[0], f64(vals[1]) @ f64(vals[2])) < 2e-2, key
+
+
 def test_gemm_batched_and_f32_out(ops):
     a, b = rnd(3, 70, 96, seed=4), rnd(3, 50, 96, seed=5)
     assert nmax(ops.gemm_nt(a, b), f64(a) @ f64(b).transpose(1, 2)) < 2e-5
