@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- and lrp_set_gemm_scratch / lrp_gemm_scratch_bytes; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes and lrp_attn_bwd_dq_d[_ok]; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -268,6 +268,9 @@ int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, f
 int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);
 int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout,
                    int dtype, void* stream);
+int lrp_gemm_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds, int64_t ldw, int64_t ldout,
+                   int dtype, void* stream);      /* out[M,N] = bf16(rs[m] * (s W)), W [K,N] as stored (rs = 1/2 everywhere: the o-projection's dgrad
+                                                     with the uniform rule's factor of the P.V product, lxt/efficient/patches.py:193-203) */
 int lrp_gemm_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
                           int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
 int lrp_gemm_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds, int64_t ldw,
@@ -355,6 +358,13 @@ int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t
                     int64_t lddq, float scale, float eps_mask, float eps_qk, int causal,
                     int window, int q_begin, const int* row_lo, const int* row_hi, int dtype,
                     void* stream);
+/* lxt.efficient placement, bf16 d in {64, 96, 128} (lrp_attn_bwd_dq_d_ok): the dQ kernel forms D_i = sum_d Gho_i o_i itself from the rows it
+ * holds anyway and WRITES D for lrp_attn_bwd_dkv -- no lrp_attn_bwd_prep pass (Gho = 1/2 x the o-projection's dgrad comes out of
+ * lrp_gemm_nn_rs; ref lxt/efficient/patches.py:193-203).  Dense calls only (q_begin = 0). */
+int lrp_attn_bwd_dq_d_ok(int dtype, int d);
+int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, const void* Gho, const void* o, const float* lse, float* D, void* dq,
+                      int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldgho, int64_t ldo, int64_t lddq,
+                      float scale, int causal, int window, const int* row_lo, const int* row_hi, int dtype, void* stream);
 int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* q_t, const void* Gho,
                      const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h,
                      int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,

@@ -1074,7 +1074,7 @@ int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* 
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
                   int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
-                  hipStream_t st);
+                  hipStream_t st, const void* o = nullptr, int64_t ldo = 0, float* Dout = nullptr);
 int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
                    void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
                    int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
@@ -1237,6 +1237,26 @@ extern "C" int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, cons
     if (!al16(k_t) || (ldt % epc) || ldt < S) return LRP_EALIGN;
     if (dtype == LRP_F32) return attn_dq_t<float>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
     return attn_dq_t<bf16_t>(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldt, ldgho, lddq, scale, eps_mask, eps_qk, causal, window, q_begin, row_lo, row_hi, st);
+}
+
+// dQ with the statistic D_i = sum_d Gho_i o_i formed in the kernel's prologue (lxt.efficient placement: no stabiliser on P.V or the scores, so
+// Gho is the o-projection's dgrad times the uniform rule's 1/2 and needs no pass of its own): D is an OUTPUT here, for the dK / dV kernel
+extern "C" int lrp_attn_bwd_dq_d_ok(int dtype, int d) { return (use_attn32(dtype, d) && d != 256) ? 1 : 0; }
+
+extern "C" int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, const void* Gho, const void* o, const float* lse, float* D,
+                                 void* dq, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldgho,
+                                 int64_t ldo, int64_t lddq, float scale, int causal, int window, const int* row_lo, const int* row_hi,
+                                 int dtype, void* stream) {
+    if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
+    if (!q || !k || !v || !Gho || !o || !lse || !D || !dq) return LRP_EINVAL;
+    int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
+    if (rc) return rc;
+    if (!lrp_attn_bwd_dq_d_ok(dtype, d)) return LRP_ESHAPE;
+    if (B == 0 || S == 0) return LRP_OK;
+    if (!al16(q) || !al16(k) || !al16(v) || !al16(Gho) || !al16(o) || !al16(dq) || (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldgho % 8) ||
+        (ldo % 8) || (lddq % 4)) return LRP_EALIGN;
+    return lrp_attn32_dq(q, k, v, Gho, lse, nullptr, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldgho, lddq, scale, 0.f, 0.f, causal, window, 0,
+                         row_lo, row_hi, (hipStream_t)stream, o, ldo, D);
 }
 
 template <typename T>

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ gho,
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
     int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
-    int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi) {
+    int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi, const bf16_t* __restrict__ ofw, int64_t ldo,
+    float* __restrict__ Dout) {
     constexpr int BQ = NWQ * 32, STAGE = 2 * TILE, NK = DH / 16, ND32 = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -585,7 +586,22 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     load_row_frags<DH>(qf, q + (int64_t)b * S * ldq + (int64_t)h * DH, ldq, qi, S, hi);
     load_row_frags<DH>(gf, gho + (int64_t)b * S * ldg + (int64_t)h * DH, ldg, qi, S, hi);
     const float lse2 = ((qi < S) ? lse[((int64_t)b * Hq + h) * S + qi] : 0.f) * LRP_LOG2E;
-    const float Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
+    float Dq;
+    if (ofw != nullptr) {
+        // D_i = sum_d Gho_i o_i from the rows themselves: the wave holds its 32 Gho rows as fragments anyway (two lanes per row, 64 columns each),
+        // so the stand-alone attn_bwd_prep pass (3 x 67 MB per layer at B 4 / S 2048) reduces to one more row read here; the dK / dV kernel, which
+        // runs after this one, takes D from Dout
+        bf16x8 of[NK];
+        load_row_frags<DH>(of, ofw + (int64_t)b * S * ldo + (int64_t)h * DH, ldo, qi, S, hi);
+        float sd = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sd += (float)gf[ks][e] * (float)of[ks][e];
+        sd += __shfl_xor(sd, 32);
+        Dq = sd;
+        if (hi == 0 && qi < S) Dout[((int64_t)b * Hq + h) * S + qi] = sd;
+    } else Dq = (qi < S) ? Dd[((int64_t)b * Hq + h) * S + qi] : 0.f;
     int ivlo = 0, ivhi = S;
     if (row_lo != nullptr && qi < S) { ivlo = row_lo[(int64_t)b * S + qi]; ivhi = row_hi[(int64_t)b * S + qi]; }
     f32x16 acc[ND32];
@@ -1741,10 +1757,11 @@ int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* 
     return lrp_check_launch();
 }
 
+// o != NULL: D is COMPUTED from (gho, o) and written to Dout (then D_ is not read)
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
                   int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
-                  hipStream_t st) {
+                  hipStream_t st, const void* o, int64_t ldo, float* Dout) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE);
     dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
@@ -1755,7 +1772,7 @@ int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, 
         LRP_SET_MAX_LDS(kern, lds);                                                                                                         \
         hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho, \
                            lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,         \
-                           q_begin, row_lo, row_hi);                                                                                       \
+                           q_begin, row_lo, row_hi, (const bf16_t*)o, ldo, Dout);                                                          \
     }
     A32_FOR_DH(d, { if (expl) A32_LAUNCH_DQ(true) else A32_LAUNCH_DQ(false) })
 #undef A32_LAUNCH_DQ

@@ -25,6 +25,8 @@ int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, vo
                                int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st);
 int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw,
                              int64_t ldout, hipStream_t st);
+int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
+                             int64_t ldout, hipStream_t st);
 int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
                                     int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
@@ -654,6 +656,21 @@ extern "C" int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, voi
     for (int m0 = 0; m0 < M; m0 += chunk) {
         const int rc = lrp_launch_gemm_pp_nt_rs((const char*)x + (int64_t)m0 * ldx * 2, W, rs + m0, (char*)out + (int64_t)m0 * ldout * 2,
                                                 M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw, ldout, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
+                              int64_t ldout, int dtype, void* stream) {
+    if (!s || !W || !rs || !out || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (!lrp_gemm_norm_fused_ok(M, N, K, lds_, ldw, 1, dtype)) return LRP_ESHAPE;
+    if (!a16(s) || !a16(W) || (ldout % 8)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(lds_);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_nn_rs((const char*)s + (int64_t)m0 * lds_ * 2, W, rs + m0, (char*)out + (int64_t)m0 * ldout * 2,
+                                                M - m0 < chunk ? M - m0 : chunk, N, K, lds_, ldw, ldout, (hipStream_t)stream);
         if (rc != LRP_OK) return rc;
     }
     return LRP_OK;

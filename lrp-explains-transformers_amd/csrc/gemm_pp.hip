@@ -881,6 +881,13 @@ int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void
     ep.rs = rs;
     return launch_pp_t<bf16_t, false, 0, 0, false, false, true>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
 }
+// out = rs (.) (s W) (NN: W [K, N] as stored)
+int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
+                             int64_t ldout, hipStream_t st) {
+    PPEpi ep{};
+    ep.rs = rs;
+    return launch_pp_t<bf16_t, true, 0, 0, false, false, true>(s, W, out, nullptr, M, N, K, lds_, ldw, ldout, 1, K / PP_KT, 0, ep, st);
+}
 // gate/up forward on the un-normalised rows: gu = rs (.) (x Wgu^T), m = act(g) (*) u
 int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
                                     int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st) {

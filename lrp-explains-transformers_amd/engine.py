@@ -442,6 +442,10 @@ class LlamaLRP:
         layer_R = [rel_last] if layer_relevance else None
         plain_add = E["add"] == 0.0 and E["lin"] == 0.0          # efficient placement: add2 / Linear eps factors are exactly 1
         nfb = plain_add and self._norm_fused(M)                  # K1n in the backward (independent of what the forward ran: both need only rstd)
+        # attn_bwd_prep folded away (efficient placement, the bf16 kernels that take every operand token-major, M = B S rows)
+        fuse_prep = (plain_add and E["pv"] == 0.0 and E["mask"] == 0.0 and E["qk"] == 0.0 and not self.attn_t and ops.attn_dq_d_ok(dt, d)
+                     and bool(self.layers) and ops.norm_fused_ok(M, nq * d, H, H, self.layers[0]["wo"].stride(0), True, dt))
+        half = ar.get("half", (M,), torch.float32).fill_(0.5) if fuse_prep else None
 
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
@@ -482,10 +486,15 @@ class LlamaLRP:
                         Aa = new("Aa", M, H)
                         ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln2"], st["rstd2"], st["h1"], st["a"], Gs1, Aa, None, 0.0, E["add"], E["lin"])
                 # ---- attention
-                Gof = self._lin_bwd(Aa, Lw["wo"], new("Gof", M, nq * d))
                 Gho = new("Gho", M, nq * d)
                 D = f32("D", B, nq, S)
-                ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
+                if fuse_prep:
+                    # no attn_bwd_prep pass: Gho = 1/2 (Aa Wo) straight out of the o-projection's dgrad (row scale 1/2: exact), and the dQ
+                    # kernel forms D = rowsum(Gho (*) o) from the rows it loads anyway and leaves it for the dK / dV kernel
+                    ops.gemm_nn_rs(Aa, Lw["wo"], half, Gho)
+                else:
+                    Gof = self._lin_bwd(Aa, Lw["wo"], new("Gof", M, nq * d))
+                    ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
             q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
             k_t = q_t = Gho_t = None
             if self.attn_t:        # kernels that read head-transposed copies (fp32, head dims other than 128)
@@ -494,8 +503,11 @@ class LlamaLRP:
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dqk = new("dqk", M, nqk) if q_begin == 0 else zeros("dqk", M, nqk)
             dk_h, dv_h = new("dk_h", M, nq * d), new("dv_h", M, nq * d)
-            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                            q_begin=q_begin, row_iv=row_iv)
+            if fuse_prep and q_begin == 0:
+                ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv)
+            else:
+                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                                q_begin=q_begin, row_iv=row_iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
                              q_begin=q_begin, row_iv=row_iv)
             ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
@@ -508,10 +520,14 @@ class LlamaLRP:
                 ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
                 ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
             rel = f32(("rel", li), M) if layer_relevance else None
-            if nfb and not layer_relevance and ops.norm_fusion_part("bwd_qkv"):
-                # K1n: Gs = rstd1 (.) (Aqkv W'qkv) + Gs1 -- the input norm's identity rule and the residual add in the qkv dgrad's epilogue
+            if nfb and ops.norm_fusion_part("bwd_qkv"):
+                # K1n: Gs = rstd1 (.) (Aqkv W'qkv) + Gs1 -- the input norm's identity rule and the residual add in the qkv dgrad's epilogue.  The
+                # layer relevance sum_j h_j G_j (a diagnostic) is then one read-out pass over the stored gradient: the SAME kernels serve the call
+                # with and without it (a prompt's relevance must not depend on the options of the call)
                 Gs = ops.gemm_nn_rs_res(Aqkv, Lw["wqkv"], st["rstd1"], Gs1, new(("Gs", li & 1), M, H))
                 Adn = Gs
+                if layer_relevance:
+                    layer_R.append(ops.readout(st["h"], Gs, out=rel))
                 continue
             Gx = self._lin_bwd(Aqkv, Lw["wqkv"], new("Gx", M, H))
             # ---- input norm + the residual add below (or the embedding)

@@ -570,6 +570,17 @@ def gemm_nt_rs(x, W, rs, out):
     return out
 
 
+def gemm_nn_rs(s, W, rs, out):
+    """out = rs[:, None] * (s @ W) from the STORED weight W [K, N] (rs = 1/2: the o-projection's dgrad with the uniform rule's factor)"""
+    M, K = s.shape
+    N = W.shape[1]
+    same(s, W, out)
+    f32(rs)
+    _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_nn_rs(p(s), p(W), p(rs), p(out), M, N, K, s.stride(0), W.stride(0), out.stride(0),
+                                                                     dt(s), stream()), "lrp_gemm_nn_rs")
+    return out
+
+
 def gemm_gated_fwd_rs(x, Wgu, rs, gu, m, act="silu"):
     M, K = x.shape
     I = m.shape[1]
@@ -699,10 +710,11 @@ def softmax_rule_bwd(x, pr, Rp, inv_temp=1.0):
     return Rx
 
 
-def readout(emb, G):
+def readout(emb, G, out=None):
     M, H = emb.shape
-    out = torch.empty(M, device=emb.device, dtype=torch.float32)
+    out = torch.empty(M, device=emb.device, dtype=torch.float32) if out is None else out
     same(emb, G)
+    f32(out)
     check(lib.lrp_readout(p(emb), p(G), p(out), M, H, dt(emb), stream()), "lrp_readout")
     return out
 
@@ -1002,6 +1014,24 @@ def attn_bwd_dq(q, k, v, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, eps_mask
                               k.stride(0), v.stride(0), k_t.stride(2) if k_t is not None else 0, Gho.stride(0), dq.stride(0),
                               scale, eps_mask, eps_qk,
                               int(causal), window, q_begin, *_iv(row_iv, B, S), dt(q), stream()), "lrp_attn_bwd_dq")
+    return dq
+
+
+PREP_FUSION = True       # module attribute: False = the stand-alone lrp_attn_bwd_prep pass (A/B measurements)
+
+
+def attn_dq_d_ok(dtype, d):
+    """lrp_attn_bwd_dq_d serves (dtype, d): the dQ kernel forms D = rowsum(Gho (*) o) itself (no attn_bwd_prep pass)"""
+    return bool(PREP_FUSION and dtype in _DT and lib.lrp_attn_bwd_dq_d_ok(_DT[dtype], d))
+
+
+def attn_bwd_dq_d(q, k, v, Gho, o, lse, D, dq, B, S, Hq, Hkv, d, scale, causal=True, window=0, row_iv=None):
+    """dQ of the lxt.efficient placement with D[b, h, s] = sum_d Gho o formed in the kernel and WRITTEN to D (for attn_bwd_dkv)"""
+    same(q, k, v, Gho, o, dq)
+    f32(lse, D)
+    check(lib.lrp_attn_bwd_dq_d(p(q), p(k), p(v), p(Gho), p(o), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v.stride(0),
+                                Gho.stride(0), o.stride(0), dq.stride(0), scale, int(causal), window, *_iv(row_iv, B, S), dt(q), stream()),
+          "lrp_attn_bwd_dq_d")
     return dq
 
 

@@ -395,6 +395,10 @@ def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     ops.gemm_nn_rs_res(A, W2, rstd, Gres, Gh)
     Gh_ref = rstd.double()[:, None] * (f64(A) @ f64(W2)) + f64(Gres)
     assert not torch.isnan(Gh).any() and nmax(Gh, Gh_ref) < 1e-2
+    half = torch.full((M,), 0.5, device="cuda")
+    Gq = torch.full((M, H), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_nn_rs(A, W2, half, Gq)                                                   # plain row scale: 1/2 x the dgrad, exact
+    assert torch.equal(Gq.float(), 0.5 * ops.linear_dgrad(A, W2).float())
     Gx = ops.linear_dgrad(A, W2)                                                      # stand-alone pair: dgrad, then the norm's backward kernel
     Gh2 = torch.empty_like(Gh)
     ops.rmsnorm_bwd_add2(Gres, Gx, torch.ones(H, dtype=bf, device="cuda"), rstd, None, None, Gh2, None, None, 0.0, 0.0, 0.0)
@@ -785,6 +789,12 @@ def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
     dq = torch.empty_like(qt)
     ops.attn_bwd_dq(qt, kt, vt, k_t, Gho, lse, D, dq, B, S, Hq, Hkv, d, scale, E["mask"], E["qk"], causal, window)
     assert nmax(dq, _tm(dQ)) < tol * 3
+    if mode == "efficient" and ops.attn_dq_d_ok(dtype, d):
+        # lrp_attn_bwd_dq_d: the same dQ with D = rowsum(Gho (*) o) formed inside the kernel (no prep pass) and handed on to dK / dV
+        D2, dq2 = torch.full_like(D, float("nan")), torch.full_like(dq, float("nan"))
+        ops.attn_bwd_dq_d(qt, kt, vt, Gho, o, lse, D2, dq2, B, S, Hq, Hkv, d, scale, causal, window)
+        assert not torch.isnan(D2).any() and torch.allclose(D2, D, rtol=1e-4, atol=1e-5 * float(D.abs().max()))
+        assert not torch.isnan(dq2).any() and nmax(dq2, dq) < 1e-2 and nmax(dq2, _tm(dQ)) < tol * 3
     dk_h, dv_h = torch.empty_like(qt), torch.empty_like(qt)
     ops.attn_bwd_dkv(qt, kt, vt, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, E["mask"], E["qk"], causal, window)
     dk, dv = torch.empty_like(kt), torch.empty_like(vt)
