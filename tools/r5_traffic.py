@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof", "pmc_summary.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof2", "pmc_summary.json")
 d = json.load(open(src))
 M, out = 8192, {}
 
@@ -19,13 +19,13 @@ def alg(N, K):
 
 
 def classify(name):
-    """-> (nn, epi, skinny) of a gemm_pp_kernel<bf16, NN, EPI, ACT, SK> row (mangled, or rocprof's half-demangled form), None otherwise"""
-    m = re.search(r"gemm_pp_kernelIDF16bLb(\d)ELi(\d)ELi\dELb(\d)E", name)
+    """-> (nn, epi, skinny, rs) of a gemm_pp_kernel<bf16, NN, EPI, ACT, SK, LEAN, RS> row (mangled, or rocprof's half-demangled form), None otherwise"""
+    m = re.search(r"gemm_pp_kernelIDF16bLb(\d)ELi(\d)ELi\dELb(\d)ELb\dELb(\d)E", name)
     if m:
-        return int(m.group(1)), int(m.group(2)), int(m.group(3))
-    m = re.search(r"gemm_pp_kernel<bool _Accum, bool, E, (\d), \d, (false|true)(?:, (?:false|true))?>", name)   # <bf16, true, EPI, ACT, SK[, LEAN]>: NN
+        return int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))
+    m = re.search(r"gemm_pp_kernel<bool _Accum, bool, E, (\d), \d, (false|true), (?:false|true), (false|true)>", name)   # <bf16, true, ...>: NN
     if m:
-        return 1, int(m.group(1)), int(m.group(2) == "true")
+        return 1, int(m.group(1)), int(m.group(2) == "true"), int(m.group(3) == "true")
     return None
 
 
@@ -40,16 +40,23 @@ def add(tag, key, algb):
 
 
 keys = {classify(k): k for k in d if classify(k) is not None}
-# one step of the 4-layer run (the top layer's o-proj / MLP run on one row per prompt): NT plain = 4 qkv + 3 o + 3 down forward,
-# NN plain = 3 gate/up dgrad + 3 o dgrad + 4 qkv dgrad
-a_nt = (4 * alg(6144, 4096) + 3 * alg(4096, 4096) + 3 * alg(4096, 14336)) / 10
-a_nn = (3 * alg(4096, 28672) + 3 * alg(4096, 4096) + 4 * alg(4096, 6144)) / 10
-add("plain_nt", keys[(0, 0, 0)], a_nt)
-add("plain_nn", keys[(1, 0, 0)], a_nn)
-add("gated_fwd", keys[(0, 1, 0)], alg(28672, 4096) + 2 * M * 14336)
-add("gated_bwd", keys[(1, 2, 0)], 2 * (M * 4096 + 14336 * 4096) + 2 * 2 * M * 28672)
-tt = sum(out[k]["traffic_bytes_per_launch"] * out[k]["launches"] for k in ("plain_nt", "plain_nn"))
-tn = sum(out[k]["launches"] for k in ("plain_nt", "plain_nn"))
+R = 2 * M * 4096                                   # one [M, 4096] bf16 operand of an epilogue (residual / residual gradient)
+# one step of the 4-layer run (top layer: o-proj / MLP on one row per prompt; K1n parts fwd + bwd_qkv, the o-projection's dgrad with the 1/2 row
+# scale): layer 0's qkv forward is the plain kernel, layers 1-3 take the row-scale form; o-proj + down forward of layers 0-2 carry the residual +
+# sum-of-squares epilogue; qkv dgrad x 4 the residual one; gate/up dgrad x 3 plain NN; o dgrad x 3 NN + row scale
+add("nt_plain (qkv fwd, layer 0)", keys[(0, 0, 0, 0)], alg(6144, 4096))
+add("nt_rowscale (qkv fwd)", keys[(0, 0, 0, 1)], alg(6144, 4096))
+add("nt_residual_ssq (o-proj, down fwd)", keys[(0, 3, 0, 0)], (alg(4096, 4096) + alg(4096, 14336)) / 2 + R)
+add("nn_plain (gate/up dgrad)", keys[(1, 0, 0, 0)], alg(4096, 28672))
+add("nn_rowscale (o dgrad)", keys[(1, 0, 0, 1)], alg(4096, 4096))
+add("nn_rowscale_residual (qkv dgrad)", keys[(1, 4, 0, 1)], alg(4096, 6144) + R)
+add("gated_fwd", keys[(0, 1, 0, 1)], alg(28672, 4096) + 2 * M * 14336)
+add("gated_bwd", keys[(1, 2, 0, 0)], 2 * (M * 4096 + 14336 * 4096) + 2 * 2 * M * 28672)
+roof = [k for k in out if not k.startswith("gated")]          # the kernel set of bench.py's roofline key: every launch but the two gated ones
+tt = sum(out[k]["traffic_bytes_per_launch"] * out[k]["launches"] for k in roof)
+ta = sum(out[k]["algorithmic_bytes_per_launch"] * out[k]["launches"] for k in roof)
+tn = sum(out[k]["launches"] for k in roof)
+a_nt = a_nn = ta / tn
 with open(os.path.join(ROOT, "lrp-explains-transformers_amd", "csrc", "gemm_pp.hip"), "rb") as f:
     sha = hashlib.sha256(f.read()).hexdigest()[:16]
 res = {"gemm_pp_sha16": sha, "traffic_bytes_per_launch": tt / tn, "algorithmic_bytes_per_launch": (a_nt + a_nn) / 2,
