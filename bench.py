@@ -149,6 +149,8 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
     layout, no W^T copy); the stabiliser is formed inside the dgrad kernel for M <= 16 (one 16-row block: beyond that its
     element-wise work outweighs the launch it saves, profiles/r04_call8_*.txt) and by a separate lrp_eps_scale launch above.  Headline entry = what explain() itself runs on its one-row-per-prompt path: the LM-head-sized Linear
     [vocab, hidden] at M = prompts per step.  `table` = M = 1 ... 160 on the gate/up-sized weight [14336, 4096] and on the LM head.
+    Weights in the ENGINE's layout (round 5): row pitch off the 4-KiB grid as `LlamaLRP` stores them (engine.weight_pitch_pad / pitch_pad: +256 / +128
+    bytes per row) -- with a pitch of exactly 8 KiB (28 KiB) the stream kernels ran 12-25 % slower (channel aliasing, bimodal with the allocation).
     Algorithmic bytes = sizeof * (N K + M K + M N) forward, sizeof * (N K + M K + 2 M N) backward; HIP events on the launching
     stream, 21 launches each, ROTATING through three distinct layer-sized weights (3 x 117 MB > the 256-MB Infinity Cache: the figure is
     an HBM figure); the LM head is 1.05 GB by itself."""
@@ -182,10 +184,10 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
 
         def bwd(i):      # eps-rule redistribution c = (g z/(z+eps)) W
             W = Ws[i % len(Ws)]
-            if M <= 2:
-                return ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the W stream (lane-local FMA kernel)
             if M <= 16 and ops.linear_stream_dgrad_ok(gg, W):
                 return ops.linear_stream_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the MFMA weight-streaming dgrad
+            if M <= 2:
+                return ops.linear_smallm_dgrad(gg, W, z=z, eps=1e-6, out=out)            # stabiliser fused into the W stream (lane-local FMA kernel)
             return ops.linear_dgrad(ops.eps_scale(gg, z, 1.0, 1e-6), W, out=out)
         bwd(0)
         tf = timed(fwd)
@@ -195,14 +197,19 @@ def smallm_roofline(ops, dtype, device, cfg, batch):
                     pair_GBs=(bf + bb) / (tf + tb) / 1e9, pair_frac=(bf + bb) / (tf + tb) / 1e9 / 8000.0)
 
     M = min(batch, 256)
+    import lxt_amd.engine as E_
     Wh = [(torch.randn(cfg["vocab"], cfg["hidden"], generator=g, device=device) * cfg["hidden"] ** -0.5).to(dtype)]      # 1.05 GB: beyond any cache
     head = pair(M, cfg["vocab"], cfg["hidden"], Wh)
     rows = (1, 2, 4, 8, 16, 32, 64, 128, 160)
-    Wl = [(torch.randn(cfg["inter"], cfg["hidden"], generator=g, device=device) * cfg["hidden"] ** -0.5).to(dtype) for _ in range(NROT)]
+    # layer-sized weights in the ENGINE's layout: stored-weight row pitch off the 4-KiB grid (engine.weight_pitch_pad: +256 bytes per row)
+    padw = E_.weight_pitch_pad(cfg["hidden"], es, cfg["inter"])
+    Wl = [(torch.randn(cfg["inter"], cfg["hidden"] + padw, generator=g, device=device) * cfg["hidden"] ** -0.5).to(dtype)[:, : cfg["hidden"]] for _ in range(NROT)]
     table = [pair(m, cfg["inter"], cfg["hidden"], Wl) for m in rows]
     del Wl
-    Wd = [(torch.randn(cfg["hidden"], cfg["inter"], generator=g, device=device) * cfg["inter"] ** -0.5).to(dtype) for _ in range(NROT)]
-    table_down = [pair(m, cfg["hidden"], cfg["inter"], Wd) for m in rows]          # the down-projection's shape [4096, 14336]
+    # the down-projection's shape [4096, 14336], in the engine's layout: row pitch off the 4-KiB grid (engine.pitch_pad: +128 bytes per row)
+    padc = E_.pitch_pad(cfg["inter"], es)
+    Wd = [(torch.randn(cfg["hidden"], cfg["inter"] + padc, generator=g, device=device) * cfg["inter"] ** -0.5).to(dtype)[:, : cfg["inter"]] for _ in range(NROT)]
+    table_down = [pair(m, cfg["hidden"], cfg["inter"], Wd) for m in rows]
     del Wd
     table_head = [pair(m, cfg["vocab"], cfg["hidden"], Wh) for m in rows]
     del Wh

@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes and lrp_attn_bwd_dq_d[_ok]; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok] and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -81,6 +81,15 @@ int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* bias, int M,
  * applies AND its ceil(N / 64) workgroups fill the chip (>= 192); otherwise the caller uses lrp_gemm_skinny.
  * ref: lxt/explicit/functional.py:345-351 (forward of linear_epsilon_fn), lxt/explicit/rules.py:188-205. */
 int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ldw);
+/* Round 5 (ABI 6): narrow weights (N = 4096: 64 workgroups of full K) run the same kernel with 2 ... 8 K SPLITS -- fp32 partial slabs in `ws`
+ * (lrp_linear_stream_fwd_ws bytes), summed inside the kernel by the last workgroup to arrive on a 64-row block (`tickets`:
+ * lrp_linear_stream_fwd_tickets zeroed 32-bit words, left zero again; slab order: deterministic) -- still ONE launch.  With ws / tickets NULL, or
+ * through lrp_linear_stream_fwd, the full-K form runs whatever the workgroup count. */
+int lrp_linear_stream_fwd_splits(int M, int N, int K);
+int64_t lrp_linear_stream_fwd_ws(int M, int N, int K);
+int lrp_linear_stream_fwd_tickets(int M, int N, int K);
+int lrp_linear_stream_fwd_tk(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
+                             int64_t ldz, int dtype, int out_dtype, void* ws, void* tickets, void* stream);
 int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
                           int64_t ldz, int dtype, int out_dtype, void* stream);
 

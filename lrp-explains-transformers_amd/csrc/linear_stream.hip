@@ -57,7 +57,8 @@ template <int I, int N, typename F> LRP_DEVICE void ls_for(F&& f) {
 template <typename TO, int MBMAX>
 __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, TO* __restrict__ z, const bf16_t* __restrict__ bias, int M, int N, int K,
-    int64_t ldx, int64_t ldw, int64_t ldz, int rw) {
+    int64_t ldx, int64_t ldw, int64_t ldz, int rw, int kt_per_split, int64_t slab_stride, unsigned* __restrict__ tickets,
+    void* __restrict__ fin, int64_t ldf, int fin_f32) {
     using C = LSCfg<MBMAX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -66,7 +67,11 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
     // 16 rows per wave is 224 workgroups, and a CU streams at ~23 GB/s whatever the others do: 32 idle CUs are 12.5 % of the bandwidth.  Rows
     // rw .. 15 of the wave's 16-row MFMA block are never fetched (offset beyond num_records: zero fill) and never stored.
     const int n0 = blockIdx.x * (4 * rw);
-    const int nkt = K / LS_KT;
+    // round 5 -- K SPLITS for narrow weights (N = 4096: 64 workgroups of full K would leave three quarters of the chip idle, and the split-K path of
+    // the ping-pong GEMM costs a second launch): blockIdx.y owns kt_per_split K tiles and writes an fp32 partial slab; the slabs of a column block
+    // are summed by the LAST workgroup to arrive on it (tickets: the protocol of the dgrad kernel below)
+    const int kt0 = (int)blockIdx.y * kt_per_split;
+    const int nkt = (gridDim.y > 1) ? kt_per_split : K / LS_KT;
     int nb = (M + 15) >> 4;
     nb = nb > MBMAX ? MBMAX : nb;
 
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
         for (int p = 0; p < C::P; ++p) {
             const int q = wave * C::P + p;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ls_lds_ptr_t)(smem + buf * C::XTILE + q * 1024), 16, voX,
-                                                     (int)((int64_t)(8 * q) * ldx * 2) + kt * 128, 0, 0);
+                                                     (int)((int64_t)(8 * q) * ldx * 2) + (kt + kt0) * 128, 0, 0);
         }
     };
     // fragment of row block i, k-step ks: row 16 i + (l & 15), chunk (4 ks + (l >> 4)) ^ (row & 7)
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ls_lds_ptr_t)(wring + s * 2048 + p * 1024), 16, voW[p],
-                                                     soW + (int)((int64_t)(8 * p) * ldw * 2) + kt * 128, 0, 2);
+                                                     soW + (int)((int64_t)(8 * p) * ldw * 2) + (kt + kt0) * 128, 0, 2);
     };
 
     // ---- prologue: W(0 .. WD - XD - 1), then [x(v), W(WD - XD + v)] for v = 0 .. XD - 1 (the order the steady state continues)
@@ -191,6 +196,55 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
             if (c16 + e < rw && ncol + e < N) bv[e] = to_f32(bias[ncol + e]);
     }
     const bool vec = (c16 + 3 < rw) && (ncol + 3 < N) && ((ncol & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
+    if constexpr (sizeof(TO) == 4) {
+        if (tickets != nullptr) {
+            // ---- split K: publish the partial quad (the host guarantees whole, aligned quads: rw = 16, N % 64 == 0), take a ticket, and the last
+            // arriver of the column block sums the slabs in slab order, adds the bias and writes z
+            float* const slab = reinterpret_cast<float*>(z) + (int64_t)blockIdx.y * slab_stride;
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i) {
+                const int m = 16 * i + (lane & 15);
+                if (i < nb && m < M) {
+                    uint64_t* d8 = reinterpret_cast<uint64_t*>(slab + (int64_t)m * ldz + ncol);
+                    const f32x2 lo = {acc[i][0], acc[i][1]}, hi2 = {acc[i][2], acc[i][3]};
+                    __hip_atomic_store(d8, __builtin_bit_cast(uint64_t, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d8 + 1, __builtin_bit_cast(uint64_t, hi2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                              // every wave's slab stores have left; the LDS rings are no longer read
+            unsigned* tk = reinterpret_cast<unsigned*>(smem);
+            if (threadIdx.x == 0) tk[0] = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned nsp = gridDim.y;
+            if (tk[0] != nsp - 1) return;
+            if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+#pragma unroll
+            for (int i = 0; i < MBMAX; ++i) {
+                const int m = 16 * i + (lane & 15);
+                if (i < nb && m < M) {
+                    const float* src = reinterpret_cast<const float*>(z) + (int64_t)m * ldz + ncol;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < (int)nsp) {
+                            uint64_t* s8 = reinterpret_cast<uint64_t*>(const_cast<float*>(src + (int64_t)k * slab_stride));
+                            const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const f32x2 hi2 = __builtin_bit_cast(f32x2, __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            const f32x4 pk = {lo[0], lo[1], hi2[0], hi2[1]};
+                            v = (k == 0) ? pk : v + pk;
+                        }
+                    v += bv;
+                    if (fin_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(fin) + (int64_t)m * ldf + ncol) = v;
+                    else {
+                        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(fin) + (int64_t)m * ldf + ncol) = o;
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MBMAX; ++i) {
         const int m = 16 * i + (lane & 15);
@@ -468,6 +522,18 @@ inline int dgrad_splits(int N, int Kout) {
     return 0;
 }
 
+// K splits of the forward for narrow weights: the smallest count in {2, 3, 4, 6, 8} that puts 192 ... 1024 workgroups of 64 rows on the chip with
+// whole 8-tile rings per split (1: the full-K form applies; 0: neither does)
+inline int fwd_splits(int N, int K) {
+    if (N < 1 || K < 512 || (K % 512)) return 0;
+    const int wgs = (N + 63) / 64;
+    if (wgs >= 192) return wgs <= 1024 ? 1 : 0;
+    if (N % 64) return 0;                                 // whole quads per lane in the slabs: 16 rows per wave
+    for (int s_ : {2, 3, 4, 6, 8})
+        if (wgs * s_ >= 192 && wgs * s_ <= 1024 && (K % (512 * s_)) == 0) return s_;
+    return 0;
+}
+
 template <typename TO, int MBMAX>
 int launch_stream(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
                   hipStream_t st) {
@@ -477,7 +543,20 @@ int launch_stream(const void* x, const void* W, const void* bias, void* z, int M
     LRP_SET_MAX_LDS(kern, lds);
     const int rw = stream_rows_per_wave(N);
     hipLaunchKernelGGL(kern, dim3((N + 4 * rw - 1) / (4 * rw)), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (TO*)z, (const bf16_t*)bias, M,
-                       N, K, ldx, ldw, ldz, rw);
+                       N, K, ldx, ldw, ldz, rw, 0, (int64_t)0, (unsigned*)nullptr, (void*)nullptr, (int64_t)0, 0);
+    return lrp_check_launch();
+}
+
+// split form: fp32 slabs [splits][M][N] in ws, summed in-kernel by the last arriver of each 64-row block into z
+template <int MBMAX>
+int launch_stream_split(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldz,
+                        int out_f32, int splits, void* ws, unsigned* tickets, hipStream_t st) {
+    using C = LSCfg<MBMAX>;
+    const size_t lds = (size_t)C::NBUF * C::XTILE + 4 * (size_t)LS_WD * 2048;
+    auto kern = linear_stream_fwd_kernel<float, MBMAX>;
+    LRP_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(N / 64, splits), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W, (float*)ws, (const bf16_t*)bias, M, N, K, ldx,
+                       ldw, (int64_t)N, 16, K / LS_KT / splits, (int64_t)M * N, tickets, z, ldz, out_f32);
     return lrp_check_launch();
 }
 
@@ -499,22 +578,43 @@ extern "C" int lrp_linear_stream_ok(int M, int N, int K, int64_t ldx, int64_t ld
     if (M < 1 || M > 128 || N < 1 || K < 512 || (K % 512)) return 0;
     if ((ldx % 8) || (ldw % 8) || ldx < K || ldw < K) return 0;
     if ((int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return 0;
-    // enough 64-row workgroups to put one on (nearly) every CU; for very many (the 128256-row LM head: 2004) the split-K path with its
-    // 256 x 256 tiles streams ~4 % faster (6.1 vs 5.8 TB/s, profiles/r04_call3_*.txt) and its second launch no longer matters
-    const int wgs = (N + 63) / 64;
-    return wgs >= 192 && wgs <= 1024;
+    // enough 64-row workgroups to put one on (nearly) every CU -- with K splits where the weight is narrow (round 5); for very many (the
+    // 128256-row LM head: 2004) the split-K path with its 256 x 256 tiles streams ~4 % faster (6.1 vs 5.8 TB/s, profiles/r04_call3_*.txt) and its
+    // second launch no longer matters
+    return fwd_splits(N, K) >= 1 ? 1 : 0;
 }
 
-extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
-                                     int64_t ldz, int dtype, int out_dtype, void* stream) {
+// K splits lrp_linear_stream_fwd_tk uses for the problem (1: none), its slab workspace in bytes and its ticket words (0 / 0 when not split)
+extern "C" int lrp_linear_stream_fwd_splits(int M, int N, int K) { return (M >= 1 && M <= 128) ? fwd_splits(N, K) : 0; }
+extern "C" int64_t lrp_linear_stream_fwd_ws(int M, int N, int K) {
+    const int s_ = lrp_linear_stream_fwd_splits(M, N, K);
+    return s_ > 1 ? (int64_t)s_ * M * N * 4 : 0;
+}
+extern "C" int lrp_linear_stream_fwd_tickets(int M, int N, int K) { return lrp_linear_stream_fwd_splits(M, N, K) > 1 ? N / 64 : 0; }
+
+extern "C" int lrp_linear_stream_fwd_tk(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                        int64_t ldz, int dtype, int out_dtype, void* ws, void* tickets, void* stream) {
     if (!x || !W || !z || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
     if (M == 0 || N == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (out_dtype != LRP_BF16 && out_dtype != LRP_F32)) return LRP_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (ldx % 8) || (ldw % 8)) return LRP_EALIGN;
     if (M > 128 || K < 512 || (K % 512) || ldx < K || ldw < K || (int64_t)N * ldw >= (1ll << 30) || (int64_t)M * ldx >= (1ll << 30)) return LRP_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    const int splits = (ws && tickets) ? fwd_splits(N, K) : 1;          // without the scratch: the full-K form, whatever the workgroup count
+    if (splits > 1) {
+        if ((reinterpret_cast<uintptr_t>(z) & 15) || (ldz % 4) || (reinterpret_cast<uintptr_t>(ws) & 15)) return LRP_EALIGN;
+        const int nb = (M + 15) / 16, f32o = out_dtype == LRP_F32 ? 1 : 0;
+        if (nb <= 2) return launch_stream_split<2>(x, W, bias, z, M, N, K, ldx, ldw, ldz, f32o, splits, ws, (unsigned*)tickets, st);
+        if (nb <= 4) return launch_stream_split<4>(x, W, bias, z, M, N, K, ldx, ldw, ldz, f32o, splits, ws, (unsigned*)tickets, st);
+        return launch_stream_split<8>(x, W, bias, z, M, N, K, ldx, ldw, ldz, f32o, splits, ws, (unsigned*)tickets, st);
+    }
     if (out_dtype == LRP_F32) return launch_stream_m<float>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
     return launch_stream_m<bf16_t>(x, W, bias, z, M, N, K, ldx, ldw, ldz, st);
+}
+
+extern "C" int lrp_linear_stream_fwd(const void* x, const void* W, const void* bias, void* z, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                     int64_t ldz, int dtype, int out_dtype, void* stream) {
+    return lrp_linear_stream_fwd_tk(x, W, bias, z, M, N, K, ldx, ldw, ldz, dtype, out_dtype, nullptr, nullptr, stream);
 }
 
 // fp32 slab reduction (+ cast) of gemm.hip's split-K path, re-used for the dgrad's contraction splits

@@ -816,6 +816,9 @@ def tail_split_cols(M, Nout, Kc):
 STREAM_FWD = True        # module attribute (A/B measurements): False sends every M <= 256 forward to the split-K skinny path
 
 
+STREAM_FWD_SPLITS = True    # module attribute (A/B measurements): False = narrow weights (N < 192 * 64) stay on the split-K skinny path
+
+
 def linear_stream_ok(x2, W):
     """does the one-launch weight-streaming forward (lrp_linear_stream_fwd: narrow-N, full-K, no split-K slabs) serve z = x2 W^T?  bf16,
     M <= 256 rows, K % 512 == 0, contiguous 16-byte aligned rows, and ceil(N / 64) workgroups that fill the chip"""
@@ -823,7 +826,9 @@ def linear_stream_ok(x2, W):
         return False
     if x2.stride(1) != 1 or W.stride(1) != 1 or x2.data_ptr() % 16 or W.data_ptr() % 16:
         return False
-    return bool(lib.lrp_linear_stream_ok(x2.shape[0], W.shape[0], x2.shape[1], x2.stride(0), W.stride(0)))
+    if not lib.lrp_linear_stream_ok(x2.shape[0], W.shape[0], x2.shape[1], x2.stride(0), W.stride(0)):
+        return False
+    return bool(STREAM_FWD_SPLITS or lib.lrp_linear_stream_fwd_splits(x2.shape[0], W.shape[0], x2.shape[1]) == 1)
 
 
 def linear_stream_fwd(x2, W, bias=None, out=None, out_dtype=None):
@@ -833,8 +838,11 @@ def linear_stream_fwd(x2, W, bias=None, out=None, out_dtype=None):
     same(x2, W)
     if out is None:
         out = torch.empty(M, N, device=x2.device, dtype=out_dtype or x2.dtype)
-    check(lib.lrp_linear_stream_fwd(p(x2), p(W), p(aux(bias, x2, N)), p(out), M, N, K, x2.stride(0), W.stride(0), out.stride(0), dt(x2),
-                                    _DT[out.dtype], stream()), "lrp_linear_stream_fwd")
+    need = lib.lrp_linear_stream_fwd_ws(M, N, K) if STREAM_FWD_SPLITS else 0      # narrow weights: K splits, slabs summed in-kernel (tickets)
+    ws = workspace(need, x2) if need else None
+    ntk = lib.lrp_linear_stream_fwd_tickets(M, N, K) if need else 0
+    check(lib.lrp_linear_stream_fwd_tk(p(x2), p(W), p(aux(bias, x2, N)), p(out), M, N, K, x2.stride(0), W.stride(0), out.stride(0), dt(x2),
+                                       _DT[out.dtype], p(ws), p(tickets(ntk, x2) if ntk else None), stream()), "lrp_linear_stream_fwd_tk")
     return out
 
 
@@ -912,7 +920,9 @@ def linear_stream_dgrad(s2, W, out=None, out_dtype=None, z=None, eps=0.0, releva
 def linear_dgrad(s2, W, out=None, out_dtype=None):
     """c[M,K] = s2[M,N] @ W[N,K]: the redistribution half of the Linear eps-rule (ref: lxt/explicit/functional.py:355-364) from the
     STORED weight layout:
-       2 < M <= 32, bf16, N % 128 == 0, Kout % 64 == 0        : lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings)
+       M <= 32, bf16, N % 128 == 0, Kout % 64 == 0            : lrp_linear_stream_dgrad (64-column workgroups, wave-private LDS rings; round 5: also
+                                                               for M <= 2 -- with the in-kernel slab reduction it is 1.5 ... 8 us ahead of the
+                                                               lane-local kernel there, tools/dgrad_m12.py)
        M <= 2, or M <= 16 where the NN kernel does not apply : W-streaming small-M dgrad
        M <= 256, bf16, N % 64 == 0                           : split-K skinny path, NN form
        bf16 problems of >= 190 tiles of 256 x 256            : lrp_gemm_nn (no W^T copy)
@@ -920,7 +930,7 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     M, N = s2.shape
     K = W.shape[1]
     odt = out_dtype or (out.dtype if out is not None else W.dtype)
-    if 2 < M <= 32 and linear_stream_dgrad_ok(s2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
+    if M <= 32 and linear_stream_dgrad_ok(s2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
         return linear_stream_dgrad(s2, W, out=out, out_dtype=odt)
     nn = gemm_nn_ok(s2, W)
     if (M <= 2 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:

@@ -139,7 +139,36 @@ def test_linear_stream_fwd(ops, M):
     # shapes the kernel refuses go to the split-K path (more than 128 rows; K not a multiple of 512; too few 64-row workgroups)
     assert not ops.linear_stream_ok(torch.empty(160, 4096, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096, dtype=torch.bfloat16, device="cuda"))
     assert not ops.linear_stream_ok(torch.empty(4, 4096 + 64, dtype=torch.bfloat16, device="cuda"), torch.empty(14336, 4096 + 64, dtype=torch.bfloat16, device="cuda"))
-    assert not ops.linear_stream_ok(torch.empty(4, 4096, dtype=torch.bfloat16, device="cuda"), torch.empty(4096, 4096, dtype=torch.bfloat16, device="cuda"))
+    assert not ops.linear_stream_ok(torch.empty(4, 4096, dtype=torch.bfloat16, device="cuda"), torch.empty(1024, 4096, dtype=torch.bfloat16, device="cuda"))
+    # round 5 -- narrow weights: the same kernel with K splits, the fp32 slabs summed in-kernel by the last arriver of a 64-row block (still one
+    # launch; lrp_linear_stream_fwd_tk).  [4096, 14336] (the down projection: 4 splits of 56 K tiles), [4096, 4096] (4 x 16), [8192, 2048] (2 x 16);
+    # repeated calls (the ticket words must come back to zero), bias, both output dtypes, row independence, and the split-K skinny path beside it
+    for (N, K) in ((4096, 14336), (4096, 4096), (8192, 2048)):
+        x = torch.randn(M, K, generator=g).bfloat16().cuda()
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        bias = torch.randn(N, generator=g).bfloat16().cuda() if (M + N // 4096) % 2 else None
+        assert ops.linear_stream_ok(x, W) and ops.lib.lrp_linear_stream_fwd_splits(M, N, K) in (2, 4)
+        ref = f64(x) @ f64(W).T + (f64(bias) if bias is not None else 0.0)
+        for odt, tol in ((torch.float32, 2e-5), (torch.bfloat16, TOL[torch.bfloat16])):
+            outs = []
+            for rep in range(3):
+                out = torch.full((M, N), float("nan"), dtype=odt, device="cuda")
+                ops.linear_stream_fwd(x, W, bias, out=out)
+                outs.append(out)
+            assert not torch.isnan(outs[0]).any() and nmax(outs[0], ref) < tol, (M, N, K, odt, nmax(outs[0], ref))
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        z = ops.linear_fwd(x, W, bias)
+        assert torch.equal(z, outs[0])
+        if M > 1:
+            assert torch.equal(ops.linear_stream_fwd(x[: M - 1], W, bias), z[: M - 1])
+        keep = ops.STREAM_FWD_SPLITS
+        ops.STREAM_FWD_SPLITS = False
+        try:
+            assert not ops.linear_stream_ok(x, W)
+            z2 = ops.linear_fwd(x, W, bias)                                    # split-K skinny path of the ping-pong GEMM: two launches
+        finally:
+            ops.STREAM_FWD_SPLITS = keep
+        assert nmax(z2, z) < 1e-2
 
 
 @pytest.mark.parametrize("M", [1, 3, 16, 17, 33, 64])
