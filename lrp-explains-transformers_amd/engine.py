@@ -114,9 +114,11 @@ def weight_pitch_pad(cols, elem_size, rows=0):
     (in = 4096 in bf16) puts a column block of every row on the same memory channels.  Measured on MI355X, M = 8192 (tools/nn_pitch_probe.py,
     profiles/r05_gemm_experiments.txt): the [28672, 4096] gate/up weight 1418 -> 1274 us with 128 bytes of padding per row, 1237 us (1357 -> 1555
     TFLOP/s) with 256; the [6144, 4096] qkv weight 271 -> 267 us; the cache-resident [4096, 4096] o weight and the [4096, 14336] down weight:
-    nothing.  256 bytes where the pitch is a multiple of 4 KiB and the weight is at least 32 MB."""
+    nothing.  256 bytes where the pitch is a multiple of 1 KiB and the weight is at least 32 MB."""
     nbytes = cols * elem_size
-    if not PITCH_PAD or nbytes % 4096 != 0 or rows * nbytes < (32 << 20):
+    # (round 5, Gemma-3-4B's [20480, 2560] gate/up weight: a pitch of 5 KiB -- a multiple of 1 KiB, not of 4 -- aliases too: dgrad 751 -> 650 us,
+    # forward 612 -> 588 us with the same 256 bytes, tools/gemma_pitch_probe.py; the L2-resident qkv / o weights and SigLIP's: nothing)
+    if not PITCH_PAD or nbytes % 1024 != 0 or rows * nbytes < (32 << 20):
         return 0
     return 256 // elem_size
 

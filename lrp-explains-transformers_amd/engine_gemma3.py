@@ -18,7 +18,7 @@ activations live in the same tagged arena as the Llama driver's.
 import torch
 
 from . import ops
-from .engine import EFFICIENT, LlamaLRP, pitch_pad
+from .engine import EFFICIENT, LlamaLRP, pitch_pad, weight_pitch_pad
 
 _STATIC_ROPE = ("default", "linear")
 
@@ -96,7 +96,8 @@ class Gemma3LRP:
         es = torch.empty(0, dtype=dtype).element_size()
         up = lambda n: (n + 63) // 64 * 64                                   # noqa: E731
         tied = W["lm_head"].data_ptr() == W["embed"].data_ptr()
-        per_layer = 4 * up(H) + 2 * up(d) + up(nqkv * H) + up(H * nq * d) + up(2 * I * H) + up(H * (I + pitch_pad(I, es)))
+        wpad = weight_pitch_pad(H, es, 2 * I)              # gate/up weight: stored row pitch off the 1-KiB grid (its dgrad strides over the rows)
+        per_layer = 4 * up(H) + 2 * up(d) + up(nqkv * H) + up(H * nq * d) + up(2 * I * (H + wpad)) + up(H * (I + pitch_pad(I, es)))
         total = (1 if tied else 2) * up(V * H) + up(H) + len(W["layers"]) * per_layer
         self.flat = torch.empty(total, device=dev, dtype=dtype)          # ONE buffer: a multi-GPU start-up is a single broadcast
         cursor = [0]
@@ -126,7 +127,7 @@ class Gemma3LRP:
                 ln_in=put(take(H), L["ln_in"]), ln_pa=put(take(H), L["ln_pa"]), ln_pf=put(take(H), L["ln_pf"]), ln_pff=put(take(H), L["ln_pff"]),
                 qn=put(take(d), L["qn"]), kn=put(take(d), L["kn"]),
                 wqkv=put(take(nqkv, H), L["wq"], L["wk"], L["wv"]), wo=put(take(H, nq * d), L["wo"]),
-                wgu=ops.interleave_gate_up(L["wg"].to(device=dev, dtype=dtype), L["wu"].to(device=dev, dtype=dtype), out=take(2 * I, H)),
+                wgu=ops.interleave_gate_up(L["wg"].to(device=dev, dtype=dtype), L["wu"].to(device=dev, dtype=dtype), out=take(2 * I, H + wpad)[:, :H]),
                 wd=put(take(H, I + pad)[:, :I], L["wd"])))
         self.attn_t = ops.attn_needs_transposed(self.embed, d)
         # rotary tables per layer type (HF hands cos / sin to the layers in the model dtype: keep that rounding, store fp32)
