@@ -515,10 +515,12 @@ def ensure_gemm_scratch(device=None):
 
 
 # ---- K1n: RMSNorm folded into the GEMMs around it (include/lrp_hip.h; ref lxt/efficient/patches.py:111-123 + the residual sums of HF modeling_llama)
-# module attribute: False = the stand-alone add_rmsnorm_fwd / rmsnorm_bwd_add2 launches (A/B measurements, equality tests); True = every part;
-# a set of {"fwd", "bwd_qkv", "bwd_gu"} = the named parts.  Default: everything but the gate/up dgrad -- its residual epilogue costs more than
-# the stand-alone kernel it replaces (tools/k1n_shapes.py at M = 8192: 1312 us fused against 1258 + 31 us; the other five GEMMs gain 13-34 us each)
-NORM_FUSION = frozenset({"fwd", "bwd_qkv"})
+# module attribute: True (default) = every part; False = the stand-alone add_rmsnorm_fwd / rmsnorm_bwd_add2 launches (A/B measurements, equality
+# tests); a set of {"fwd", "bwd_qkv", "bwd_gu"} = the named parts.  In situ, 8-layer judged step (tools/r5_k1n_parts.sh, final kernel, three
+# interleaved repeats): all parts 43.58-43.67 ms, without the gate/up dgrad's residual epilogue 43.62-43.78, none 44.15-44.34 (+1.5 %).  (The first
+# version of the residual epilogue -- two row blocks in flight, loads requested at the start of the epilogue -- LOST on the gate/up dgrad: 1312 us
+# against 1258 + 31.)
+NORM_FUSION = True
 
 
 def norm_fusion_part(part):

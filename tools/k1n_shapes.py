@@ -7,6 +7,7 @@ import lxt_amd.ops as ops
 import lxt_amd.engine as E
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+RPAD = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # extra elements per row of the residual-stream operands (h, out, Gres)
 H, I, NQKV = 4096, 14336, 6144
 bf, dev = torch.bfloat16, "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -14,13 +15,13 @@ rn = lambda r, c, pad=0, sc=1.0: (torch.randn(r, c + pad, generator=g, device=de
 wpad = lambda rows, cols: E.weight_pitch_pad(cols, 2, rows)      # noqa: E731
 Wo, Wd = rn(H, H, sc=H ** -0.5), rn(H, I, E.pitch_pad(I, 2), sc=I ** -0.5)
 Wqkv, Wgu = rn(NQKV, H, wpad(NQKV, H), sc=H ** -0.5), rn(2 * I, H, wpad(2 * I, H), sc=H ** -0.5)
-o, h, m = rn(M, H), rn(M, H), rn(M, I, E.pitch_pad(I, 2))
+o, h, m = rn(M, H), rn(M, H, RPAD), rn(M, I, E.pitch_pad(I, 2))
 Aqkv, Agu = rn(M, NQKV), rn(M, 2 * I, E.pitch_pad(2 * I, 2))
 ones = torch.ones(H, dtype=bf, device=dev)
-out, out2, x = torch.empty(M, H, dtype=bf, device=dev), torch.empty(M, H, dtype=bf, device=dev), torch.empty(M, H, dtype=bf, device=dev)
+out, out2, x = torch.empty(M, H, dtype=bf, device=dev), torch.empty(M, H + RPAD, dtype=bf, device=dev)[:, :H], torch.empty(M, H, dtype=bf, device=dev)
 ssq, rstd = torch.empty(H // 64, M, device=dev), torch.rand(M, device=dev) + 0.5
 qkv, gu, mm = torch.empty(M, NQKV, dtype=bf, device=dev), torch.empty(M, 2 * I, dtype=bf, device=dev), torch.empty(M, I, dtype=bf, device=dev)
-Gres = rn(M, H)
+Gres = rn(M, H, RPAD)
 
 
 def timed(fn, n=8):
@@ -49,7 +50,7 @@ cases = {
     "gate/up dgrad [rstd (Agu Wgu) + Gres]": (lambda: (ops.linear_dgrad(Agu, Wgu, out=out), ops.rmsnorm_bwd_add2(Gres, out, ones, rstd, None, None, out2, None, None, 0.0, 0.0, 0.0)),
                                              lambda: ops.gemm_nn_rs_res(Agu, Wgu, rstd, Gres, out2), lambda: ops.linear_dgrad(Agu, Wgu, out=out)),
 }
-print(f"M = {M}; us per call: stand-alone pair | K1n | (GEMM alone)")
+print(f"M = {M}, residual-stream row pad {RPAD}; us per call: stand-alone pair | K1n | (GEMM alone)")
 for name, (pair, fused, alone) in cases.items():
     tp, tf, ta = [], [], []
     for _ in range(3):
