@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof2", "pmc_summary.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof3", "pmc_summary.json")
 d = json.load(open(src))
 M, out = 8192, {}
 
@@ -43,13 +43,16 @@ keys = {classify(k): k for k in d if classify(k) is not None}
 R = 2 * M * 4096                                   # one [M, 4096] bf16 operand of an epilogue (residual / residual gradient)
 # one step of the 4-layer run (top layer: o-proj / MLP on one row per prompt; K1n parts fwd + bwd_qkv, the o-projection's dgrad with the 1/2 row
 # scale): layer 0's qkv forward is the plain kernel, layers 1-3 take the row-scale form; o-proj + down forward of layers 0-2 carry the residual +
-# sum-of-squares epilogue; qkv dgrad x 4 the residual one; gate/up dgrad x 3 plain NN; o dgrad x 3 NN + row scale
+# sum-of-squares epilogue; qkv dgrad x 4 and gate/up dgrad x 3 the residual one; o dgrad x 3 NN + row scale
 add("nt_plain (qkv fwd, layer 0)", keys[(0, 0, 0, 0)], alg(6144, 4096))
 add("nt_rowscale (qkv fwd)", keys[(0, 0, 0, 1)], alg(6144, 4096))
 add("nt_residual_ssq (o-proj, down fwd)", keys[(0, 3, 0, 0)], (alg(4096, 4096) + alg(4096, 14336)) / 2 + R)
-add("nn_plain (gate/up dgrad)", keys[(1, 0, 0, 0)], alg(4096, 28672))
+if (1, 0, 0, 0) in keys:                       # (gate/up dgrad as the plain kernel: ops.NORM_FUSION without "bwd_gu")
+    add("nn_plain (gate/up dgrad)", keys[(1, 0, 0, 0)], alg(4096, 28672))
+    add("nn_rowscale_residual (qkv dgrad)", keys[(1, 4, 0, 1)], alg(4096, 6144) + R)
+else:                                          # default: 4 qkv dgrads + 3 gate/up dgrads per step carry the residual epilogue
+    add("nn_rowscale_residual (qkv, gate/up dgrad)", keys[(1, 4, 0, 1)], (4 * alg(4096, 6144) + 3 * alg(4096, 28672)) / 7 + R)
 add("nn_rowscale (o dgrad)", keys[(1, 0, 0, 1)], alg(4096, 4096))
-add("nn_rowscale_residual (qkv dgrad)", keys[(1, 4, 0, 1)], alg(4096, 6144) + R)
 add("gated_fwd", keys[(0, 1, 0, 1)], alg(28672, 4096) + 2 * M * 14336)
 add("gated_bwd", keys[(1, 2, 0, 0)], 2 * (M * 4096 + 14336 * 4096) + 2 * 2 * M * 28672)
 roof = [k for k in out if not k.startswith("gated")]          # the kernel set of bench.py's roofline key: every launch but the two gated ones
