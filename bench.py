@@ -500,6 +500,7 @@ def main():
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     ap.add_argument("--unfused-gated", action="store_true", help="A/B knob: gated-MLP rules as separate kernels (ops.GATED_FUSION = False)")
     ap.add_argument("--dephase", action="store_true", help="A/B knob: de-phased GEMM tile walk (ops.GEMM_DEPHASE = True: scratch registered; measured negative)")
+    ap.add_argument("--no-rope-bwd-fusion", action="store_true", help="A/B knob: stand-alone rope_bwd pass (ops.ROPE_BWD_FUSION = False)")
     ap.add_argument("--no-prep-fusion", action="store_true", help="A/B knob: stand-alone attn_bwd_prep pass (ops.PREP_FUSION = False)")
     ap.add_argument("--norm-fusion-parts", default="", help="A/B knob: comma-separated subset of fwd,bwd_qkv,bwd_gu (ops.NORM_FUSION as a set)")
     ap.add_argument("--no-norm-fusion", action="store_true", help="A/B knob: RMSNorm / residual sums as stand-alone kernels (ops.NORM_FUSION = False)")
@@ -521,6 +522,7 @@ def main():
     E.PITCH_PAD = not args.no_pitch_pad
     ops.GEMM_DEPHASE = bool(args.dephase)
     ops.PREP_FUSION = not args.no_prep_fusion
+    ops.ROPE_BWD_FUSION = not args.no_rope_bwd_fusion
     if args.no_norm_fusion:
         ops.NORM_FUSION = False
     if args.norm_fusion_parts:

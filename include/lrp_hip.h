@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok] and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -373,7 +373,14 @@ int lrp_attn_bwd_dq(const void* q, const void* k, const void* v, const void* k_t
 int lrp_attn_bwd_dq_d_ok(int dtype, int d);
 int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, const void* Gho, const void* o, const float* lse, float* D, void* dq,
                       int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldgho, int64_t ldo, int64_t lddq,
-                      float scale, int causal, int window, const int* row_lo, const int* row_hi, int dtype, void* stream);
+                      float scale, int causal, int window, const int* row_lo, const int* row_hi, const float* cos_t, const float* sin_t,
+                      int dtype, void* stream);
+/* cos_t / sin_t (fp32 [S, d], NULL = none; d = 64 or 128): RoPE's backward applied to dQ on its way out of the kernel -- and, for dK, inside the
+ * group sum: lrp_gqa_reduce_rope(dk_h [rows, Hkv rep d] -> out [rows, Hkv d]) sums the rep query heads of a kv head and applies the transposed
+ * rotation (rotate-half pairs (c, c + d/2), position = row % seq) in one pass.  Together they replace the lrp_rope_bwd launch of the
+ * lxt.efficient placement (no stabiliser on the rotation: lxt/explicit/models/llama.py:226-260 with eps = 0 = HF's apply_rotary_pos_emb VJP). */
+int lrp_gqa_reduce_rope(const void* in, void* out, int64_t rows, int seq, int Hkv, int rep, int d, int64_t ld_in, int64_t ld_out,
+                        const float* cos_t, const float* sin_t, int dtype, void* stream);
 int lrp_attn_bwd_dkv(const void* q, const void* k, const void* v, const void* q_t, const void* Gho,
                      const void* Gho_t, const float* lse, const float* D, void* dk_h, void* dv_h,
                      int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv,

@@ -1059,6 +1059,43 @@ __global__ void gqa_reduce_kernel(const T* in, T* out, int64_t rows, int Hkv, in
     }
 }
 
+// group sum of the per-query-head dK + the inverse rotation of RoPE (rotate-half pairs (c, c + d/2), efficient placement: plain transposed
+// rotation a1 = g1 cos(c) + g2 sin(c + d/2), a2 = g2 cos(c + d/2) - g1 sin(c), the formula of rope_bwd_kernel with eps = 0) in ONE pass
+template <typename T>
+__global__ void gqa_reduce_rope_kernel(const T* in, T* out, int64_t rows, int seq, int Hkv, int rep, int d, int64_t ld_in, int64_t ld_out,
+                                       const float* __restrict__ cs, const float* __restrict__ sn) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int hd = d / 2, cpr = hd / EPC;
+    const int64_t total = rows * Hkv * cpr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * EPC;
+        const int64_t rh = i / cpr;
+        const int hk = (int)(rh % Hkv);
+        const int64_t r = rh / Hkv;
+        const int pos = (int)(r % seq);
+        float g1[EPC], g2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g1[e] = g2[e] = 0.f;
+        for (int gq = 0; gq < rep; ++gq) {
+            const T* p = in + r * ld_in + (int64_t)(hk * rep + gq) * d + c;
+            const Vec16<T> t1 = ld16(p), t2 = ld16(p + hd);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { g1[e] += t1.get(e); g2[e] += t2.get(e); }
+        }
+        const float* pc = cs + (int64_t)pos * d + c;
+        const float* ps = sn + (int64_t)pos * d + c;
+        Vec16<T> o1, o2;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            o1.set(e, g1[e] * pc[e] + g2[e] * ps[e + hd]);
+            o2.set(e, g2[e] * pc[e + hd] - g1[e] * ps[e]);
+        }
+        T* po = out + r * ld_out + (int64_t)hk * d + c;
+        st16(po, o1);
+        st16(po + hd, o2);
+    }
+}
+
 template <typename K> void set_lds(K kern, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1074,7 +1111,8 @@ int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* 
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
                   int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
-                  hipStream_t st, const void* o = nullptr, int64_t ldo = 0, float* Dout = nullptr);
+                  hipStream_t st, const void* o = nullptr, int64_t ldo = 0, float* Dout = nullptr, const float* cos_t = nullptr,
+                  const float* sin_t = nullptr);
 int lrp_attn32_dkv(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dk,
                    void* dv, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddk,
                    int64_t lddv, float scale, float eps_mask, float eps_qk, int causal, int window, int q_begin,
@@ -1246,7 +1284,9 @@ extern "C" int lrp_attn_bwd_dq_d_ok(int dtype, int d) { return (use_attn32(dtype
 extern "C" int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, const void* Gho, const void* o, const float* lse, float* D,
                                  void* dq, int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldgho,
                                  int64_t ldo, int64_t lddq, float scale, int causal, int window, const int* row_lo, const int* row_hi,
-                                 int dtype, void* stream) {
+                                 const float* cos_t, const float* sin_t, int dtype, void* stream) {
+    if ((cos_t == nullptr) != (sin_t == nullptr)) return LRP_EINVAL;
+    if (cos_t && d != 64 && d != 128) return LRP_ESHAPE;                // the rotation's partner column d/2 away must be a whole 32-column block
     if ((row_lo == nullptr) != (row_hi == nullptr)) return LRP_EINVAL;
     if (!q || !k || !v || !Gho || !o || !lse || !D || !dq) return LRP_EINVAL;
     int rc = attn_common_check(B, S, Hq, Hkv, d, dtype, scale);
@@ -1256,7 +1296,7 @@ extern "C" int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, co
     if (!al16(q) || !al16(k) || !al16(v) || !al16(Gho) || !al16(o) || !al16(dq) || (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldgho % 8) ||
         (ldo % 8) || (lddq % 4)) return LRP_EALIGN;
     return lrp_attn32_dq(q, k, v, Gho, lse, nullptr, dq, B, S, Hq, Hkv, d, ldq, ldk, ldv, ldgho, lddq, scale, 0.f, 0.f, causal, window, 0,
-                         row_lo, row_hi, (hipStream_t)stream, o, ldo, D);
+                         row_lo, row_hi, (hipStream_t)stream, o, ldo, D, cos_t, sin_t);
 }
 
 template <typename T>
@@ -1351,5 +1391,21 @@ extern "C" int lrp_gqa_reduce(const void* in, void* out, int64_t rows, int Hkv, 
     if (nb > 2048) nb = 2048;
     if (dtype == LRP_F32) hipLaunchKernelGGL((gqa_reduce_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)in, (float*)out, rows, Hkv, rep, d, ld_in, ld_out);
     else hipLaunchKernelGGL((gqa_reduce_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, Hkv, rep, d, ld_in, ld_out);
+    return lrp_check_launch();
+}
+
+extern "C" int lrp_gqa_reduce_rope(const void* in, void* out, int64_t rows, int seq, int Hkv, int rep, int d, int64_t ld_in, int64_t ld_out,
+                                   const float* cos_t, const float* sin_t, int dtype, void* stream) {
+    if (!in || !out || !cos_t || !sin_t || rows < 0 || seq < 1 || Hkv < 1 || rep < 1 || d < 2 || (d & 1)) return LRP_EINVAL;
+    if (rows == 0) return LRP_OK;
+    if (dtype != LRP_F32 && dtype != LRP_BF16) return LRP_EINVAL;
+    const int epc = dtype == LRP_F32 ? 4 : 8;
+    if (!al16(in) || !al16(out) || ((d / 2) % epc) || (ld_in % epc) || (ld_out % epc)) return LRP_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = rows * Hkv * (d / 2 / epc);
+    int64_t nb = (work + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (dtype == LRP_F32) hipLaunchKernelGGL((gqa_reduce_rope_kernel<float>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)in, (float*)out, rows, seq, Hkv, rep, d, ld_in, ld_out, cos_t, sin_t);
+    else hipLaunchKernelGGL((gqa_reduce_rope_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, seq, Hkv, rep, d, ld_in, ld_out, cos_t, sin_t);
     return lrp_check_launch();
 }

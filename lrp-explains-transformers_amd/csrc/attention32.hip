@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
     const float* __restrict__ lse, const float* __restrict__ Dd, bf16_t* __restrict__ dq, int S, int Hq, int Hkv, int64_t ldq,
     int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale, float eps_mask, float eps_qk, int causal, int window,
     int B, int q_begin, const int* __restrict__ row_lo, const int* __restrict__ row_hi, const bf16_t* __restrict__ ofw, int64_t ldo,
-    float* __restrict__ Dout) {
+    float* __restrict__ Dout, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin) {
     constexpr int BQ = NWQ * 32, STAGE = 2 * TILE, NK = DH / 16, ND32 = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -724,7 +724,32 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
         }
         cur ^= 1;
     }
-    store_rows<DH>(dq + (int64_t)b * S * lddq + (int64_t)h * DH, lddq, qi, S, acc, EXPL ? 1.f : 0.5f * scale, hi);
+    const float omul = EXPL ? 1.f : 0.5f * scale;
+    if constexpr (!EXPL && (DH == 64 || DH == 128)) {
+        if (rope_cos != nullptr) {
+            // RoPE's backward on the way out (round 5: no rope_bwd pass over dQ): the rotate-half partner of column c is c + DH/2 = the SAME lane's
+            // accumulator block db + ND32/2 -- a1 = g1 cos(c) + g2 sin(c + DH/2), a2 = g2 cos(c + DH/2) - g1 sin(c) at the row's position, in fp32
+            // on the un-rounded gradients (the formula of rope_bwd_kernel with both stabilisers 0)
+            const int pos = qi < S ? qi : 0;
+            const float* pc = rope_cos + (int64_t)pos * DH;
+            const float* ps = rope_sin + (int64_t)pos * DH;
+#pragma unroll
+            for (int db = 0; db < ND32 / 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = db * 32 + 8 * i + 4 * hi;
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pc + c), c2 = *reinterpret_cast<const f32x4*>(pc + c + DH / 2);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(ps + c), s2 = *reinterpret_cast<const f32x4*>(ps + c + DH / 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g1 = acc[db][4 * i + e], g2 = acc[db + ND32 / 2][4 * i + e];
+                        acc[db][4 * i + e] = g1 * c1[e] + g2 * s2[e];
+                        acc[db + ND32 / 2][4 * i + e] = g2 * c2[e] - g1 * s1[e];
+                    }
+                }
+        }
+    }
+    store_rows<DH>(dq + (int64_t)b * S * lddq + (int64_t)h * DH, lddq, qi, S, acc, omul, hi);
 #ifdef A32_TIMELINE
     if (lane == 0 && qw < S) {
         uint32_t* w = reinterpret_cast<uint32_t*>(dq + ((int64_t)b * S + qw) * lddq + (int64_t)h * DH);
@@ -1761,7 +1786,7 @@ int lrp_attn32_fwd(const void* q, const void* k, const void* v, void* o, float* 
 int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, const float* lse, const float* D_, void* dq, int B,
                   int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldg, int64_t lddq, float scale,
                   float eps_mask, float eps_qk, int causal, int window, int q_begin, const int* row_lo, const int* row_hi,
-                  hipStream_t st, const void* o, int64_t ldo, float* Dout) {
+                  hipStream_t st, const void* o, int64_t ldo, float* Dout, const float* cos_t, const float* sin_t) {
     using namespace attn32;
     const size_t lds = 2 * (2 * (size_t)TILE);
     dim3 grid(xcd_group_grid(B * Hkv, (Hq / Hkv) * ((S + NWQ * 32 - 1) / (NWQ * 32))));
@@ -1772,7 +1797,7 @@ int lrp_attn32_dq(const void* q, const void* k, const void* v, const void* gho, 
         LRP_SET_MAX_LDS(kern, lds);                                                                                                         \
         hipLaunchKernelGGL(kern, grid, dim3(NWQ * 64), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)gho, \
                            lse, D_, (bf16_t*)dq, S, Hq, Hkv, ldq, ldk, ldv, ldg, lddq, scale, eps_mask, eps_qk, causal, window, B,         \
-                           q_begin, row_lo, row_hi, (const bf16_t*)o, ldo, Dout);                                                          \
+                           q_begin, row_lo, row_hi, (const bf16_t*)o, ldo, Dout, cos_t, sin_t);                                            \
     }
     A32_FOR_DH(d, { if (expl) A32_LAUNCH_DQ(true) else A32_LAUNCH_DQ(false) })
 #undef A32_LAUNCH_DQ

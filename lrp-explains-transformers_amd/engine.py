@@ -448,6 +448,7 @@ class LlamaLRP:
         fuse_prep = (plain_add and E["pv"] == 0.0 and E["mask"] == 0.0 and E["qk"] == 0.0 and not self.attn_t and ops.attn_dq_d_ok(dt, d)
                      and bool(self.layers) and ops.norm_fused_ok(M, nq * d, H, H, self.layers[0]["wo"].stride(0), True, dt))
         half = ar.get("half", (M,), torch.float32).fill_(0.5) if fuse_prep else None
+        fuse_rope = fuse_prep and ops.ROPE_BWD_FUSION and E["rope"] == 0.0 and E["lin"] == 0.0 and d in (64, 128) and S <= self.max_seq
 
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
@@ -503,24 +504,32 @@ class LlamaLRP:
                 k_t = ops.transpose_heads(k, B, S, nk, d)
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
-            dqk = new("dqk", M, nqk) if q_begin == 0 else zeros("dqk", M, nqk)
             dk_h, dv_h = new("dk_h", M, nq * d), new("dv_h", M, nq * d)
-            if fuse_prep and q_begin == 0:
-                ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv)
-            else:
-                ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                                q_begin=q_begin, row_iv=row_iv)
-            ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
-                             q_begin=q_begin, row_iv=row_iv)
-            ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
             Aqkv = new("Aqkv", M, nqkv)
-            if E["lin"] == 0.0:
+            if fuse_prep and q_begin == 0 and fuse_rope:
+                # RoPE's backward rides on the dQ store and on dK's group sum (no rope_bwd pass, no dqk round trip): both write Aqkv directly
+                ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, Aqkv[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv,
+                                  rope=(self.cos, self.sin))
+                ops.attn_bwd_dkv(q, k, v, None, Gho, None, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, 0.0, 0.0, row_iv=row_iv)
+                ops.gqa_reduce_rope(dk_h, Aqkv[:, nq * d: nqk], M, S, nk, rep, d, self.cos, self.sin)
                 ops.gqa_reduce(dv_h, Aqkv[:, nqk:], M, nk, rep, d)
-                ops.rope_bwd(dqk, None, None, Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, 0.0, 0.0)
             else:
-                dv = ops.gqa_reduce(dv_h, new("dv", M, nk * d), M, nk, rep, d)
-                ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
-                ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
+                dqk = new("dqk", M, nqk) if q_begin == 0 else zeros("dqk", M, nqk)
+                if fuse_prep and q_begin == 0:
+                    ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv)
+                else:
+                    ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dqk[:, : nq * d], B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                                    q_begin=q_begin, row_iv=row_iv)
+                ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, scale, E["mask"], E["qk"],
+                                 q_begin=q_begin, row_iv=row_iv)
+                ops.gqa_reduce(dk_h, dqk[:, nq * d:], M, nk, rep, d)
+                if E["lin"] == 0.0:
+                    ops.gqa_reduce(dv_h, Aqkv[:, nqk:], M, nk, rep, d)
+                    ops.rope_bwd(dqk, None, None, Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, 0.0, 0.0)
+                else:
+                    dv = ops.gqa_reduce(dv_h, new("dv", M, nk * d), M, nk, rep, d)
+                    ops.eps_scale2d(dv, v, Aqkv[:, nqk:], 1.0, E["lin"])
+                    ops.rope_bwd(dqk, qkr, qkv[:, :nqk], Aqkv[:, :nqk], self.cos, self.sin, S, nq + nk, d, E["rope"], E["lin"])
             rel = f32(("rel", li), M) if layer_relevance else None
             if nfb and ops.norm_fusion_part("bwd_qkv"):
                 # K1n: Gs = rstd1 (.) (Aqkv W'qkv) + Gs1 -- the input norm's identity rule and the residual add in the qkv dgrad's epilogue.  The

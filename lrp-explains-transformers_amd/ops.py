@@ -1037,14 +1037,28 @@ def attn_dq_d_ok(dtype, d):
     return bool(PREP_FUSION and dtype in _DT and lib.lrp_attn_bwd_dq_d_ok(_DT[dtype], d))
 
 
-def attn_bwd_dq_d(q, k, v, Gho, o, lse, D, dq, B, S, Hq, Hkv, d, scale, causal=True, window=0, row_iv=None):
-    """dQ of the lxt.efficient placement with D[b, h, s] = sum_d Gho o formed in the kernel and WRITTEN to D (for attn_bwd_dkv)"""
+def attn_bwd_dq_d(q, k, v, Gho, o, lse, D, dq, B, S, Hq, Hkv, d, scale, causal=True, window=0, row_iv=None, rope=None):
+    """dQ of the lxt.efficient placement with D[b, h, s] = sum_d Gho o formed in the kernel and WRITTEN to D (for attn_bwd_dkv); rope = (cos, sin)
+    fp32 [>= S, d]: RoPE's backward applied to dQ on its way out (then dq is the gradient w.r.t. the UN-rotated q)"""
     same(q, k, v, Gho, o, dq)
     f32(lse, D)
+    cs, sn = rope if rope is not None else (None, None)
+    f32(cs, sn)
     check(lib.lrp_attn_bwd_dq_d(p(q), p(k), p(v), p(Gho), p(o), p(lse), p(D), p(dq), B, S, Hq, Hkv, d, q.stride(0), k.stride(0), v.stride(0),
-                                Gho.stride(0), o.stride(0), dq.stride(0), scale, int(causal), window, *_iv(row_iv, B, S), dt(q), stream()),
-          "lrp_attn_bwd_dq_d")
+                                Gho.stride(0), o.stride(0), dq.stride(0), scale, int(causal), window, *_iv(row_iv, B, S), p(cs), p(sn), dt(q),
+                                stream()), "lrp_attn_bwd_dq_d")
     return dq
+
+
+ROPE_BWD_FUSION = True   # module attribute (A/B): False = the stand-alone lrp_rope_bwd pass
+
+
+def gqa_reduce_rope(x, out, rows, seq, Hkv, rep, d, cos, sin):
+    """out[r, hk, :] = RoPE^T(sum_j x[r, hk rep + j, :]) -- the GQA group sum of dK and RoPE's backward in one pass"""
+    f32(cos, sin)
+    check(lib.lrp_gqa_reduce_rope(p(x), p(out), rows, seq, Hkv, rep, d, x.stride(0), out.stride(0), p(cos), p(sin), dt(x), stream()),
+          "lrp_gqa_reduce_rope")
+    return out
 
 
 def attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, eps_mask, eps_qk, causal=True,

@@ -824,6 +824,24 @@ def test_attention(ops, dtype, B, S, Hq, Hkv, d, causal, window, mode):
         ops.attn_bwd_dq_d(qt, kt, vt, Gho, o, lse, D2, dq2, B, S, Hq, Hkv, d, scale, causal, window)
         assert not torch.isnan(D2).any() and torch.allclose(D2, D, rtol=1e-4, atol=1e-5 * float(D.abs().max()))
         assert not torch.isnan(dq2).any() and nmax(dq2, dq) < 1e-2 and nmax(dq2, _tm(dQ)) < tol * 3
+        if d in (64, 128):
+            # RoPE's backward on the way out of the dQ kernel / inside dK's group sum == rope_bwd on the stored gradients (ref: HF
+            # apply_rotary_pos_emb's VJP; lxt/explicit/models/llama.py:226-260 with eps = 0), to one bf16 rounding
+            inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+            fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+            cs, sn = torch.cat((fr, fr), -1).cos().cuda().contiguous(), torch.cat((fr, fr), -1).sin().cuda().contiguous()
+            dq3 = torch.full_like(dq, float("nan"))
+            ops.attn_bwd_dq_d(qt, kt, vt, Gho, o, lse, D2, dq3, B, S, Hq, Hkv, d, scale, causal, window, rope=(cs, sn))
+            dq_rot = torch.empty_like(dq2)
+            ops.rope_bwd(dq2, None, None, dq_rot, cs, sn, S, Hq, d, 0.0, 0.0)
+            assert not torch.isnan(dq3).any() and nmax(dq3, dq_rot) < 1e-2
+            xh = rnd(B * S, Hq * d, dtype=dtype, seed=9)                        # per-query-head dK stand-in
+            red, red_rot, fused = torch.empty(B * S, Hkv * d, dtype=dtype, device="cuda"), torch.empty(B * S, Hkv * d, dtype=dtype, device="cuda"), \
+                torch.full((B * S, Hkv * d), float("nan"), dtype=dtype, device="cuda")
+            ops.gqa_reduce(xh, red, B * S, Hkv, rep, d)
+            ops.rope_bwd(red, None, None, red_rot, cs, sn, S, Hkv, d, 0.0, 0.0)
+            ops.gqa_reduce_rope(xh, fused, B * S, S, Hkv, rep, d, cs, sn)
+            assert not torch.isnan(fused).any() and nmax(fused, red_rot) < 1e-2
     dk_h, dv_h = torch.empty_like(qt), torch.empty_like(qt)
     ops.attn_bwd_dkv(qt, kt, vt, q_t, Gho, Gho_t, lse, D, dk_h, dv_h, B, S, Hq, Hkv, d, scale, E["mask"], E["qk"], causal, window)
     dk, dv = torch.empty_like(kt), torch.empty_like(vt)
