@@ -375,7 +375,8 @@ int lrp_attn_bwd_dq_d(const void* q, const void* k, const void* v, const void* G
                       int B, int S, int Hq, int Hkv, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldgho, int64_t ldo, int64_t lddq,
                       float scale, int causal, int window, const int* row_lo, const int* row_hi, const float* cos_t, const float* sin_t,
                       int dtype, void* stream);
-/* cos_t / sin_t (fp32 [S, d], NULL = none; d = 64 or 128): RoPE's backward applied to dQ on its way out of the kernel -- and, for dK, inside the
+/* cos_t / sin_t (fp32 [S, d] in the rotate-half convention, i.e. columns c and c + d/2 hold the SAME value -- only the first half is read;
+ * NULL = none; d = 64 or 128): RoPE's backward applied to dQ on its way out of the kernel -- and, for dK, inside the
  * group sum: lrp_gqa_reduce_rope(dk_h [rows, Hkv rep d] -> out [rows, Hkv d]) sums the rep query heads of a kv head and applies the transposed
  * rotation (rotate-half pairs (c, c + d/2), position = row % seq) in one pass.  Together they replace the lrp_rope_bwd launch of the
  * lxt.efficient placement (no stabiliser on the rotation: lxt/explicit/models/llama.py:226-260 with eps = 0 = HF's apply_rotary_pos_emb VJP). */

@@ -738,13 +738,14 @@ __global__ __launch_bounds__(NWQ * 64, 2) void dq_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = db * 32 + 8 * i + 4 * hi;
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pc + c), c2 = *reinterpret_cast<const f32x4*>(pc + c + DH / 2);
-                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(ps + c), s2 = *reinterpret_cast<const f32x4*>(ps + c + DH / 2);
+                    // (the tables' two halves are EQUAL in the rotate-half convention -- emb = cat(freqs, freqs) -- and only the first is read:
+                    // every workgroup pulls its rows of both tables through L2, 2048 workgroups x 128 rows x 2 x 256 B per launch)
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(pc + c), s1 = *reinterpret_cast<const f32x4*>(ps + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float g1 = acc[db][4 * i + e], g2 = acc[db + ND32 / 2][4 * i + e];
-                        acc[db][4 * i + e] = g1 * c1[e] + g2 * s2[e];
-                        acc[db + ND32 / 2][4 * i + e] = g2 * c2[e] - g1 * s1[e];
+                        acc[db][4 * i + e] = g1 * c1[e] + g2 * s1[e];
+                        acc[db + ND32 / 2][4 * i + e] = g2 * c1[e] - g1 * s1[e];
                     }
                 }
         }

@@ -505,7 +505,9 @@ class LlamaLRP:
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
             dk_h, dv_h = new("dk_h", M, nq * d), new("dv_h", M, nq * d)
-            Aqkv = new("Aqkv", M, nqkv)
+            # (row pitch off the 4-KiB grid: the dQ kernel stores one row segment per lane straight into it, and 12 KiB would put them all on the
+            # same channels -- dqk's 10 KiB never did)
+            Aqkv = ar.get("Aqkv", (M, nqkv), dt, pad=(64 if (nqkv * emb.element_size()) % 4096 == 0 and PITCH_PAD else 0))
             if fuse_prep and q_begin == 0 and fuse_rope:
                 # RoPE's backward rides on the dQ store and on dK's group sum (no rope_bwd pass, no dqk round trip): both write Aqkv directly
                 ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, Aqkv[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv,
