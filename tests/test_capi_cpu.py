@@ -28,6 +28,49 @@ def test_argument_validation_without_gpu():
     assert L.lib.lrp_attn_fwd(16, 16, 16, 16, 16, 16, 1, 8, 3, 2, 64, 64, 64, 64, 8, 64, 1.0, 1, 0, 0, None, None, 1, None) == -1  # Hq % Hkv
 
 
+def test_round5_host_side_queries_and_layout_rules():
+    """the dispatch questions of the round-5 entry points are host code (no launch): K1n applicability, the stream forward's K splits / workspace /
+    ticket words, the dQ-with-D kernel's coverage, argument checks of the new calls -- and the engine's row-pitch rules"""
+    import lxt_amd._lib as L
+    lib, BF16, F32 = L.lib, L.BF16, L.F32
+    # K1n: bf16 only, N % 256 == 0, >= 190 tiles of 256 x 256
+    assert lib.lrp_gemm_norm_fused_ok(8192, 4096, 4096, 4096, 4096, 0, BF16) == 1
+    assert lib.lrp_gemm_norm_fused_ok(8192, 4096, 28672, 28736, 4224, 1, BF16) == 1
+    assert lib.lrp_gemm_norm_fused_ok(8192, 4096 + 64, 4096, 4096, 4096, 0, BF16) == 0          # N % 256
+    assert lib.lrp_gemm_norm_fused_ok(2048, 4096, 4096, 4096, 4096, 0, BF16) == 0               # 128 tiles
+    assert lib.lrp_gemm_norm_fused_ok(8192, 4096, 4096, 4096, 4096, 0, F32) == 0
+    assert lib.lrp_gemm_res_ssq(None, None, None, None, None, 8, 256, 128, 128, 128, 256, 256, 8, BF16, None) == -1
+    assert lib.lrp_rms_rstd(None, 4, 8, 8, 256, 1e-5, None, None) == -1
+    # stream forward: wide weights run full K (1 split), narrow ones 2 ... 8 splits with whole 8-tile rings; ws = splits * M * N * 4 bytes
+    assert lib.lrp_linear_stream_fwd_splits(4, 14336, 4096) == 1 and lib.lrp_linear_stream_fwd_ws(4, 14336, 4096) == 0
+    assert lib.lrp_linear_stream_fwd_splits(4, 4096, 14336) == 4 and lib.lrp_linear_stream_fwd_ws(4, 4096, 14336) == 4 * 4 * 4096 * 4
+    assert lib.lrp_linear_stream_fwd_tickets(4, 4096, 14336) == 64 and lib.lrp_linear_stream_fwd_tickets(4, 14336, 4096) == 0
+    assert lib.lrp_linear_stream_fwd_splits(4, 8192, 2048) == 2 and lib.lrp_linear_stream_fwd_splits(4, 1024, 4096) == 0
+    assert lib.lrp_linear_stream_fwd_splits(200, 4096, 14336) == 0                                # M > 128
+    assert lib.lrp_linear_stream_ok(4, 4096, 14336, 14336, 14400) == 1 and lib.lrp_linear_stream_ok(4, 1024, 4096, 4096, 4096) == 0
+    # dQ with D (and RoPE's backward): the bf16 32x32 kernels of head dims 64 / 96 / 128
+    assert [lib.lrp_attn_bwd_dq_d_ok(BF16, d) for d in (64, 96, 128, 256, 32)] == [1, 1, 1, 0, 0] and lib.lrp_attn_bwd_dq_d_ok(F32, 128) == 0
+    assert lib.lrp_gqa_reduce_rope(None, None, 8, 8, 2, 2, 64, 256, 128, None, None, BF16, None) == -1
+    assert lib.lrp_set_gemm_scratch(1, 0, None) == -1 and lib.lrp_set_gemm_scratch(None, 0, None) == 0     # bad size refused; dropping nothing is fine
+    assert lib.lrp_gemm_scratch_bytes() % (32 * 512 * 16) == 0
+    # row-pitch rules (pure functions)
+    import lxt_amd.engine as E
+    assert E.weight_pitch_pad(4096, 2, 28672) == 128 and E.weight_pitch_pad(4096, 2, 2048) == 0          # 8-KiB pitch: padded when the weight exceeds the caches
+    assert E.weight_pitch_pad(2560, 2, 20480) == 128 and E.weight_pitch_pad(1152, 2, 4352) == 0          # 5 KiB (Gemma-3): padded; SigLIP: small, odd pitch
+    assert E.pitch_pad(14336, 2) == 64 and E.pitch_pad(28672, 2) == 64 and E.pitch_pad(4096, 2) == 0
+    import lxt_amd.ops as ops
+    keep = ops.NORM_FUSION
+    try:
+        ops.NORM_FUSION = frozenset({"fwd"})
+        assert ops.norm_fusion_part("fwd") and not ops.norm_fusion_part("bwd_gu")
+        ops.NORM_FUSION = True
+        assert ops.norm_fusion_part("bwd_gu")
+        ops.NORM_FUSION = False
+        assert not ops.norm_fusion_part("fwd")
+    finally:
+        ops.NORM_FUSION = keep
+
+
 def test_no_cpu_fallback():
     import lxt_amd.ops as ops
     a = torch.randn(4, 8)
