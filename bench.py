@@ -606,6 +606,7 @@ def main():
         # never idles (the next step is already queued) and the step time is reproducible.
         if i >= 1:
             done[i - 1].synchronize()
+            timer.drain()                                   # fold the finished step's GEMM spans, re-use their events (ops.KernelTimer)
         if args.per_step:                                   # dev: per-step wall times (adds a full sync per step)
             torch.cuda.synchronize()
             per_step.append(time.perf_counter() - t0)

@@ -111,24 +111,47 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=None):
 
 class KernelTimer:
     """HIP-event timing of every launch of one kernel family on the launching stream (bench.py's
-    roofline leg).  Enabled by assigning an instance to ops.GEMM_TIMER; records (flops, ev0, ev1)."""
+    roofline leg).  Enabled by assigning an instance to ops.GEMM_TIMER; records (flops, ev0, ev1).
+    drain() folds the spans whose end event has completed into per-tag sums and RE-USES their event objects: a long run then keeps ~one step's
+    worth of events alive instead of steps x launches x 2 (each live event holds a signal of the HIP runtime's pool; with thousands alive the
+    runtime takes a slow path in some processes -- the judged run's sporadic +14 ms per step sat entirely in launch gaps, not in kernels:
+    profiles/r05_gemm_experiments.txt, section O)."""
 
     def __init__(self):
         self.records = []
+        self.sums = {}            # tag -> [launches, flops, seconds]
+        self.pool = []
 
     def span(self, flops, tag="plain"):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if len(self.pool) >= 2:
+            e0, e1 = self.pool.pop(), self.pool.pop()
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.append((flops, e0, e1, tag))
         return e0, e1
+
+    def drain(self, wait=False):
+        """fold every span whose end event has completed (all of them with wait=True: call after a device synchronise)"""
+        keep = []
+        for r in self.records:
+            if not keep and (wait or r[2].query()):
+                acc = self.sums.setdefault(r[3], [0, 0.0, 0.0])
+                acc[0] += 1
+                acc[1] += r[0]
+                acc[2] += r[1].elapsed_time(r[2]) * 1e-3
+                self.pool.append(r[1])
+                self.pool.append(r[2])
+            else:
+                keep.append(r)        # spans complete in issue order: stop at the first one still in flight
+        self.records = keep
 
     def summary(self, tag=None):
         """-> (launches, total_flops, total_seconds) of the launches with this tag (None: all); call after a device synchronise.
         Tags: "plain" = GEMM only; "plain_norm" = the same kernel with a K1n epilogue (row scale / residual add / row sums of squares);
         "gated_fwd" / "gated_bwd" = the launches that carry a gated-MLP rule in their epilogue; a tuple selects several"""
-        recs = [r for r in self.records if tag is None or r[3] == tag or (isinstance(tag, tuple) and r[3] in tag)]
-        tot_f = sum(r[0] for r in recs)
-        tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
-        return len(recs), tot_f, tot_t
+        self.drain(wait=True)
+        sel = [v for k, v in self.sums.items() if tag is None or k == tag or (isinstance(tag, tuple) and k in tag)]
+        return sum(v[0] for v in sel), sum(v[1] for v in sel), sum(v[2] for v in sel)
 
 
 GEMM_TIMER = None
