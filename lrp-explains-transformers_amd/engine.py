@@ -143,6 +143,7 @@ class LlamaLRP:
         # identity rule does not see its weight.  What it buys: the norm is then a pure row scale, which commutes with the Linear --
         # rstd (.) (h W'^T) -- so for M = B S rows the efficient placement runs it inside the GEMM epilogues (K1n, _norm_fused below).
         self.folded = bool(dtype == torch.bfloat16 if fold_norm is None else fold_norm)
+        self._nf_cache = {}                 # row count -> do the K1n entry points take every GEMM around the norms (_norm_fused)
 
         # ONE flat device buffer holds every weight in its forward layout (embedding, norms, LM head, per layer the fused
         # [q;k;v] and [gate;up] matrices, o, down): the tensors below are views into it, so the multi-GPU start-up is a
@@ -238,7 +239,7 @@ class LlamaLRP:
         if not (self.folded and self.mode == "efficient" and ops.NORM_FUSION):
             return False
         key = ("nf", M)
-        hit = self._nf_cache.get(key) if hasattr(self, "_nf_cache") else None
+        hit = self._nf_cache.get(key)
         if hit is None:
             c = self.cfg
             H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
@@ -254,8 +255,6 @@ class LlamaLRP:
                     (M, 2 * I, H, H, L0["wgu"].stride(0), False),                   # gu = rstd (h1 W'gu^T)
                     (M, H, nqkv, nqkv, L0["wqkv"].stride(0), True),                 # G_h = rstd (Aqkv W'qkv) + G_res
                     (M, H, 2 * I, 2 * I + pitch_pad(2 * I, 2), L0["wgu"].stride(0), True)))
-            if not hasattr(self, "_nf_cache"):
-                self._nf_cache = {}
             self._nf_cache[key] = hit = bool(ok)
         return hit
 
