@@ -476,6 +476,23 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started bare (no RANK / WORLD_SIZE in the environment): become the launcher -- the same command the driver
+    issues for N > 1, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`,
+    one rank per GPU over RCCL -- and hand its exit code back.  Rank 0's JSON line reaches this process's stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,7 +516,6 @@ def main():
                     "launches carry the same kernel names as the step's GEMMs and would dilute the per-kernel averages)")
     ap.add_argument("--dense-top", action="store_true", help="disable the top-layer sparsity (A/B knob)")
     ap.add_argument("--unfused-gated", action="store_true", help="A/B knob: gated-MLP rules as separate kernels (ops.GATED_FUSION = False)")
-    ap.add_argument("--dephase", action="store_true", help="A/B knob: de-phased GEMM tile walk (ops.GEMM_DEPHASE = True: scratch registered; measured negative)")
     ap.add_argument("--no-rope-bwd-fusion", action="store_true", help="A/B knob: stand-alone rope_bwd pass (ops.ROPE_BWD_FUSION = False)")
     ap.add_argument("--no-prep-fusion", action="store_true", help="A/B knob: stand-alone attn_bwd_prep pass (ops.PREP_FUSION = False)")
     ap.add_argument("--norm-fusion-parts", default="", help="A/B knob: comma-separated subset of fwd,bwd_qkv,bwd_gu (ops.NORM_FUSION as a set)")
@@ -510,6 +526,8 @@ def main():
                     help="plumbing self-test WITHOUT kernels or a GPU (gloo): rank env, sharding, barrier, max-over-ranks, gather, "
                          "one JSON line from rank 0 -- value is null; used by tests/test_dist_cpu.py for the N>1 launch contract")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not args.single_rank_collectives:
+        return self_launch(args.gpus)
     if args.dry_run:
         return dry_run(args)
 
@@ -520,7 +538,6 @@ def main():
 
     ops.GATED_FUSION = not args.unfused_gated
     E.PITCH_PAD = not args.no_pitch_pad
-    ops.GEMM_DEPHASE = bool(args.dephase)
     ops.PREP_FUSION = not args.no_prep_fusion
     ops.ROPE_BWD_FUSION = not args.no_rope_bwd_fusion
     if args.no_norm_fusion:

@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 6 (round 5: version 6 added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -219,15 +219,12 @@ int lrp_gated_act_fwd(const void* g, const void* u, void* m, int M, int I, int64
 int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, void* Au,
                       int M, int I, int64_t ldgm, int64_t ldg, int64_t ldu, int64_t ldag,
                       int64_t ldau, float eps_g, float eps_lin, int act, int dtype, void* stream);
-/* The same two rules on the INTERLEAVED output of a fused gate/up Linear and fused into the GEMMs around them (the engine's layout:
- * the rows of the fused weight [2 I, H] are ordered in blocks of 64 = [gate rows 32 b .. 32 b + 31 | up rows 32 b .. 32 b + 31], so one
- * 64-column block of gu = W_gu x holds gate AND up of the same 32 intermediate indices -- and so does one wave's accumulator tile):
- *   lrp_gated_act_fwd_il / _bwd_il : the element-wise kernels on gu / Agu [M, 2 I] in that layout (small M, fp32)
- *   lrp_gemm_gated_fwd : gu = x W_gu^T (stored, the backward needs it) AND m = act(g) (*) u written by the SAME kernel's epilogue
- *   lrp_gemm_gated_bwd : Gm = A_dn W_dn (NN form, W_dn [H, I] as stored) is never written: the epilogue reads gu and writes
- *                        Agu = { Gm u/2 act(g)/(g + eps_g) | Gm act(g)/2 u/(u + eps_lin) } directly
- * bf16; when the problem is too small for the 256 x 256 ping-pong kernel the two entry points run the GEMM and the element-wise
- * kernel one after the other (`ws`: M x I elements of scratch for Gm in that case; may be NULL when lrp_gemm_gated_bwd_ws() == 0).
+/* The same two rules on the INTERLEAVED output of a fused gate/up Linear (the engine's layout: the rows of the fused weight [2 I, H] are
+ * ordered in blocks of 64 = [gate rows 32 b .. 32 b + 31 | up rows 32 b .. 32 b + 31], so one 64-column block of gu = W_gu x holds gate AND up
+ * of the same 32 intermediate indices -- and so does one wave's accumulator tile of the GEMM):
+ *   lrp_gated_act_fwd_il / _bwd_il : the element-wise kernels on gu / Agu [M, 2 I] in that layout
+ *   lrp_gemm_gated_fwd / _bwd      : the Linear + the element-wise kernel one after the other (gu = x W_gu^T stored; Gm = A_dn W_dn in `ws`,
+ *                                    lrp_gemm_gated_bwd_ws() bytes) -- small M, shapes the fused form below refuses
  * ref: lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281. */
 #define LRP_GATED_IL 32
 int lrp_gated_act_fwd_il(const void* gu, void* m, int M, int I, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
@@ -238,6 +235,25 @@ int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M,
 int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype);
 int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
                        int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws, void* stream);
+/* FUSED form, M = B S rows (round 6): the rules run in the epilogues of the two GEMMs around them and the forward stashes the backward's
+ * COEFFICIENTS instead of g and u.  The gate/up GEMM has g and u of an intermediate index in fp32 registers; it evaluates the activation once
+ * and writes   m  = act(g) u,
+ *              cg = 1/2 u act(g) / (g + eps_g)    (0 where g + eps_g = 0)     = identity rule on act (*) uniform rule (*) the gate Linear's stabiliser
+ *              cu = 1/2 act(g) u / (u + eps_lin)  (1/2 act(g) for eps_lin = 0) = uniform rule (*) the up Linear's stabiliser
+ * (eps_g = 1e-10, eps_lin = 0: lxt.efficient, ref lxt/efficient/rules.py:88-100, patches.py:145-157; eps_g = eps_lin = the Linear eps:
+ * lxt.explicit, ref lxt/explicit/models/llama.py:84-86,273-281 with rules.py:68-78,405-418 and functional.py:355-364).  The down-projection's
+ * dgrad Gm = A_dn W_dn (NN form, W_dn [H, I] as stored) is never written: its epilogue forms Agu = { Gm cg | Gm cu } -- one multiply per element,
+ * no transcendental in the backward -- in the interleaved layout above, ready to be the gate/up dgrad's operand.  g and u are never stored.
+ *   coef [M, 2 I] bf16, row pitch ldcoef (multiple of 8): PRIVATE to the pair of entry points, in accumulator order -- the 16 bytes
+ *   { cg x 4 | cu x 4 } of intermediate indices 4 t .. 4 t + 3 at columns 8 t .. 8 t + 7 of the row.
+ *   rs (may be NULL): fp32 [M], the accumulators of the forward are scaled by rs[m] first (K1n below: the folded RMSNorm's 1 / rms).
+ *   lrp_gemm_gated_coef_ok(M, I, H, ldx, ldwgu, lda, ldwd, act, dtype) -> 1 when BOTH launches are problems the fused epilogues take (bf16,
+ *   I % 32 == 0, >= 190 tiles of 256 x 256 each, SiLU / tanh-GELU); the two entry points return LRP_ESHAPE otherwise (no fallback inside). */
+int lrp_gemm_gated_coef_ok(int M, int I, int H, int64_t ldx, int64_t ldwgu, int64_t lda, int64_t ldwd, int act, int dtype);
+int lrp_gemm_gated_fwd_coef(const void* x, const void* Wgu, const float* rs, void* coef, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
+                            int64_t ldcoef, int64_t ldm, float eps_g, float eps_lin, int act, int dtype, void* stream);
+int lrp_gemm_gated_bwd_coef(const void* Adn, const void* Wdn, const void* coef, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
+                            int64_t ldcoef, int64_t ldagu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1n  Llama-type RMSNorm FOLDED INTO THE LINEARS AROUND IT (round 5; M = B S rows, bf16, the 256 x 256 ping-pong kernel only).
@@ -247,7 +263,7 @@ int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* A
  *   lxt/explicit/functional.py:345-364 on both sides.
  *   The norm's weight w is folded into the consuming Linear by the host (W' = W diag(w): (w (.) x rstd) W^T = rstd (x W'^T)), after which
  *     forward :  h1 = h + o Wo^T            and the sums of squares of h1's rows      -> lrp_gemm_res_ssq  (+ lrp_rms_rstd: rstd from the partials)
- *                gu = rstd (.) (h1 W'gu^T), m = act(g) (*) u                          -> lrp_gemm_gated_fwd_rs
+ *                gu = rstd (.) (h1 W'gu^T), m = act(g) (*) u + coefficient stash      -> lrp_gemm_gated_fwd_coef with rs = rstd
  *                qkv = rstd (.) (h W'qkv^T)                                           -> lrp_gemm_nt_rs
  *     backward:  G_h = rstd (.) (A W') + G_res  (norm's identity rule + residual add) -> lrp_gemm_nn_rs_res
  *   i.e. the stand-alone lrp_add_rmsnorm_fwd / lrp_rmsnorm_bwd_add2 launches (4 x 67 MB round trips per layer at M = 8192, H = 4096) become
@@ -259,19 +275,9 @@ int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* A
  *                      ROUNDED out[m][.]^2  (ldssq >= M; every entry of rows < M is written)
  *   lrp_rms_rstd     : rstd[m] = rsqrt(sum_p ssq[p][m] / H + eps)  (partials summed in order: deterministic)
  *   lrp_gemm_nt_rs   : out[M,N] = bf16(rs[m] * (x W^T))
- *   lrp_gemm_gated_fwd_rs : as lrp_gemm_gated_fwd with the accumulators scaled by rs[m] first (gu is the scaled product)
  *   lrp_gemm_nn_rs_res    : out[M,N] = bf16(rs[m] * (s W) + res), W [K,N] as stored (the dgrad form of lrp_gemm_nn); out may alias res
  * --------------------------------------------------------------------------------------- */
 int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype);
-/* De-phased tile walk of the 256 x 256 ping-pong GEMM (every entry point that launches it: lrp_gemm_nt / _nn, lrp_gemm_gated_*, the K1n family).
- * With scratch registered for the launching stream a workgroup computes its first tile in two sittings -- K tiles [0, phi) at the start, the
- * partial sums parked in the scratch in fp32, K tiles [phi, nkt) at the very end: the same summation order as one sitting, results identical bit
- * for bit -- with phi a function of the XCD it runs on, so that the eight XCDs' epilogues no longer coincide (the fused epilogues' HBM traffic
- * then runs under other XCDs' K loops instead of as chip-wide bursts).  The memory stays the caller's: lrp_gemm_scratch_bytes() bytes (256 KiB
- * per CU), 16-byte aligned, one region per stream that launches GEMMs concurrently; p = NULL drops the registration.  Nothing is registered by
- * default (one sitting per tile). */
-int lrp_set_gemm_scratch(void* p, int64_t bytes, void* stream);
-int64_t lrp_gemm_scratch_bytes(void);
 int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx, int64_t ldw,
                      int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream);
 int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);
@@ -280,8 +286,6 @@ int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int
 int lrp_gemm_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds, int64_t ldw, int64_t ldout,
                    int dtype, void* stream);      /* out[M,N] = bf16(rs[m] * (s W)), W [K,N] as stored (rs = 1/2 everywhere: the o-projection's dgrad
                                                      with the uniform rule's factor of the P.V product, lxt/efficient/patches.py:193-203) */
-int lrp_gemm_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
-                          int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
 int lrp_gemm_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds, int64_t ldw,
                        int64_t ldres, int64_t ldout, int dtype, void* stream);
 

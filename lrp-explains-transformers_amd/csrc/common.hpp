@@ -184,6 +184,27 @@ LRP_DEVICE void gated_bwd_pair_bf16(float g, float u, float gmh, float eps_g, fl
     }
 }
 
+// ---- the same rule as COEFFICIENTS (round 6; gemm_pp.hip EPI 1 / 2): the gate/up forward, which has g and u in fp32 registers, evaluates the
+// activation ONCE and leaves the two factors the backward multiplies Gm by -- cg = 1/2 u act(g) / (g + eps_g) (0 where g + eps_g = 0) and
+// cu = 1/2 act(g) u / (u + eps_lin) (1/2 act(g) for eps_lin = 0) -- next to m = act(g) u.  LEAN as above.
+template <bool LEAN, int ACT_CT>
+LRP_DEVICE void gated_coef(float g, float u, float eps_g, float eps_lin, float& m, float& cg, float& cu) {
+    const float y = act_apply_t<true>(g, ACT_CT);
+    m = y * u;
+    const float den = g + eps_g, hy = 0.5f * y;
+    if constexpr (LEAN) {
+        const float q = hy * __builtin_amdgcn_rcpf(den);
+        cg = (den == 0.f) ? 0.f : u * q;
+        cu = hy;
+    } else {
+        cg = (den == 0.f) ? 0.f : u * fdiv_small_t<true>(hy, den);
+        cu = hy * eps_ratio_t<true>(u, 1.f, eps_lin);
+    }
+}
+// the two bf16 halves of a 32-bit word as fp32 (one VALU each)
+LRP_DEVICE float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+LRP_DEVICE float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
 // ---- MFMA 16x16 "macro" op, identical byte geometry for both dtypes ---------------------------
 // One macro step contracts a 64-BYTE K chunk: lane l supplies the 16 bytes at K-byte offset
 // (l>>4)*16 of row (l&15) for each operand (8 bf16 / 4 fp32).  bf16: one v_mfma_f32_16x16x32_bf16;

@@ -16,10 +16,10 @@
 int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                        int64_t ldc, int out_dtype, int nn, int splits, int kt_per_split, int64_t slab_stride, hipStream_t st);
 
-int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
-                                 int64_t ldgu, int64_t ldm, int act, hipStream_t st);
-int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
-                                 int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st);
+int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, const float* rs, void* coef, void* m, int M, int I, int K, int64_t ldx,
+                                 int64_t ldw, int64_t ldcoef, int64_t ldm, float eps_g, float eps_lin, int act, hipStream_t st);
+int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* coef, void* Agu, int M, int I, int K, int64_t lda,
+                                 int64_t ldw, int64_t ldcoef, int64_t ldagu, hipStream_t st);
 
 int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
                                int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st);
@@ -27,8 +27,6 @@ int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void
                              int64_t ldout, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
                              int64_t ldout, hipStream_t st);
-int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
-                                    int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
                                  int64_t ldw, int64_t ldres, int64_t ldout, hipStream_t st);
 
@@ -566,22 +564,12 @@ bool gated_fused_ok(int M, int Ncols, int K, int I, int64_t lda, int64_t ldb, in
 }
 }  // namespace
 
+// the GEMM + element-wise pair on the stored gate/up output gu (small M, fp32, shapes the fused form refuses)
 extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
                                   int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
     if (!x || !Wgu || !gu || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
     if (M == 0 || I == 0) return LRP_OK;
     if (I % LRP_GATED_IL) return LRP_ESHAPE;
-    if (dtype == LRP_BF16 && (ldx % 8) == 0 && (ldw % 8) == 0 && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(Wgu) & 15) &&
-        gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act)) {
-        const int chunk = pp_row_chunk(ldx);
-        for (int m0 = 0; m0 < M; m0 += chunk) {
-            const int rc = lrp_launch_gemm_pp_gated_fwd((const char*)x + (int64_t)m0 * ldx * 2, Wgu, (char*)gu + (int64_t)m0 * ldgu * 2,
-                                                        (char*)m + (int64_t)m0 * ldm * 2, M - m0 < chunk ? M - m0 : chunk, I, K, ldx, ldw, ldgu,
-                                                        ldm, act, (hipStream_t)stream);
-            if (rc != LRP_OK) return rc;
-        }
-        return LRP_OK;
-    }
     const int rc = lrp_gemm_nt(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, 0, 0, 0, dtype, dtype, stream);
     if (rc != LRP_OK) return rc;
     return lrp_gated_act_fwd_il(gu, m, M, I, ldgu, ldm, act, dtype, stream);
@@ -589,8 +577,7 @@ extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void
 
 extern "C" int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype) {
     if (dtype != LRP_BF16 || M <= 0 || I <= 0) return 0;
-    // the fused kernel needs no scratch; the GEMM + element-wise pair needs Gm [M, I]
-    return gated_fused_ok(M, I, K, I, lda, ldw, 1, act) ? 0 : (int64_t)M * I * 2;
+    return (int64_t)M * I * 2;                                              // Gm [M, I]
 }
 
 extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
@@ -600,20 +587,50 @@ extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* 
     if (M == 0 || I == 0) return LRP_OK;
     if (dtype != LRP_BF16 || (I % LRP_GATED_IL)) return LRP_ESHAPE;
     if ((lda % 8) || (ldw % 8) || (reinterpret_cast<uintptr_t>(Adn) & 15) || (reinterpret_cast<uintptr_t>(Wdn) & 15)) return LRP_EALIGN;
-    if (gated_fused_ok(M, I, K, I, lda, ldw, 1, act)) {
-        const int chunk = pp_row_chunk(lda);
-        for (int m0 = 0; m0 < M; m0 += chunk) {
-            const int rc = lrp_launch_gemm_pp_gated_bwd((const char*)Adn + (int64_t)m0 * lda * 2, Wdn, (const char*)gu + (int64_t)m0 * ldgu * 2,
-                                                        (char*)Agu + (int64_t)m0 * ldagu * 2, M - m0 < chunk ? M - m0 : chunk, I, K, lda, ldw,
-                                                        ldgu, ldagu, eps_g, eps_lin, act, (hipStream_t)stream);
-            if (rc != LRP_OK) return rc;
-        }
-        return LRP_OK;
-    }
     if (!ws) return LRP_EINVAL;
     const int rc = lrp_gemm_nn(Adn, Wdn, ws, nullptr, M, I, K, lda, ldw, I, dtype, dtype, stream);
     if (rc != LRP_OK) return rc;
     return lrp_gated_act_bwd_il(ws, gu, Agu, M, I, I, ldgu, ldagu, eps_g, eps_lin, act, dtype, stream);
+}
+
+// ---- round 6: the fused form stashes the backward's COEFFICIENTS (include/lrp_hip.h).  Both launches of a layer must be problems the
+// ping-pong kernel's fused epilogues take: the gate/up forward [M, 2 I] over K = hidden (NT) and the down-projection dgrad [M, I] over hidden (NN)
+extern "C" int lrp_gemm_gated_coef_ok(int M, int I, int H, int64_t ldx, int64_t ldwgu, int64_t lda, int64_t ldwd, int act, int dtype) {
+    if (dtype != LRP_BF16 || M <= 0 || I <= 0 || H <= 0 || (ldx % 8) || (ldwgu % 8) || (lda % 8) || (ldwd % 8)) return 0;
+    return (gated_fused_ok(M, 2 * I, H, I, ldx, ldwgu, 0, act) && gated_fused_ok(M, I, H, I, lda, ldwd, 1, act)) ? 1 : 0;
+}
+
+extern "C" int lrp_gemm_gated_fwd_coef(const void* x, const void* Wgu, const float* rs, void* coef, void* m, int M, int I, int K, int64_t ldx,
+                                       int64_t ldw, int64_t ldcoef, int64_t ldm, float eps_g, float eps_lin, int act, int dtype, void* stream) {
+    if (!x || !Wgu || !coef || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3 || eps_g < 0.f || eps_lin < 0.f) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (ldx % 8) || (ldw % 8) || !gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act)) return LRP_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(Wgu) & 15)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(ldx);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_gated_fwd((const char*)x + (int64_t)m0 * ldx * 2, Wgu, rs ? rs + m0 : nullptr,
+                                                    (char*)coef + (int64_t)m0 * ldcoef * 2, (char*)m + (int64_t)m0 * ldm * 2,
+                                                    M - m0 < chunk ? M - m0 : chunk, I, K, ldx, ldw, ldcoef, ldm, eps_g, eps_lin, act,
+                                                    (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_gated_bwd_coef(const void* Adn, const void* Wdn, const void* coef, void* Agu, int M, int I, int K, int64_t lda,
+                                       int64_t ldw, int64_t ldcoef, int64_t ldagu, int dtype, void* stream) {
+    if (!Adn || !Wdn || !coef || !Agu || M < 0 || I < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || I == 0) return LRP_OK;
+    if (dtype != LRP_BF16 || (lda % 8) || (ldw % 8) || !gated_fused_ok(M, I, K, I, lda, ldw, 1, LRP_ACT_SILU)) return LRP_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(Adn) & 15) || (reinterpret_cast<uintptr_t>(Wdn) & 15)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(lda);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        const int rc = lrp_launch_gemm_pp_gated_bwd((const char*)Adn + (int64_t)m0 * lda * 2, Wdn, (const char*)coef + (int64_t)m0 * ldcoef * 2,
+                                                    (char*)Agu + (int64_t)m0 * ldagu * 2, M - m0 < chunk ? M - m0 : chunk, I, K, lda, ldw,
+                                                    ldcoef, ldagu, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
 }
 
 
@@ -671,22 +688,6 @@ extern "C" int lrp_gemm_nn_rs(const void* s, const void* W, const float* rs, voi
     for (int m0 = 0; m0 < M; m0 += chunk) {
         const int rc = lrp_launch_gemm_pp_nn_rs((const char*)s + (int64_t)m0 * lds_ * 2, W, rs + m0, (char*)out + (int64_t)m0 * ldout * 2,
                                                 M - m0 < chunk ? M - m0 : chunk, N, K, lds_, ldw, ldout, (hipStream_t)stream);
-        if (rc != LRP_OK) return rc;
-    }
-    return LRP_OK;
-}
-
-extern "C" int lrp_gemm_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
-                                     int64_t ldw, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
-    if (!x || !Wgu || !rs || !gu || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
-    if (M == 0 || I == 0) return LRP_OK;
-    if ((I % LRP_GATED_IL) || !lrp_gemm_norm_fused_ok(M, 2 * I, K, ldx, ldw, 0, dtype) || !gated_fused_ok(M, 2 * I, K, I, ldx, ldw, 0, act)) return LRP_ESHAPE;
-    if (!a16(x) || !a16(Wgu)) return LRP_EALIGN;
-    const int chunk = pp_row_chunk(ldx);
-    for (int m0 = 0; m0 < M; m0 += chunk) {
-        const int rc = lrp_launch_gemm_pp_gated_fwd_rs((const char*)x + (int64_t)m0 * ldx * 2, Wgu, rs + m0, (char*)gu + (int64_t)m0 * ldgu * 2,
-                                                       (char*)m + (int64_t)m0 * ldm * 2, M - m0 < chunk ? M - m0 : chunk, I, K, ldx, ldw, ldgu,
-                                                       ldm, act, (hipStream_t)stream);
         if (rc != LRP_OK) return rc;
     }
     return LRP_OK;

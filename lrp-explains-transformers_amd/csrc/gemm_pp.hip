@@ -57,14 +57,9 @@
 // (workgroups starting up to 17 us apart to de-phase the CUs' epilogue bursts) changed nothing and was removed: the fused epilogues are bound by
 // their own VALU issue (see gated_bwd_pair_bf16 in common.hpp), not by a shared HBM burst.
 #include "common.hpp"
-#include <mutex>
-#include <vector>
 
 #ifndef PP_PERSIST
 #define PP_PERSIST 1
-#endif
-#ifndef PP_EARLY_GU
-#define PP_EARLY_GU 1
 #endif
 
 namespace {
@@ -74,28 +69,14 @@ constexpr int PP_OPND = 256 * 128;                // one operand of one buffer (
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
 
-// PP_TIMELINE (dev builds only, tools/gemm_ab.py): waves 0 and 4 of three workgroups stamp s_memtime at kernel start, loop start, loop
-// end, stores issued, stores retired (plus the 100 MHz s_memrealtime at loop start and at the end: shader clock) into the spare LDS above
-// the 128 KiB of tiles and dump the stamps through the `bias` pointer (which is then NOT a bias).
-#ifdef PP_TIMELINE
-#define PP_STAMP(fn)                                                                              \
-    if (tl_on) {                                                                                  \
-        const uint64_t tt_ = fn();                                                                \
-        if (tl_idx < 192) asm volatile("ds_write_b64 %0, %1" ::"v"(tl_base + 8u * tl_idx), "v"(tt_) : "memory");   \
-        ++tl_idx;                                                                                 \
-    }
-#else
-#define PP_STAMP(fn)
-#endif
-
 #define PP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define PP_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // fused gated-MLP epilogues (EPI 1 / 2, see the end of the kernel); EPI 0 = plain (+ bias)
 struct PPEpi {
-    bf16_t* c2;            // EPI 1: m [M, I]
+    bf16_t* c2;            // EPI 1: m [M, I]  (C is then the COEFFICIENT stash [M, 2 I], see below)
     int64_t ldc2;
-    const bf16_t* gu;      // EPI 2: the stashed gate/up output [M, 2 I], interleaved
+    const bf16_t* gu;      // EPI 2: the coefficient stash [M, 2 I] the gate/up forward (EPI 1) left
     int64_t ldgu;
     float eps_g, eps_lin;
     int act;
@@ -116,8 +97,7 @@ struct PPEpi {
 template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep,
-    int phi_mult, f32x4* __restrict__ scratch) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,43 +105,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // this workgroup's range of K tiles (split-K: blockIdx.y), host guarantees >= 2 tiles per split
     const int nkt_all = K / PP_KT;
     const int kt0 = blockIdx.y * kt_per_split;
-    const int nkt_full = min(kt_per_split, nkt_all - kt0);
-    int nkt = nkt_full;                                                // K tiles of the running segment (a whole tile, or one part of a split one)
+    const int nkt = min(kt_per_split, nkt_all - kt0);
     C += (int64_t)blockIdx.y * slab_stride;
     const int ntiles = tiles_m * tiles_n;
     int tile = blockIdx.x;
     int m0, n0;                                                        // the tile whose K loop runs / ran last (epilogue coordinates)
-    // ---- DE-PHASED WORKGROUPS (round 5).  Left alone, the 256 CUs run in lock step: they reach the epilogue together (the fused epilogues' HBM
-    // traffic -- 0.94 GB per down-projection dgrad -- comes as 7 chip-wide bursts during which no CU multiplies) and start every K loop with all
-    // staging requests at once.  With scratch registered for the stream (lrp_set_gemm_scratch) a workgroup computes its FIRST tile in two
-    // sittings: K tiles [0, phi) at the start, the accumulators parked in the scratch (fp32, exact); K tiles [phi, nkt) at the very end, on top
-    // of the reloaded accumulators -- the same summation order as one sitting, bit for bit -- which shifts all its other tiles, hence its
-    // epilogues, by phi K tiles.  phi is a function of the XCD the workgroup runs on (HW_REG_XCC_ID): the 32 workgroups of an XCD stay in
-    // step with each other -- they share operand panels through the XCD's L2, and tiles walking K out of step re-fetch them (a per-tile phase
-    // cost 5 % on the whole step) -- while the eight XCDs, which share nothing but HBM, are spread evenly over a tile's K loop.
-    // MEASURED NEGATIVE (profiles/r05_gemm_experiments.txt, section K; the host leaves it off: ops.GEMM_DEPHASE): results bit-identical, but the
-    // 8-layer judged step goes 43.56 -> 44.47 ms -- parking and reloading one tile per CU costs ~25 us per launch, and the epilogues were not
-    // waiting for HBM bandwidth to begin with.
-    int rot = 0;                                                       // first K tile of the running segment
-    int mode = 0;                                                      // 0: whole tile; 1: first sitting of a split tile (park); 2: second sitting (reload)
-    bool split = false, second_done = false;
     {
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * 256; n0 = tn * 256;
-#if PP_PERSIST && !defined(PP_TIMELINE)
-        if (scratch != nullptr && gridDim.y == 1) {
-            unsigned xcc;                                              // the XCD this workgroup REALLY runs on (the dispatcher's round robin does not
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));      // restart at XCD 0 with every launch)
-            const int phi = (int)(xcc & 7u) * nkt_all / 8;
-            if (phi >= 2 && phi <= nkt_all - 2) { split = true; mode = 1; nkt = phi; }      // (both sittings need the two K tiles the prologue stages)
-        }
-#endif
     }
-    const int m00 = m0, n00 = n0, phi0 = nkt;
-    // parked accumulators: [workgroup][32 accumulator quads][512 threads] fp32 x 4 (lane-linear: 16 bytes per lane, 1 KiB per wave instruction).
-    // Written as inline asm: left to the compiler, the 32 addresses become 64 live registers and the kernel spills.
-    f32x4* const park = scratch + (size_t)blockIdx.x * (32 * 512) + tid;
     // ---- staging (buffer_load_dwordx4 .. lds, 1 KiB per wave instruction; rows / columns past the operand read as zero)
     // A (both forms): piece = 8 rows x 128 B; lane l -> row (l >> 3), LDS position (l & 7), source chunk position ^ (row & 7).  A pieces of
     // this wave: rows g*128 + a*64 + wc*16 + 8 p (a = unit half, p = 0, 1).
@@ -201,21 +154,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const int bstep = NN ? (int)(PP_KT * ldb * 2) : 128;                // bytes per K tile along B
     char* const ldsA = smem + (g * 128 + wc * 16) * 128;               // + buf*PP_OPND + a*8192 + p*1024
     char* const ldsB = smem + 2 * PP_OPND + (NN ? wave * 8 * 512 : wave * 32 * 128);      // + buf*PP_OPND + p*1024
-    // (running K-tile index + the segment's first K tile, written out in both staging lambdas: a helper lambda called from them makes the HOST
-    // pass of hipcc drop the kernel's stub without a diagnostic)
     auto stage_A = [&](int a, int kt, int buf) {
-        const int kr = kt + rot;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (pp_lds_ptr_t)(ldsA + buf * PP_OPND + a * 8192 + p * 1024), 16, voA,
-                                                     soA[a][p] + kr * 128, 0, 0);
+                                                     soA[a][p] + kt * 128, 0, 0);
     };
     auto stage_B = [&](int kt, int buf) {
-        const int kr = kt + rot;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (pp_lds_ptr_t)(ldsB + buf * PP_OPND + p * 1024), 16, voB[p & 1],
-                                                     soB[p] + kr * bstep, 0, 0);
+                                                     soB[p] + kt * bstep, 0, 0);
     };
 
     // ---- fragment addresses.  A (and NT B): row (l & 15) of a 16-row block, chunk (4 ks + (l >> 4)) ^ (l & 7).
@@ -253,13 +202,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     bf16x8 fa[4][2];                                                    // [16-row block][k-step]
     union BFrag { bf16x8 v; bf16x4 h[2]; } fb[4][2];                    // [16-column tile][k-step]; NN: two 4-row transpose reads each
 
-#ifdef PP_TIMELINE
-    const int tl_slot = (blockIdx.x == 0) ? 0 : (blockIdx.x == 101) ? 1 : (blockIdx.x == 257) ? 2 : -1;
-    const bool tl_on = tl_slot >= 0 && (wave & 3) == 0 && blockIdx.y == 0;
-    const unsigned tl_base = 4u * PP_OPND + (unsigned)g * 2048u;
-    unsigned tl_idx = 0;
-    PP_STAMP(__builtin_amdgcn_s_memtime)
-#endif
     // ---- prologue of a tile: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
     auto issue_prologue = [&]() { stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1); };
     issue_prologue();
@@ -296,30 +238,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     if constexpr (EPI == 3) {
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
-    if (mode == 2) {                                                   // second sitting: continue on the parked partial sums
-        uint64_t pa = reinterpret_cast<uint64_t>(park);               // ONE running address (made opaque per step: hoisted, the 32 addresses spill)
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[q >> 4][(q >> 2) & 3][q & 3]) : "v"(pa) : "memory");
-            pa += 8192;
-            asm volatile("" : "+v"(pa));
-        }
-        // (the loads are invisible to the compiler's own wait insertion: the values pass through the wait as operands, 8 quads per statement)
-#define PP_TIE8(A, I) "+v"(acc[A][I][0]), "+v"(acc[A][I][1]), "+v"(acc[A][I][2]), "+v"(acc[A][I][3]), \
-                      "+v"(acc[A][I + 1][0]), "+v"(acc[A][I + 1][1]), "+v"(acc[A][I + 1][2]), "+v"(acc[A][I + 1][3])
-        asm volatile("s_waitcnt vmcnt(0)" : PP_TIE8(0, 0) :: "memory");
-        asm volatile("" : PP_TIE8(0, 2));
-        asm volatile("" : PP_TIE8(1, 0));
-        asm volatile("" : PP_TIE8(1, 2));
-#undef PP_TIE8
-    } else {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     __builtin_amdgcn_s_barrier();
     if (g == 1) __builtin_amdgcn_s_barrier();                          // the half-phase offset between the two groups
 
@@ -381,8 +305,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
     }
 
-    PP_STAMP(__builtin_amdgcn_s_memrealtime)
-    PP_STAMP(__builtin_amdgcn_s_memtime)
     int t = 0;
     for (; t + 1 < nkt; t += 2) {
         PP_KTILE(0)
@@ -391,11 +313,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         --t;
     }
     if (t < nkt) PP_KTILE(0)
-    PP_STAMP(__builtin_amdgcn_s_memtime)
-#ifdef PP_TIMELINE
-    uint64_t* const tl_out = (uint64_t*)bias;
-    bias = nullptr;
-#endif
     // ---- the next tile of this workgroup: its first staging units go out NOW, ahead of the epilogue's memory traffic
     bool has_next = false;
     // the epilogue's first operands were requested at the top of the tile (below); make them architecturally "used" HERE, ahead of the next
@@ -408,116 +325,74 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     if constexpr (EPI == 3) {
         asm volatile("" : "+v"(rpre[0][0]), "+v"(rpre[0][1]), "+v"(rpre[1][0]), "+v"(rpre[1][1]));
     }
-    // EPI 2: the gu loads of the first two row blocks, likewise ahead of the staging pieces (PP_EARLY_GU 0: behind them, the round-4 order)
+    // EPI 2: the coefficient loads of the first row block, likewise ahead of the staging pieces.  Lane (row l & 15, hi) reads, for column tile j,
+    // the 16 bytes {cg x 4 | cu x 4} of ITS four intermediate indices ncol + 16 j + 4 hi .. + 3: the stash is in accumulator order (no cross-lane
+    // exchange on either side), 64 contiguous bytes per row and wave instruction
     u32x4 gpre[2][4];
     auto issue_gu = [&](int b, u32x4 (&d)[4]) {
-        const bf16_t* p = ep.gu + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldgu + 2 * (int64_t)ncol + epoff;
+        const bf16_t* p = ep.gu + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldgu + 2 * (int64_t)ncol + 8 * hi;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u32x4*>(p + 32 * k);        // q0 gate, q0 up, q1 gate, q1 up
+        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u32x4*>(p + 32 * k);
     };
-#if PP_EARLY_GU
     if constexpr (EPI == 2) {
         if (full) issue_gu(0, gpre[0]);                           // (both blocks: 32 registers more than the kernel has at this point -- spills)
     }
-#endif
     if constexpr (EPI == 4) {       // (NN form: no 24 registers to spare across the K loop -- requested here, ahead of the staging pieces; two tiles per CU)
         load_rs();
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
-    const int emode = mode;                                           // what to do with the accumulators of the segment that just ran
-#if PP_PERSIST && !defined(PP_TIMELINE)
+#if PP_PERSIST
     if (tile + (int)gridDim.x < ntiles) {
         tile += gridDim.x;
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * 256; n0 = tn * 256;
-        rot = 0; nkt = nkt_full; mode = 0;
         has_next = true;
-    } else if (split && !second_done) {                                // the parked first tile: its K tiles [phi, nkt)
-        m0 = m00; n0 = n00;
-        rot = phi0; nkt = nkt_all - phi0; mode = 2;
-        second_done = true;
-        has_next = true;
-    }
-    if (has_next) {
         set_soA(m0);
         set_soB(n0);
         issue_prologue();
     }
 #endif
-
-    if (emode == 1) {
-        // ---- first sitting of a split tile: park the partial sums (fp32, lane-linear: 16 bytes per lane, 8 KiB per wave store)
-        uint64_t pa = reinterpret_cast<uint64_t>(park);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            // (s_nop: a store of more than 8 bytes reads its data registers one wait state after issue, and the compiler -- which re-uses the
-            // just-stored accumulator registers for the next address -- does not see hazards of inline asm)
-            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(pa), "v"(acc[q >> 4][(q >> 2) & 3][q & 3]) : "memory");
-            pa += 8192;
-            asm volatile("" : "+v"(pa));
-        }
-    } else {
+    {
     // ---- epilogue
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     bool done = false;
     if constexpr (EPI == 2) {
-        // ---- gated-MLP backward rule in the down-projection dgrad's epilogue, full tiles.  The accumulators are Gm for 64 intermediate
-        // indices (two 32-index groups q); gate / up of group q sit at gu columns 64 (ncol/32 + q) + {0..31 | 32..63}; Agu in the same
-        // layout.  Gm is rounded to bf16 first: bit-identical to the unfused pair lrp_gemm_nn + lrp_gated_act_bwd_il.
-        // Software-pipelined over the 8 row blocks (a, i): the four 16-byte gu loads of block b + 2 are issued right after block b's
-        // stores, into the registers block b just released -- 8 loads in flight per wave.  (Written as one load pair per (i, q) inside
-        // the generic loop below, hipcc waits vmcnt(0) after every pair: 2 KiB in flight per wave, 1.9 TB/s over the epilogue.)
+        // ---- gated-MLP backward rule in the down-projection dgrad's epilogue, full tiles (round 6: COEFFICIENT form).  The accumulators are Gm
+        // for 64 intermediate indices; the gate/up forward (EPI 1) left, per index, cg = 1/2 u act(g) / (g + eps_g) and cu = 1/2 act(g) u / (u + eps_lin)
+        // -- the identity rule on the activation, the uniform rule on the product and both Linears' stabilisers (ref lxt/efficient/patches.py:145-157,
+        // lxt/efficient/rules.py:88-100, lxt/explicit/models/llama.py:84-86,273-281) -- so the rule here is Agu = Gm (*) (cg | cu): one multiply and
+        // one pack per element, no v_exp / v_rcp (the round-5 epilogue recomputed act(g) from the stashed g: ~310 VALU instructions per 16 pairs,
+        // 20 of the 26 us a tile's epilogue took).  Agu keeps the GEMM-operand layout [32 gate | 32 up] per 64 columns (v_permlane16_swap pairing).
+        // Software-pipelined over the 8 row blocks (a, i): the four 16-byte loads of block b + 2 are issued right after block b's
+        // stores, into the registers block b just released -- 8 loads in flight per wave.
         if (full) {
-            const int off = epoff;
-            bf16_t* adst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + 2 * (int64_t)ncol + off;
+            bf16_t* adst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + 2 * (int64_t)ncol + epoff;
             auto& pre = gpre;
-            auto& issue = issue_gu;
-            auto unswz = [&](const u32x4& o, f32x4 (&t)[2]) {
-                auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
-                auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
-                const bf16x2 a0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[0]), a1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[0]);
-                const bf16x2 b0 = __builtin_bit_cast(bf16x2, (uint32_t)s0[1]), b1 = __builtin_bit_cast(bf16x2, (uint32_t)s1[1]);
-                t[0] = f32x4{(float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1]};
-                t[1] = f32x4{(float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
-            };
-            auto swz = [&](const f32x4 (&t)[2]) {
-                bf16x2 x0 = {(bf16_t)t[0][0], (bf16_t)t[0][1]}, x1 = {(bf16_t)t[0][2], (bf16_t)t[0][3]};
-                bf16x2 y0 = {(bf16_t)t[1][0], (bf16_t)t[1][1]}, y1 = {(bf16_t)t[1][2], (bf16_t)t[1][3]};
+            auto swz = [&](const f32x4& t0, const f32x4& t1) {
+                bf16x2 x0 = {(bf16_t)t0[0], (bf16_t)t0[1]}, x1 = {(bf16_t)t0[2], (bf16_t)t0[3]};
+                bf16x2 y0 = {(bf16_t)t1[0], (bf16_t)t1[1]}, y1 = {(bf16_t)t1[2], (bf16_t)t1[3]};
                 auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
                 return u32x4{s0[0], s1[0], s0[1], s1[1]};
             };
-#if !PP_EARLY_GU
-            issue(0, pre[0]);
-#endif
-            issue(1, pre[1]);
+            issue_gu(1, pre[1]);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 bf16_t* dst = adst + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ldc;
-                u32x4 out[4];
+                f32x4 ag[4], au[4];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    f32x4 gq[2], uq[2], ag[2], au[2];
-                    unswz(pre[b & 1][2 * q], gq);
-                    unswz(pre[b & 1][2 * q + 1], uq);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float half = 0.5f * (float)(bf16_t)acc[b >> 2][b & 3][2 * q + jj][e];
-                            float ag_, au_;
-                            gated_bwd_pair_bf16<LEAN, ACT>(gq[jj][e], uq[jj][e], half, ep.eps_g, ep.eps_lin, ACT, ag_, au_);
-                            ag[jj][e] = ag_;
-                            au[jj][e] = au_;
-                        }
-                    out[2 * q] = swz(ag);
-                    out[2 * q + 1] = swz(au);
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 c = pre[b & 1][j];
+                    const f32x4 gm4 = acc[b >> 2][b & 3][j];
+                    ag[j] = f32x4{gm4[0] * bf16_lo(c[0]), gm4[1] * bf16_hi(c[0]), gm4[2] * bf16_lo(c[1]), gm4[3] * bf16_hi(c[1])};
+                    au[j] = f32x4{gm4[0] * bf16_lo(c[2]), gm4[1] * bf16_hi(c[2]), gm4[2] * bf16_lo(c[3]), gm4[3] * bf16_hi(c[3])};
                 }
+                u32x4 out[4] = {swz(ag[0], ag[1]), swz(au[0], au[1]), swz(ag[2], ag[3]), swz(au[2], au[3])};
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + 32 * k) = out[k];
-                if (b + 2 < 8) issue(b + 2, pre[b & 1]);
+                if (b + 2 < 8) issue_gu(b + 2, pre[b & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             done = true;
@@ -607,19 +482,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 }
             }
             if constexpr (EPI == 1) {
-                // ---- gated-MLP forward rule in the gate/up GEMM's epilogue.  The fused weight's rows are interleaved in blocks of 64 =
-                // [32 gate | 32 up], so this wave's column tiles j = 0, 1 are gate and j = 2, 3 up of the SAME 32 intermediate indices:
-                // m = act(g) (*) u on the bf16-rounded g, u (exactly what lrp_gated_act_fwd computes from the stored gu)
-                f32x4 mv[2];
+                // ---- gated-MLP forward rule in the gate/up GEMM's epilogue (round 6: the backward's COEFFICIENTS are stashed, not g / u).
+                // The fused weight's rows are interleaved in blocks of 64 = [32 gate | 32 up], so this wave's column tiles j = 0, 1 are gate and
+                // j = 2, 3 up of the SAME 32 intermediate indices, fp32, still in registers: m = act(g) (*) u, and the two factors the
+                // down-projection dgrad's epilogue (EPI 2) multiplies Gm by -- cg = 1/2 u act(g) / (g + eps_g), cu = 1/2 act(g) u / (u + eps_lin)
+                // (common.hpp: gated_coef).  act(g) is evaluated ONCE per explanation; g and u themselves are never written.  Stash layout
+                // [M, 2 I] in ACCUMULATOR order: the 16 bytes {cg x 4 | cu x 4} of intermediate indices 4 t .. 4 t + 3 at columns 8 t .. 8 t + 7.
+                f32x4 mv[2], cgv[2], cuv[2];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float gq = (float)(bf16_t)v[jj][e], uq = (float)(bf16_t)v[jj + 2][e];
-                        mv[jj][e] = (float)(bf16_t)act_apply_t<true>(gq, ACT) * uq;
+                        float m_, cg_, cu_;
+                        gated_coef<LEAN, ACT>(v[jj][e], v[jj + 2][e], ep.eps_g, ep.eps_lin, m_, cg_, cu_);
+                        mv[jj][e] = m_; cgv[jj][e] = cg_; cuv[jj][e] = cu_;
                     }
                 const int mcol = ncol / 2;                               // first intermediate index of this wave's block
                 if (full) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        bf16x2 c0 = {(bf16_t)cgv[jj][0], (bf16_t)cgv[jj][1]}, c1 = {(bf16_t)cgv[jj][2], (bf16_t)cgv[jj][3]};
+                        bf16x2 c2_ = {(bf16_t)cuv[jj][0], (bf16_t)cuv[jj][1]}, c3 = {(bf16_t)cuv[jj][2], (bf16_t)cuv[jj][3]};
+                        u32x4 o = {__builtin_bit_cast(uint32_t, c0), __builtin_bit_cast(uint32_t, c1), __builtin_bit_cast(uint32_t, c2_),
+                                   __builtin_bit_cast(uint32_t, c3)};
+                        *reinterpret_cast<u32x4*>(C + (int64_t)gm * ldc + ncol + 32 * jj + 8 * hi) = o;
+                    }
                     bf16x2 x0 = {(bf16_t)mv[0][0], (bf16_t)mv[0][1]}, x1 = {(bf16_t)mv[0][2], (bf16_t)mv[0][3]};
                     bf16x2 y0 = {(bf16_t)mv[1][0], (bf16_t)mv[1][1]}, y1 = {(bf16_t)mv[1][2], (bf16_t)mv[1][3]};
                     auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
@@ -632,7 +519,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int ci = mcol + 16 * jj + 4 * hi + e;
-                            if (2 * ci < N) ep.c2[(int64_t)gm * ep.ldc2 + ci] = (bf16_t)mv[jj][e];
+                            if (2 * ci < N) {
+                                ep.c2[(int64_t)gm * ep.ldc2 + ci] = (bf16_t)mv[jj][e];
+                                C[(int64_t)gm * ldc + ncol + 32 * jj + 8 * hi + e] = (TO)cgv[jj][e];
+                                C[(int64_t)gm * ldc + ncol + 32 * jj + 8 * hi + 4 + e] = (TO)cuv[jj][e];
+                            }
                         }
                 }
             }
@@ -650,25 +541,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 sq += __shfl_xor(sq, 32);
                 if (hi == 0 && gm < M && ncol < N) ep.ssq[(int64_t)(ncol >> 6) * ep.ldssq + gm] = sq;
             }
-            if constexpr (EPI == 2) {
+            if constexpr (EPI == 1) {
+                // (coefficients and m written above)
+            } else if constexpr (EPI == 2) {
                 // ragged tiles of the gated backward rule (the full tiles took the pipelined path above): element-wise, bounds-checked
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int64_t gcol = 2 * (int64_t)ncol + 64 * q;
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t gcol = 2 * (int64_t)ncol + 64 * (j >> 1);            // this column tile's [32 gate | 32 up] block of Agu
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int ci = 16 * jj + 4 * hi + e;
-                            if (gm < M && ncol + 32 * q + ci < N) {
-                                const float gq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + ci], uq = (float)ep.gu[(int64_t)gm * ep.ldgu + gcol + 32 + ci];
-                                const float half = 0.5f * (float)(bf16_t)v[2 * q + jj][e];
-                                float ag_, au_;
-                                gated_bwd_pair_bf16<LEAN, ACT>(gq, uq, half, ep.eps_g, ep.eps_lin, ACT, ag_, au_);
-                                C[(int64_t)gm * ldc + gcol + ci] = (TO)ag_;
-                                C[(int64_t)gm * ldc + gcol + 32 + ci] = (TO)au_;
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const int ci = 16 * (j & 1) + 4 * hi + e;
+                        if (gm < M && ncol + 16 * j + 4 * hi + e < N) {
+                            const bf16_t* cp = ep.gu + (int64_t)gm * ep.ldgu + 2 * (int64_t)ncol + 32 * j + 8 * hi + e;
+                            C[(int64_t)gm * ldc + gcol + ci] = (TO)(v[j][e] * (float)cp[0]);
+                            C[(int64_t)gm * ldc + gcol + 32 + ci] = (TO)(v[j][e] * (float)cp[4]);
                         }
+                    }
                 }
             } else
             if constexpr (sizeof(TO) == 4) {
@@ -708,39 +596,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     }
             }
         }
-    }   // emode != 1
+    }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
     if (!has_next) break;
     // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
     // retire in issue order through vmcnt on gfx9; the counter has 6 bits).  Full bf16 tiles: 16 stores per wave (+ 8 of m in the gated forward);
     // the fused gated backward's own gu loads were issued after the pieces and waited for by the compiler, only its last stores remain;
     // ragged tiles and fp32 output (scalar / conditional stores): drain.
-    if (emode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (once per launch: the parked sums drain)
-    else if (full && sizeof(TO) == 2) {
+    if (full && sizeof(TO) == 2) {
         if constexpr (EPI == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else if constexpr (EPI == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // (every LDS-DMA load was waited for inside the last K tile; the C stores may still be in flight when the wave ends)
-#if defined(PP_TIMELINE) || defined(PP_TAIL_WAIT)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifdef PP_TIMELINE
-    if (tl_on) {
-        PP_STAMP(__builtin_amdgcn_s_memtime)                            // C stores issued (and, after the wait above, retired)
-        PP_STAMP(__builtin_amdgcn_s_memtime)
-        PP_STAMP(__builtin_amdgcn_s_memrealtime)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tl_out && lane < 3) {
-            for (int i2 = lane * 64; i2 < lane * 64 + 64; ++i2) {
-                uint64_t v2;
-                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v2) : "v"(tl_base + 8u * (unsigned)i2) : "memory");
-                tl_out[(tl_slot * 2 + g) * 192 + i2] = v2;
-            }
-        }
-    }
-#endif
 #undef PP_KTILE
 #undef PP_READ_A
 #undef PP_READ_B
@@ -750,65 +619,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-// caller-owned scratch for the parked accumulators of the de-phased walk, registered per stream (the library allocates nothing)
-struct PPScratch { hipStream_t st; void* p; int64_t bytes; };
-std::mutex pp_scratch_mu;
-std::vector<PPScratch> pp_scratch;
-
-void* pp_scratch_for(hipStream_t st, int64_t need) {
-    std::lock_guard<std::mutex> lk(pp_scratch_mu);
-    for (const auto& e : pp_scratch)
-        if (e.st == st) return e.bytes >= need ? e.p : nullptr;
-    return nullptr;
-}
-
 template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false, bool RS = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     int gx = tiles_m * tiles_n;
-#if PP_PERSIST && !defined(PP_TIMELINE)
+#if PP_PERSIST
     if (splits == 1) {
         const int ncu = lrp_num_cus();
         if (gx > ncu) gx = ncu;
     }
 #endif
     dim3 grid(gx, splits), block(512);
-#ifdef PP_TIMELINE
-    const size_t lds = 4 * (size_t)PP_OPND + 4096;
-#else
     const size_t lds = 4 * (size_t)PP_OPND;
-#endif
     auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS>;
     LRP_SET_MAX_LDS(kern, lds);
-    // de-phased walk: when the stream has scratch for one parked tile per workgroup and every workgroup has at least two tiles
-    const int phi_mult = 0;                                           // (unused: a per-tile rotated K order was measured and dropped, see the kernel)
-    void* scratch = nullptr;
-#if PP_PERSIST && !defined(PP_TIMELINE) && !defined(PP_NO_DEPHASE)
-    if (splits == 1 && !SK && tiles_m * tiles_n >= 2 * gx) scratch = pp_scratch_for(st, (int64_t)gx * 32 * 512 * 16);
-#endif
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
-                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep, phi_mult, (f32x4*)scratch);
+                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
     return lrp_check_launch();
 }
 
 }  // namespace
-
-// register (p != NULL) or drop (p == NULL) the scratch of a stream: bytes >= workgroups x 256 KiB (lrp_gemm_scratch_bytes()) enables the de-phased
-// walk for the launches on that stream; the memory stays the caller's
-extern "C" int lrp_set_gemm_scratch(void* p, int64_t bytes, void* stream) {
-    if (p != nullptr && (bytes <= 0 || (reinterpret_cast<uintptr_t>(p) & 15))) return LRP_EINVAL;
-    std::lock_guard<std::mutex> lk(pp_scratch_mu);
-    for (size_t i = 0; i < pp_scratch.size(); ++i)
-        if (pp_scratch[i].st == (hipStream_t)stream) {
-            if (p) { pp_scratch[i].p = p; pp_scratch[i].bytes = bytes; }
-            else pp_scratch.erase(pp_scratch.begin() + i);
-            return LRP_OK;
-        }
-    if (p) pp_scratch.push_back(PPScratch{(hipStream_t)stream, p, bytes});
-    return LRP_OK;
-}
-extern "C" int64_t lrp_gemm_scratch_bytes(void) { return (int64_t)lrp_num_cus() * 32 * 512 * 16; }
 
 // Host entry used by the dispatchers of gemm.hip.  bf16 operands; K a multiple of 64, >= 128 per split; every operand below 2^30 elements
 // (32-bit buffer offsets).  nn = 0: B is [N, K] (ldb = row pitch of B); nn = 1: B is [K, N].  splits > 1: C must be fp32 slabs
@@ -832,38 +663,38 @@ int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, 
     return launch_pp_t<bf16_t, false, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
 }
 
-// gate/up forward with the gated rule in the epilogue: gu[M, 2 I] = x[M, K] . Wgu[2 I, K]^T (rows interleaved [32 gate | 32 up]), m[M, I]
-int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
-                                 int64_t ldgu, int64_t ldm, int act, hipStream_t st) {
+// gate/up forward with the gated rule in the epilogue: m[M, I] = act(g) (*) u and the backward's coefficient stash coef[M, 2 I] (accumulator order,
+// include/lrp_hip.h) from x[M, K] . Wgu[2 I, K]^T (rows interleaved [32 gate | 32 up]); rs != NULL: the accumulators are scaled by rs[row] first
+// (K1n: the folded RMSNorm's 1 / rms).  The activation is a compile-time parameter: with a run-time switch inside the 8-fold unrolled epilogue
+// hipcc gives up unrolling and moves the 128 accumulators to scratch.  LEAN = the lxt.efficient placement (eps_g >= 1e-30, no Linear stabiliser).
+namespace {
+template <int ACT, bool LEAN>
+int gated_fwd_t(const void* x, const void* Wgu, const float* rs, void* coef, int M, int I, int K, int64_t ldx, int64_t ldw, int64_t ldcoef,
+                const PPEpi& ep, hipStream_t st) {
+    if (rs) return launch_pp_t<bf16_t, false, 1, ACT, false, LEAN, true>(x, Wgu, coef, nullptr, M, 2 * I, K, ldx, ldw, ldcoef, 1, K / PP_KT, 0, ep, st);
+    return launch_pp_t<bf16_t, false, 1, ACT, false, LEAN, false>(x, Wgu, coef, nullptr, M, 2 * I, K, ldx, ldw, ldcoef, 1, K / PP_KT, 0, ep, st);
+}
+}  // namespace
+int lrp_launch_gemm_pp_gated_fwd(const void* x, const void* Wgu, const float* rs, void* coef, void* m, int M, int I, int K, int64_t ldx,
+                                 int64_t ldw, int64_t ldcoef, int64_t ldm, float eps_g, float eps_lin, int act, hipStream_t st) {
     PPEpi ep{};
-    ep.c2 = (bf16_t*)m; ep.ldc2 = ldm; ep.act = act;
-    // the activation is a compile-time parameter: with a run-time switch inside the 8-fold unrolled epilogue hipcc gives up unrolling and
-    // moves the 128 accumulators to scratch
-    if (act == LRP_ACT_SILU) return launch_pp_t<bf16_t, false, 1, LRP_ACT_SILU>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
-    if (act == LRP_ACT_GELU_TANH) return launch_pp_t<bf16_t, false, 1, LRP_ACT_GELU_TANH>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
+    ep.c2 = (bf16_t*)m; ep.ldc2 = ldm; ep.act = act; ep.rs = rs; ep.eps_g = eps_g; ep.eps_lin = eps_lin;
+    const bool lean = eps_g >= 1e-30f && eps_lin == 0.f;
+    if (act == LRP_ACT_SILU)
+        return lean ? gated_fwd_t<LRP_ACT_SILU, true>(x, Wgu, rs, coef, M, I, K, ldx, ldw, ldcoef, ep, st)
+                    : gated_fwd_t<LRP_ACT_SILU, false>(x, Wgu, rs, coef, M, I, K, ldx, ldw, ldcoef, ep, st);
+    if (act == LRP_ACT_GELU_TANH)
+        return lean ? gated_fwd_t<LRP_ACT_GELU_TANH, true>(x, Wgu, rs, coef, M, I, K, ldx, ldw, ldcoef, ep, st)
+                    : gated_fwd_t<LRP_ACT_GELU_TANH, false>(x, Wgu, rs, coef, M, I, K, ldx, ldw, ldcoef, ep, st);
     return LRP_ESHAPE;
 }
 
-// down-projection dgrad with the gated rule in the epilogue: Gm = Adn[M, K] . Wdn[K, I] (NN, never stored) -> Agu[M, 2 I]
-int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
-                                 int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, hipStream_t st) {
+// down-projection dgrad with the gated rule in the epilogue: Gm = Adn[M, K] . Wdn[K, I] (NN, never stored) -> Agu[M, 2 I] = Gm (*) coef
+int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* coef, void* Agu, int M, int I, int K, int64_t lda,
+                                 int64_t ldw, int64_t ldcoef, int64_t ldagu, hipStream_t st) {
     PPEpi ep{};
-    ep.gu = (const bf16_t*)gu; ep.ldgu = ldgu; ep.eps_g = eps_g; ep.eps_lin = eps_lin; ep.act = act;
-    // lxt.efficient placement (eps_g = 1e-10, no Linear stabiliser): the lean form of the rule (common.hpp: gated_bwd_pair_bf16)
-#ifdef PP_NO_LEAN
-    const bool lean = false;                                            // A/B builds
-#else
-    const bool lean = eps_g >= 1e-30f && eps_lin == 0.f;
-#endif
-    if (act == LRP_ACT_SILU) {
-        if (lean) return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU, false, true>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
-        return launch_pp_t<bf16_t, true, 2, LRP_ACT_SILU>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
-    }
-    if (act == LRP_ACT_GELU_TANH) {
-        if (lean) return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH, false, true>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
-        return launch_pp_t<bf16_t, true, 2, LRP_ACT_GELU_TANH>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
-    }
-    return LRP_ESHAPE;
+    ep.gu = (const bf16_t*)coef; ep.ldgu = ldcoef;
+    return launch_pp_t<bf16_t, true, 2>(Adn, Wdn, Agu, nullptr, M, I, K, lda, ldw, ldagu, 1, K / PP_KT, 0, ep, st);
 }
 
 // ---- RMSNorm folded into the GEMMs around it (round 5; include/lrp_hip.h "K1n").  Same kernel, three more epilogue forms.
@@ -887,17 +718,6 @@ int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void
     PPEpi ep{};
     ep.rs = rs;
     return launch_pp_t<bf16_t, true, 0, 0, false, false, true>(s, W, out, nullptr, M, N, K, lds_, ldw, ldout, 1, K / PP_KT, 0, ep, st);
-}
-// gate/up forward on the un-normalised rows: gu = rs (.) (x Wgu^T), m = act(g) (*) u
-int lrp_launch_gemm_pp_gated_fwd_rs(const void* x, const void* Wgu, const float* rs, void* gu, void* m, int M, int I, int K, int64_t ldx,
-                                    int64_t ldw, int64_t ldgu, int64_t ldm, int act, hipStream_t st) {
-    PPEpi ep{};
-    ep.c2 = (bf16_t*)m; ep.ldc2 = ldm; ep.act = act; ep.rs = rs;
-    if (act == LRP_ACT_SILU)
-        return launch_pp_t<bf16_t, false, 1, LRP_ACT_SILU, false, false, true>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
-    if (act == LRP_ACT_GELU_TANH)
-        return launch_pp_t<bf16_t, false, 1, LRP_ACT_GELU_TANH, false, false, true>(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, K / PP_KT, 0, ep, st);
-    return LRP_ESHAPE;
 }
 // out = rs (.) (s W) + res (NN: W [K, N] as stored)
 int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,

@@ -87,7 +87,13 @@ class FusedGatedMLPFn(Function):
         es = x2.element_size()
         gu = torch.empty(M, 2 * I, device=x.device, dtype=x.dtype)
         m = torch.empty(M, I + pitch_pad(I, es), device=x.device, dtype=x.dtype)[:, :I]
-        ops.gemm_gated_fwd(x2, Wgu, gu, m, act)
+        # M = B S rows: the backward's coefficients are stashed in gu's place (ops.gemm_gated_fwd_coef: no exp / rcp in the backward, g and u never
+        # stored); otherwise the GEMM + element-wise pair on the stored gate/up output
+        ctx.coef = ops.gated_coef_ok(M, I, x2.shape[1], x2.stride(0), Wgu.stride(0), Wd.shape[0], Wd.stride(0), act, x2.dtype)
+        if ctx.coef:
+            ops.gemm_gated_fwd_coef(x2, Wgu, gu, m, 1e-10, 0.0, act)
+        else:
+            ops.gemm_gated_fwd(x2, Wgu, gu, m, act)
         y = ops.linear_fwd(m, Wd, out=torch.empty(M, Wd.shape[0], device=x.device, dtype=x.dtype))
         ctx.save_for_backward(Wgu, Wd, gu)
         ctx.act = act
@@ -103,7 +109,10 @@ class FusedGatedMLPFn(Function):
             g2 = g2.contiguous()
         M, I2 = gu.shape
         Agu = torch.empty(M, I2 + pitch_pad(I2, gu.element_size()), device=gu.device, dtype=gu.dtype)[:, :I2]
-        ops.gemm_gated_bwd(g2, Wd, gu, Agu, 1e-10, 0.0, ctx.act)
+        if ctx.coef:
+            ops.gemm_gated_bwd_coef(g2, Wd, gu, Agu)
+        else:
+            ops.gemm_gated_bwd(g2, Wd, gu, Agu, 1e-10, 0.0, ctx.act)
         gx = ops.linear_dgrad(Agu, Wgu, out=torch.empty(M, Wgu.shape[1], device=gu.device, dtype=gu.dtype))
         return gx.view(*shp[:-1], Wgu.shape[1]), None, None, None
 

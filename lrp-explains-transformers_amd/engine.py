@@ -233,28 +233,49 @@ class LlamaLRP:
     def _lin_bwd(self, A, W, out):
         return ops.linear_dgrad(A, W, out=out)
 
+    def _pitches(self):
+        """row pitches (elements) of the backward's two wide GEMM operands, in ONE place: what backward() allocates is what the eligibility
+        checks below are asked about"""
+        c = self.cfg
+        es = torch.empty(0, dtype=self.dtype).element_size()
+        nqkv = (c["n_heads"] + 2 * c["n_kv"]) * c["head_dim"]
+        aqkv_pad = 64 if ((nqkv * es) % 4096 == 0 and PITCH_PAD) else 0
+        return dict(Aqkv=nqkv + aqkv_pad, Aqkv_pad=aqkv_pad, Agu=2 * c["inter"] + pitch_pad(2 * c["inter"], es), m=c["inter"] + pitch_pad(c["inter"], es))
+
+    def _gated_coef(self, M):
+        """the gated-MLP rules run as a coefficient stash inside the two GEMMs around them (ops.gemm_gated_fwd_coef / _bwd_coef) at this row count"""
+        key = ("coef", M, PITCH_PAD, ops.GATED_FUSION)
+        hit = self._nf_cache.get(key)
+        if hit is None:
+            c = self.cfg
+            L0 = self.layers[0] if self.layers else None
+            hit = bool(L0 is not None and ops.gated_coef_ok(M, c["inter"], c["hidden"], c["hidden"], L0["wgu"].stride(0), c["hidden"],
+                                                            L0["wd"].stride(0), self.act, self.dtype))
+            self._nf_cache[key] = hit
+        return hit
+
     def _norm_fused(self, M):
         """K1n applies: folded norm weights, efficient placement (no stabiliser on the residual add / the Linears: eps = 0), and every GEMM on
         both sides of the two norms is a problem the ping-pong kernel's fused epilogues take (bf16, >= 190 tiles, N % 256 == 0)"""
         if not (self.folded and self.mode == "efficient" and ops.NORM_FUSION):
             return False
-        key = ("nf", M)
+        key = ("nf", M, PITCH_PAD, repr(ops.NORM_FUSION), ops.GATED_FUSION)
         hit = self._nf_cache.get(key)
         if hit is None:
             c = self.cfg
             H, I, d, nq, nk = c["hidden"], c["inter"], c["head_dim"], c["n_heads"], c["n_kv"]
             nqkv = (nq + 2 * nk) * d
             L0 = self.layers[0] if self.layers else None
-            ok = L0 is not None
+            ok = L0 is not None and self._gated_coef(M)
             if ok:
-                ldm = I + pitch_pad(I, 2)
+                pt = self._pitches()
                 ok = all(ops.norm_fused_ok(*a, self.dtype) for a in (
                     (M, H, nq * d, nq * d, L0["wo"].stride(0), False),              # h1 = h + o Wo^T
-                    (M, H, I, ldm, L0["wd"].stride(0), False),                      # h' = h1 + m Wd^T
+                    (M, H, I, pt["m"], L0["wd"].stride(0), False),                  # h' = h1 + m Wd^T
                     (M, nqkv, H, H, L0["wqkv"].stride(0), False),                   # qkv = rstd (h W'qkv^T)
-                    (M, 2 * I, H, H, L0["wgu"].stride(0), False),                   # gu = rstd (h1 W'gu^T)
-                    (M, H, nqkv, nqkv, L0["wqkv"].stride(0), True),                 # G_h = rstd (Aqkv W'qkv) + G_res
-                    (M, H, 2 * I, 2 * I + pitch_pad(2 * I, 2), L0["wgu"].stride(0), True)))
+                    (M, 2 * I, H, H, L0["wgu"].stride(0), False),                   # gate/up = rstd (h1 W'gu^T)
+                    (M, H, nqkv, pt["Aqkv"], L0["wqkv"].stride(0), True),           # G_h = rstd (Aqkv W'qkv) + G_res
+                    (M, H, 2 * I, pt["Agu"], L0["wgu"].stride(0), True)))
             self._nf_cache[key] = hit = bool(ok)
         return hit
 
@@ -330,6 +351,7 @@ class LlamaLRP:
         stash = []
         h_prev, branch = emb, None
         last = torch.arange(B, device=dev) * S + (S - 1)
+        coef = self._gated_coef(M)
         nf = self._norm_fused(M) and ops.norm_fusion_part("fwd")          # K1n: the two norms + residual sums of a layer inside the GEMM epilogues around them
         ready = None                      # (h, rstd1) of this layer, left by the previous layer's down-projection epilogue
         nL = len(self.layers)
@@ -374,8 +396,9 @@ class LlamaLRP:
                 h1, ssq = new(("h1", li), M, H), ar.get("ssq", (H // 64, M), torch.float32)
                 ops.gemm_res_ssq(o, Lw["wo"], st["h"], h1, ssq)
                 st["rstd2"] = ops.rms_rstd(ssq, M, H, c["rms_eps"], f32(("rstd2", li), M))
-                gu, m = ops.gemm_gated_fwd_rs(h1, Lw["wgu"], st["rstd2"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
-                st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=None, h1=h1, gu=gu, dn=None)
+                gu, m = ops.gemm_gated_fwd_coef(h1, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.eps_g, self.eps["lin"], self.act,
+                                                rs=st["rstd2"])
+                st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=None, h1=h1, gu=gu, coef=True, dn=None)
                 stash.append(st)
                 if li + 1 < nL:
                     hn = new(("h", li + 1), M, H)
@@ -390,9 +413,12 @@ class LlamaLRP:
             h1 = new(("h1", li), M, H)
             x2, st["rstd2"] = new("x2", M, H), f32(("rstd2", li), M)
             ops.add_rmsnorm_fwd(st["h"], a, Lw["ln2"], c["rms_eps"], hsum_out=h1, y=x2, rstd=st["rstd2"])
-            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
+            if coef:      # the gated rules inside the two GEMMs around them: the backward's coefficients are stashed in gu's place (g, u never stored)
+                gu, m = ops.gemm_gated_fwd_coef(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.eps_g, self.eps["lin"], self.act)
+            else:
+                gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
             dn = self._lin_fwd(m, Lw["wd"], new(("dn", li), M, H))
-            st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, dn=dn)
+            st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a, h1=h1, gu=gu, coef=coef, dn=dn)
             stash.append(st)
             h_prev, branch = h1, dn
         # last token only: final residual add + norm + LM head
@@ -445,7 +471,7 @@ class LlamaLRP:
         nfb = plain_add and self._norm_fused(M)                  # K1n in the backward (independent of what the forward ran: both need only rstd)
         # attn_bwd_prep folded away (efficient placement, the bf16 kernels that take every operand token-major, M = B S rows)
         fuse_prep = (plain_add and E["pv"] == 0.0 and E["mask"] == 0.0 and E["qk"] == 0.0 and not self.attn_t and ops.attn_dq_d_ok(dt, d)
-                     and bool(self.layers) and ops.norm_fused_ok(M, nq * d, H, H, self.layers[0]["wo"].stride(0), True, dt))
+                     and bool(self.layers) and ops.norm_fused_ok(M, nq * d, H, H, self.layers[0]["wo"].stride(0), True, dt))      # (Aa [M, H] contiguous)
         half = ar.get("half", (M,), torch.float32).fill_(0.5) if fuse_prep else None
         fuse_rope = fuse_prep and ops.ROPE_BWD_FUSION and E["rope"] == 0.0 and E["lin"] == 0.0 and d in (64, 128) and S <= self.max_seq
 
@@ -475,7 +501,10 @@ class LlamaLRP:
             else:
                 gu = st["gu"]
                 # ---- MLP
-                Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
+                if st.get("coef", False):
+                    Agu = ops.gemm_gated_bwd_coef(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I))
+                else:
+                    Agu = ops.gemm_gated_bwd(Adn, Lw["wd"], gu, wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
                 Gs1 = new("Gs1", M, H)
                 if nfb and ops.norm_fusion_part("bwd_gu"):               # K1n: Gs1 = rstd2 (.) (Agu W'gu) + Gs in the dgrad GEMM's epilogue
                     Aa = ops.gemm_nn_rs_res(Agu, Lw["wgu"], st["rstd2"], Gs, Gs1)
@@ -506,7 +535,7 @@ class LlamaLRP:
             dk_h, dv_h = new("dk_h", M, nq * d), new("dv_h", M, nq * d)
             # (row pitch off the 4-KiB grid: the dQ kernel stores one row segment per lane straight into it, and 12 KiB would put them all on the
             # same channels -- dqk's 10 KiB never did)
-            Aqkv = ar.get("Aqkv", (M, nqkv), dt, pad=(64 if (nqkv * emb.element_size()) % 4096 == 0 and PITCH_PAD else 0))
+            Aqkv = ar.get("Aqkv", (M, nqkv), dt, pad=self._pitches()["Aqkv_pad"])
             if fuse_prep and q_begin == 0 and fuse_rope:
                 # RoPE's backward rides on the dQ store and on dK's group sum (no rope_bwd pass, no dqk round trip): both write Aqkv directly
                 ops.attn_bwd_dq_d(q, k, v, Gho, st["o"], st["lse"], D, Aqkv[:, : nq * d], B, S, nq, nk, d, scale, row_iv=row_iv,
@@ -563,7 +592,6 @@ class LlamaLRP:
     # ---------------------------------------------------------------------------------------------
     def _run(self, input_ids, emb, B, S, row_iv, idx, layer_relevance, return_G, seed):
         """forward + backward + read-out on the current stream: library launches only, no host synchronisation (capturable)"""
-        ops.ensure_gemm_scratch(self.device)      # de-phased GEMM tile walk: the current stream's scratch for the parked accumulators (once per stream)
         if emb is None:
             emb = self.embed.index_select(0, input_ids.reshape(-1))
         fw = self.forward(emb, B, S, row_iv)

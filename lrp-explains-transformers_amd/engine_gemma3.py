@@ -208,11 +208,15 @@ class Gemma3LRP:
             ops.add_rmsnorm_fwd(a, None, Lw["ln_pa"], eps, 1.0, y=pa, rstd=st["rstd_pa"])
             h1, x2, st["rstd2"] = new(("h1", li & 1), M, H), new("x2", M, H), f32(("rstd2", li), M)
             ops.add_rmsnorm_fwd(h, pa, Lw["ln_pf"], eps, 1.0, hsum_out=h1, y=x2, rstd=st["rstd2"])
-            gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
+            coef = ops.gated_coef_ok(M, I, H, H, Lw["wgu"].stride(0), H, Lw["wd"].stride(0), self.act, dt)
+            if coef:      # gated rules inside the two GEMMs: the backward's coefficients are stashed in gu's place (ops.gemm_gated_fwd_coef)
+                gu, m = ops.gemm_gated_fwd_coef(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.eps_g, self.eps["lin"], self.act)
+            else:
+                gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
             dn = ops.linear_fwd(m, Lw["wd"], out=new("dn", M, H))
             pff, st["rstd_pff"] = new("pff", M, H), f32(("rstd_pff", li), M)
             ops.add_rmsnorm_fwd(dn, None, Lw["ln_pff"], eps, 1.0, y=pff, rstd=st["rstd_pff"])
-            st.update(qkv=qkv, qr=qr, kr=kr, o=o, lse=lse, gu=gu)
+            st.update(qkv=qkv, qr=qr, kr=kr, o=o, lse=lse, gu=gu, coef=coef)
             stash.append(st)
             h_prev, branch = h1, pff
         last = torch.arange(B, device=dev) * S + (S - 1)
@@ -244,7 +248,10 @@ class Gemma3LRP:
             # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
             Gdn = new("Gdn", M, H)
             ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
-            Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
+            if st["coef"]:
+                Agu = ops.gemm_gated_bwd_coef(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I))
+            else:
+                Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
             Gx2 = ops.linear_dgrad(Agu, Lw["wgu"], out=new("Gx2", M, H))
             Gs1 = new("Gs1", M, H)
             ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1

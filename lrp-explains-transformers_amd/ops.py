@@ -444,48 +444,54 @@ def gated_act_bwd_il(Gm, gu, Agu, eps_g, eps_lin, act="silu"):
 
 
 GATED_FUSION = True      # module attribute (no environment knobs): False = GEMM + element-wise rule kernels, for A/B measurements and the
-                         # fused-equals-unfused tests
+                         # fused-vs-unfused tests
+
+
+def gated_coef_ok(M, I, H, ldx, ldwgu, lda, ldwd, act, dtype):
+    """both GEMMs around the gated rule are problems the fused epilogues take (lrp_gemm_gated_fwd_coef / _bwd_coef: bf16, M = B S rows)"""
+    return bool(GATED_FUSION and dtype == torch.bfloat16 and M > SKINNY_MAX
+                and lib.lrp_gemm_gated_coef_ok(M, I, H, ldx, ldwgu, lda, ldwd, ACT[act], _DT[dtype]))
+
+
+def gemm_gated_fwd_coef(x, Wgu, coef, m, eps_g, eps_lin, act="silu", rs=None):
+    """ONE launch: m[M, I] = act(g) (*) u and the backward's coefficient stash coef[M, 2 I] (cg = 1/2 u act(g) / (g + eps_g),
+    cu = 1/2 act(g) u / (u + eps_lin); layout private to the pair, include/lrp_hip.h) from x @ Wgu^T (Wgu interleaved, see interleave_gate_up);
+    rs: optional fp32 row scales applied to the product first (K1n).  g and u are never stored."""
+    M, K = x.shape
+    I = m.shape[1]
+    same(x, Wgu, coef, m)
+    if rs is not None:
+        f32(rs)
+    _timed(2.0 * M * 2 * I * K, "gated_fwd", lambda: lib.lrp_gemm_gated_fwd_coef(p(x), p(Wgu), p(rs), p(coef), p(m), M, I, K, x.stride(0), Wgu.stride(0),
+                                                                                 coef.stride(0), m.stride(0), eps_g, eps_lin, ACT[act], dt(x), stream()),
+           "lrp_gemm_gated_fwd_coef")
+    return coef, m
+
+
+def gemm_gated_bwd_coef(Adn, Wd, coef, Agu):
+    """Agu[M, 2 I] (interleaved) = { Gm cg | Gm cu } with Gm = A_dn Wd (stored down weight Wd [H, I]) never written: the multiply runs in the NN
+    GEMM's epilogue on the stash lrp_gemm_gated_fwd_coef left"""
+    M, K = Adn.shape
+    I = Wd.shape[1]
+    same(Adn, Wd, coef, Agu)
+    _timed(2.0 * M * I * K, "gated_bwd", lambda: lib.lrp_gemm_gated_bwd_coef(p(Adn), p(Wd), p(coef), p(Agu), M, I, K, Adn.stride(0), Wd.stride(0),
+                                                                             coef.stride(0), Agu.stride(0), dt(Adn), stream()), "lrp_gemm_gated_bwd_coef")
+    return Agu
 
 
 def gemm_gated_fwd(x, Wgu, gu, m, act="silu"):
-    """gu[M, 2 I] = x @ Wgu^T (Wgu interleaved, see interleave_gate_up) and m[M, I] = act(g) (*) u: ONE kernel on the big bf16 problems
-    (the gated rule runs in the GEMM's epilogue), the GEMM / skinny / small-M forward + lrp_gated_act_fwd_il otherwise"""
-    M, K = x.shape
-    I = m.shape[1]
+    """gu[M, 2 I] = x @ Wgu^T (Wgu interleaved, see interleave_gate_up) and m[M, I] = act(g) (*) u: the GEMM / skinny / small-M forward +
+    lrp_gated_act_fwd_il (small M, fp32; M = B S rows in bf16 take gemm_gated_fwd_coef)"""
     same(x, Wgu, gu, m)
-    if GATED_FUSION and x.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(x, Wgu):
-        ev = GEMM_TIMER.span(2.0 * M * 2 * I * K, "gated_fwd") if GEMM_TIMER is not None else None
-        if ev:
-            ev[0].record()
-        rc = lib.lrp_gemm_gated_fwd(p(x), p(Wgu), p(gu), p(m), M, I, K, x.stride(0), Wgu.stride(0), gu.stride(0), m.stride(0), ACT[act],
-                                    dt(x), stream())
-        if ev:
-            ev[1].record()
-        check(rc, "lrp_gemm_gated_fwd")
-        return gu, m
     linear_fwd(x, Wgu, out=gu)
     gated_act_fwd_il(gu, m, act)
     return gu, m
 
 
 def gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act="silu"):
-    """Agu[M, 2 I] (interleaved) from A_dn[M, H] and the stored down weight Wd [H, I]: Gm = A_dn Wd never reaches memory on the big bf16
-    problems (the gated backward rule runs in the NN GEMM's epilogue); otherwise ops.linear_dgrad + lrp_gated_act_bwd_il"""
-    M, K = Adn.shape
-    I = Wd.shape[1]
+    """Agu[M, 2 I] (interleaved) from A_dn[M, H], the stored down weight Wd [H, I] and the stored gate/up output: ops.linear_dgrad +
+    lrp_gated_act_bwd_il"""
     same(Adn, Wd, gu, Agu)
-    if GATED_FUSION and Adn.dtype == torch.bfloat16 and M > SKINNY_MAX and gemm_nn_ok(Adn, Wd):
-        need = lib.lrp_gemm_gated_bwd_ws(M, I, K, Adn.stride(0), Wd.stride(0), ACT[act], dt(Adn))
-        ws = workspace(need, Adn) if need else None
-        ev = GEMM_TIMER.span(2.0 * M * I * K, "gated_bwd") if GEMM_TIMER is not None else None
-        if ev:
-            ev[0].record()
-        rc = lib.lrp_gemm_gated_bwd(p(Adn), p(Wd), p(gu), p(Agu), M, I, K, Adn.stride(0), Wd.stride(0), gu.stride(0), Agu.stride(0),
-                                    eps_g, eps_lin, ACT[act], dt(Adn), p(ws), stream())
-        if ev:
-            ev[1].record()
-        check(rc, "lrp_gemm_gated_bwd")
-        return Agu
     Gm = linear_dgrad(Adn, Wd)
     return gated_act_bwd_il(Gm, gu, Agu, eps_g, eps_lin, act)
 
@@ -511,32 +517,6 @@ def rope_bwd(Gr, xr, x, A, cos, sin, seq, n_heads, d, eps_rope, eps_lin):
 
 
 # ---------------------------------------------------------------------------------------- row ops
-# ---- de-phased tile walk of the ping-pong GEMM (include/lrp_hip.h: lrp_set_gemm_scratch): one caller-owned scratch region per (device, stream)
-# module attribute.  True = register the scratch (de-phased walk); False (default) = one sitting per tile, the lock-step walk -- same results bit
-# for bit.  OFF because it measured NEGATIVE in situ (profiles/r05_gemm_experiments.txt, section K): 8-layer judged step 43.56 -> 44.47 ms; the
-# fused down-projection dgrad 808 -> 835 us, gate/up forward 1370 -> 1383 us, plain launches 0.594 -> 0.576 of peak: parking and reloading one
-# tile per CU (2 x 64 MB per launch) costs ~25 us per launch and the epilogues it spreads out were not waiting for HBM in the first place
-# (they are bound by their own instruction issue and load latency per CU).
-GEMM_DEPHASE = False
-_gemm_scratch = {}
-
-
-def ensure_gemm_scratch(device=None):
-    """register the parked-accumulator scratch of the CURRENT stream with the library (idempotent; call once per explain / per capture)"""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    key = (dev.index, st)
-    want = bool(GEMM_DEPHASE)
-    have = _gemm_scratch.get(key)
-    if want and have is None:
-        buf = torch.empty(int(lib.lrp_gemm_scratch_bytes()), dtype=torch.uint8, device=dev)
-        check(lib.lrp_set_gemm_scratch(buf.data_ptr(), buf.numel(), st), "lrp_set_gemm_scratch")
-        _gemm_scratch[key] = buf
-    elif not want and have is not None:
-        check(lib.lrp_set_gemm_scratch(None, 0, st), "lrp_set_gemm_scratch")
-        del _gemm_scratch[key]
-
-
 # ---- K1n: RMSNorm folded into the GEMMs around it (include/lrp_hip.h; ref lxt/efficient/patches.py:111-123 + the residual sums of HF modeling_llama)
 # module attribute: True (default) = every part; False = the stand-alone add_rmsnorm_fwd / rmsnorm_bwd_add2 launches (A/B measurements, equality
 # tests); a set of {"fwd", "bwd_qkv", "bwd_gu"} = the named parts.  In situ, 8-layer judged step (tools/r5_k1n_parts.sh, final kernel, three
@@ -604,17 +584,6 @@ def gemm_nn_rs(s, W, rs, out):
     _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_nn_rs(p(s), p(W), p(rs), p(out), M, N, K, s.stride(0), W.stride(0), out.stride(0),
                                                                      dt(s), stream()), "lrp_gemm_nn_rs")
     return out
-
-
-def gemm_gated_fwd_rs(x, Wgu, rs, gu, m, act="silu"):
-    M, K = x.shape
-    I = m.shape[1]
-    same(x, Wgu, gu, m)
-    f32(rs)
-    _timed(2.0 * M * 2 * I * K, "gated_fwd", lambda: lib.lrp_gemm_gated_fwd_rs(p(x), p(Wgu), p(rs), p(gu), p(m), M, I, K, x.stride(0), Wgu.stride(0),
-                                                                               gu.stride(0), m.stride(0), ACT[act], dt(x), stream()),
-           "lrp_gemm_gated_fwd_rs")
-    return gu, m
 
 
 def gemm_nn_rs_res(s, W, rs, res, out):

@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     raw = ctypes.CDLL(L.LIB_PATH)
     for name in decls:
         assert hasattr(raw, name), f"{name} declared in lrp_hip.h but not exported"
-    assert L.lib.lrp_version() == 6 and L.lib.lrp_build_arch() == b"gfx950"
+    assert L.lib.lrp_version() == 7 and L.lib.lrp_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu():
@@ -51,8 +51,14 @@ def test_round5_host_side_queries_and_layout_rules():
     # dQ with D (and RoPE's backward): the bf16 32x32 kernels of head dims 64 / 96 / 128
     assert [lib.lrp_attn_bwd_dq_d_ok(BF16, d) for d in (64, 96, 128, 256, 32)] == [1, 1, 1, 0, 0] and lib.lrp_attn_bwd_dq_d_ok(F32, 128) == 0
     assert lib.lrp_gqa_reduce_rope(None, None, 8, 8, 2, 2, 64, 256, 128, None, None, BF16, None) == -1
-    assert lib.lrp_set_gemm_scratch(1, 0, None) == -1 and lib.lrp_set_gemm_scratch(None, 0, None) == 0     # bad size refused; dropping nothing is fine
-    assert lib.lrp_gemm_scratch_bytes() % (32 * 512 * 16) == 0
+    # the fused gated-MLP pair (coefficient stash): both launches must be >= 190-tile bf16 problems
+    assert lib.lrp_gemm_gated_coef_ok(8192, 14336, 4096, 4096, 4224, 4096, 14400, 0, BF16) == 1
+    assert lib.lrp_gemm_gated_coef_ok(2048, 14336, 4096, 4096, 4224, 4096, 14400, 0, BF16) == 1        # 8 x 56 = 448 tiles in the backward
+    assert lib.lrp_gemm_gated_coef_ok(256, 14336, 4096, 4096, 4224, 4096, 14400, 0, BF16) == 0         # 56 tiles
+    assert lib.lrp_gemm_gated_coef_ok(8192, 14336, 4096, 4096, 4224, 4096, 14400, 2, BF16) == 0        # erf-GELU: no fused form
+    assert lib.lrp_gemm_gated_coef_ok(8192, 14336, 4096, 4096, 4224, 4096, 14400, 0, F32) == 0
+    assert lib.lrp_gemm_gated_fwd_coef(None, None, None, None, None, 8, 32, 128, 128, 128, 64, 32, 1e-10, 0.0, 0, BF16, None) == -1
+    assert lib.lrp_gemm_gated_bwd_coef(None, None, None, None, 8, 32, 128, 128, 32, 64, 64, BF16, None) == -1
     # row-pitch rules (pure functions)
     import lxt_amd.engine as E
     assert E.weight_pitch_pad(4096, 2, 28672) == 128 and E.weight_pitch_pad(4096, 2, 2048) == 0          # 8-KiB pitch: padded when the weight exceeds the caches

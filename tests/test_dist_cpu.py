@@ -108,6 +108,14 @@ def test_bench_launch_contract_dry_run():
     assert d["host"]["cpus"] >= 1
     r1 = subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--dry-run"], capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+    # the BARE form `python bench.py --gpus 2` (no launcher, no RANK in the environment: how the driver runs --gpus 1): bench.py re-executes
+    # itself through torch.distributed.run and still prints exactly one line, from rank 0
+    bare_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"], env=bare_env, capture_output=True,
+                        text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    assert len(l2) == 1 and json.loads(l2[0])["n_gpus"] == 2 and [e["rank"] for e in json.loads(l2[0])["per_rank"]] == [0, 1]
 
 
 def test_checksum_is_position_sensitive():

@@ -327,12 +327,10 @@ def _act64(x, act):
     return torch.nn.functional.gelu(x, approximate="tanh")
 
 
-@pytest.mark.parametrize("M,I,K,act", [(4096, 4096, 1024, "silu"), (3000, 3584, 256, "gelu_tanh"), (3000, 7168, 128, "silu"), (300, 512, 128, "silu"), (40, 64, 256, "silu")])
-def test_gemm_gated_fused_epilogues(ops, M, I, K, act):
-    """lrp_gemm_gated_fwd / _bwd: the gated-MLP rules (ref lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281)
-    inside the epilogues of the gate/up forward GEMM and of the down-projection dgrad (NN form), on the interleaved gate/up layout
-    (ops.interleave_gate_up).  Big shapes take the fused ping-pong kernel (full and ragged tiles), small ones the GEMM + element-wise
-    pair; both against fp64 on the same bf16 operands, and the fused kernels against the unfused pair bit for bit."""
+@pytest.mark.parametrize("M,I,K,act", [(300, 512, 128, "silu"), (40, 64, 256, "silu"), (520, 1024, 256, "gelu_tanh")])
+def test_gemm_gated_pair(ops, M, I, K, act):
+    """lrp_gemm_gated_fwd / _bwd: the gate/up Linear + the element-wise gated-MLP rule kernels on the STORED gate/up output (small M; ref
+    lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281), interleaved layout (ops.interleave_gate_up), vs fp64."""
     g_ = torch.Generator().manual_seed(M + I)
     bf = torch.bfloat16
     x = torch.randn(M, K, generator=g_).to(bf).cuda()
@@ -348,28 +346,86 @@ def test_gemm_gated_fused_epilogues(ops, M, I, K, act):
     assert nmax(g, g64) < 2e-2 and nmax(u, u64) < 2e-2
     m_ref = _act64(f64(g), act).to(bf).double() * f64(u)          # from the STORED g, u: the rule itself is exact up to one rounding
     assert not torch.isnan(m).any() and nmax(m, m_ref) < 1e-2
-    gu2, m2 = torch.empty_like(gu), torch.empty_like(m)            # unfused pair
-    ops.linear_fwd(x, Wgu, out=gu2)
-    ops.gated_act_fwd_il(gu2, m2, act)
-    assert torch.equal(gu, gu2) and torch.equal(m, m2)
-    # ---- backward: A_dn [M, H'] with H' = K, down weight Wd [K, I]
     Adn = torch.randn(M, K, generator=g_).to(bf).cuda()
     Wd = (torch.randn(K, I, generator=g_) * K ** -0.5).to(bf).cuda()
     for eps_g, eps_lin in ((1e-10, 0.0), (1e-8, 1e-8)):
         Agu = torch.full((M, 2 * I), float("nan"), dtype=bf, device="cuda")
         ops.gemm_gated_bwd(Adn, Wd, gu, Agu, eps_g, eps_lin, act)
         Gm = ops.linear_dgrad(Adn, Wd)
-        Agu2 = torch.empty_like(Agu)
-        ops.gated_act_bwd_il(Gm, gu, Agu2, eps_g, eps_lin, act)
-        assert not torch.isnan(Agu).any() and torch.equal(Agu, Agu2)
         av = Agu.view(M, I // 32, 2, 32)
         Ag, Au = av[:, :, 0].reshape(M, I), av[:, :, 1].reshape(M, I)
         y = _act64(f64(g), act).to(bf).double()
         half = 0.5 * f64(Gm)
         Ag_ref = half * f64(u) * (y / (f64(g) + eps_g))
         Au_ref = half * y * (f64(u) / (f64(u) + eps_lin) if eps_lin else 1.0)
-        assert nmax(Ag, Ag_ref) < 2e-2 and nmax(Au, Au_ref) < 2e-2
+        assert not torch.isnan(Agu).any() and nmax(Ag, Ag_ref) < 2e-2 and nmax(Au, Au_ref) < 2e-2
         assert nmax(Gm, f64(Adn) @ f64(Wd)) < 2e-2
+
+
+def _coef_split(coef, I):
+    """the stash of lrp_gemm_gated_fwd_coef (include/lrp_hip.h): columns 8 t .. 8 t + 7 of a row = { cg x 4 | cu x 4 } of intermediate indices 4 t .. 4 t + 3"""
+    v = coef.view(coef.shape[0], I // 4, 2, 4)
+    return v[:, :, 0].reshape(-1, I), v[:, :, 1].reshape(-1, I)
+
+
+@pytest.mark.parametrize("M,I,K,act,scaled", [(4096, 4096, 1024, "silu", False), (3000, 7168, 256, "gelu_tanh", False), (3000, 7168, 128, "silu", True),
+                                              (8192, 2048, 512, "silu", True)])
+def test_gemm_gated_coef_epilogues(ops, M, I, K, act, scaled):
+    """lrp_gemm_gated_fwd_coef / _bwd_coef (round 6): the gated-MLP rules (ref lxt/efficient/patches.py:145-157, lxt/efficient/rules.py:88-100,
+    lxt/explicit/models/llama.py:84-86,273-281) inside the epilogues of the gate/up forward GEMM and of the down-projection dgrad (NN form).  The
+    forward leaves m = act(g) u and the COEFFICIENTS cg = 1/2 u act(g) / (g + eps_g), cu = 1/2 act(g) u / (u + eps_lin); the backward is
+    Agu = Gm (*) (cg | cu).  Full and ragged tiles, both rule placements, both activations, with and without the K1n row scale -- against fp64 on
+    the same bf16 operands, and against the GEMM + element-wise pair to bf16 rounding."""
+    g_ = torch.Generator().manual_seed(M + I)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, generator=g_).to(bf).cuda()
+    wg, wu = ((torch.randn(I, K, generator=g_) * K ** -0.5).to(bf).cuda() for _ in range(2))
+    Wgu = ops.interleave_gate_up(wg, wu)
+    rs = (torch.rand(M, generator=g_) + 0.5).cuda() if scaled else None
+    Adn = torch.randn(M, K, generator=g_).to(bf).cuda()
+    Wd = (torch.randn(K, I, generator=g_) * K ** -0.5).to(bf).cuda()
+    assert ops.gated_coef_ok(M, I, K, K, K, K, I, act, bf)
+    assert not ops.gated_coef_ok(300, I, K, K, K, K, I, act, bf) and not ops.gated_coef_ok(M, I, K, K, K, K, I, act, torch.float32)
+    g64, u64 = f64(x) @ f64(wg).T, f64(x) @ f64(wu).T
+    if scaled:
+        g64, u64 = g64 * rs.double()[:, None], u64 * rs.double()[:, None]
+    y64 = _act64(g64, act)
+    Gm64 = f64(Adn) @ f64(Wd)
+    live = g64.abs() > 1e-3                      # (the stabilised ratios are compared away from their poles at g, u = -eps)
+    live_u = u64.abs() > 1e-3
+    # unfused pair for the cross-check
+    gu2, m2 = torch.empty(M, 2 * I, dtype=bf, device="cuda"), torch.empty(M, I, dtype=bf, device="cuda")
+    if not scaled:
+        ops.gemm_gated_fwd(x, Wgu, gu2, m2, act)
+    for eps_g, eps_lin in ((1e-10, 0.0), (1e-8, 1e-8)):
+        coef, m = torch.full((M, 2 * I), float("nan"), dtype=bf, device="cuda"), torch.full((M, I), float("nan"), dtype=bf, device="cuda")
+        ops.gemm_gated_fwd_coef(x, Wgu, coef, m, eps_g, eps_lin, act, rs=rs)
+        assert not torch.isnan(m).any() and not torch.isnan(coef).any()
+        assert nmax(m, y64 * u64) < 1e-2
+        cg, cu = _coef_split(coef, I)
+        cg_ref = torch.where(live, 0.5 * u64 * y64 / (g64 + eps_g), torch.zeros_like(g64))
+        cu_ref = 0.5 * y64 * (torch.where(live_u, u64 / (u64 + eps_lin), torch.ones_like(u64)) if eps_lin else 1.0)
+        assert nmax(torch.where(live, cg.double(), torch.zeros_like(g64)), cg_ref) < 1e-2
+        assert nmax(torch.where(live_u, cu.double(), cu_ref), cu_ref) < 1e-2
+        Agu = torch.full((M, 2 * I), float("nan"), dtype=bf, device="cuda")
+        ops.gemm_gated_bwd_coef(Adn, Wd, coef, Agu)
+        assert not torch.isnan(Agu).any()
+        av = Agu.view(M, I // 32, 2, 32)
+        Ag, Au = av[:, :, 0].reshape(M, I), av[:, :, 1].reshape(M, I)
+        # exactly the rule on the STORED coefficients (one product, one rounding) ...
+        assert nmax(Ag, Gm64 * cg.double()) < 1e-2 and nmax(Au, Gm64 * cu.double()) < 1e-2
+        # ... and the reference's rule in fp64
+        assert nmax(torch.where(live, Ag.double(), torch.zeros_like(g64)), Gm64 * cg_ref) < 2e-2
+        assert nmax(torch.where(live_u, Au.double(), Gm64 * cu_ref), Gm64 * cu_ref) < 2e-2
+        if not scaled:
+            assert nmax(m, m2.double()) < 1e-2
+            Agu2 = torch.empty_like(Agu)
+            ops.gemm_gated_bwd(Adn, Wd, gu2, Agu2, eps_g, eps_lin, act)
+            a2 = Agu2.view(M, I // 32, 2, 32)
+            Ag2, Au2 = a2[:, :, 0].reshape(M, I).double(), a2[:, :, 1].reshape(M, I).double()
+            z = torch.zeros_like(g64)
+            assert nmax(torch.where(live, Ag.double(), z), torch.where(live, Ag2, z)) < 2e-2
+            assert nmax(torch.where(live_u, Au.double(), z), torch.where(live_u, Au2, z)) < 2e-2
 
 
 @pytest.mark.parametrize("M,H,K,I", [(2304, 5632, 512, 2816), (2100, 5632, 256, 3072)])
@@ -407,16 +463,7 @@ def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     ops.gemm_nt_rs(out, W2, rstd, y)
     y_ref = rstd.double()[:, None] * (f64(out) @ f64(W2).T)
     assert not torch.isnan(y).any() and nmax(y, y_ref) < 1e-2
-    # ---- gate/up consumer with the gated rule behind the row scale: gu = the scaled product, m = act(g) (*) u from the stored gu
-    wg, wu = mk(I, H, sc=H ** -0.5), mk(I, H, sc=H ** -0.5)
-    Wgu = ops.interleave_gate_up(wg, wu)
-    gu, m = torch.full((M, N2), float("nan"), dtype=bf, device="cuda"), torch.full((M, I), float("nan"), dtype=bf, device="cuda")
-    ops.gemm_gated_fwd_rs(out, Wgu, rstd, gu, m, "silu")
-    gu_ref = rstd.double()[:, None] * (f64(out) @ f64(Wgu).T)
-    assert not torch.isnan(gu).any() and nmax(gu, gu_ref) < 1e-2
-    m2 = torch.empty_like(m)
-    ops.gated_act_fwd_il(gu, m2, "silu")
-    assert torch.equal(m, m2)
+    # (the gate/up consumer with the gated rule behind the row scale: test_gemm_gated_coef_epilogues, scaled cases)
     # ---- backward: G_h = rstd (.) (A W) + G_res from the stored weight (NN), also in place on the residual gradient
     A = mk(M, N2)
     Gres = mk(M, H)
@@ -435,62 +482,6 @@ def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     inpl = Gres.clone()
     ops.gemm_nn_rs_res(A, W2, rstd, inpl, inpl)
     assert torch.equal(inpl, Gh)
-
-
-def test_gemm_dephased_walk_is_bitwise_the_lockstep_walk(ops):
-    """lrp_set_gemm_scratch (include/lrp_hip.h): with scratch registered for the stream a workgroup of the ping-pong GEMM computes its first
-    tile in two sittings -- K tiles [0, phi) at the start, the partial sums parked in fp32, [phi, nkt) at the very end -- the SAME summation
-    order as one sitting, so every instantiation must return the same bits with and without the scratch.  Shapes with 2 ... 14 tiles per CU,
-    ragged rows, short K (phi must leave two K tiles per sitting; K = 192 has 3 K tiles: no split possible)."""
-    bf = torch.bfloat16
-    g_ = torch.Generator().manual_seed(99)
-    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g_) * sc).to(bf).cuda()      # noqa: E731
-    keep = ops.GEMM_DEPHASE
-
-    def run_all():
-        out = {}
-        for (M, N, K) in ((8192, 4096, 1024), (4200, 8192, 256), (8192, 4096, 192)):
-            x, W, Wn = mk(M, K), mk(N, K, sc=K ** -0.5), mk(K, N, sc=K ** -0.5)
-            out[("nt", M, N, K)] = (ops.linear_fwd(x, W), x, W)
-            out[("nn", M, N, K)] = (ops.linear_dgrad(x, Wn), x, Wn)
-            res, rs = mk(M, N), torch.rand(M, generator=g_).cuda() + 0.5
-            o, ssq = torch.empty(M, N, dtype=bf, device="cuda"), torch.empty(N // 64, M, device="cuda")
-            ops.gemm_res_ssq(x, W, res, o, ssq)
-            out[("res", M, N, K)] = (o, ssq)
-            o2 = torch.empty(M, N, dtype=bf, device="cuda")
-            ops.gemm_nn_rs_res(x, Wn, rs, res, o2)
-            out[("nnres", M, N, K)] = (o2,)
-        M, I, K = 4096, 7168, 512
-        x = mk(M, K)
-        Wgu = ops.interleave_gate_up(mk(I, K, sc=K ** -0.5), mk(I, K, sc=K ** -0.5))
-        gu, m = torch.empty(M, 2 * I, dtype=bf, device="cuda"), torch.empty(M, I, dtype=bf, device="cuda")
-        ops.gemm_gated_fwd(x, Wgu, gu, m, "silu")
-        Adn, Wd = mk(M, K), mk(K, I, sc=K ** -0.5)
-        Agu = torch.empty(M, 2 * I, dtype=bf, device="cuda")
-        ops.gemm_gated_bwd(Adn, Wd, gu, Agu, 1e-10, 0.0, "silu")
-        out["gated"] = (gu, m, Agu)
-        return out
-
-    try:
-        ops.GEMM_DEPHASE = False
-        ops.ensure_gemm_scratch()
-        g_.manual_seed(99)
-        lock = run_all()
-        ops.GEMM_DEPHASE = True
-        ops.ensure_gemm_scratch()
-        g_.manual_seed(99)
-        deph = run_all()
-    finally:
-        ops.GEMM_DEPHASE = keep
-        ops.ensure_gemm_scratch()
-    for key, vals in lock.items():
-        for a, b in zip(vals, deph[key]):
-            assert not torch.isnan(b.float()).any() and torch.equal(a, b), key
-    for key, vals in deph.items():
-        if key[0] == "nt":
-            assert nmax(vals[0], f64(vals[1]) @ f64(vals[2]).T) < 2e-2, key
-        if key[0] == "nn":
-            assert nmax(vals[0], f64(vals[1]) @ f64(vals[2])) < 2e-2, key
 
 
 def test_gemm_batched_and_f32_out(ops):
