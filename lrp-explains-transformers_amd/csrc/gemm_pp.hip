@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // EPI 2: the coefficient loads of the first row block, likewise ahead of the staging pieces.  Lane (row l & 15, hi) reads, for column tile j,
     // the 16 bytes {cg x 4 | cu x 4} of ITS four intermediate indices ncol + 16 j + 4 hi .. + 3: the stash is in accumulator order (no cross-lane
     // exchange on either side), 64 contiguous bytes per row and wave instruction
-    u32x4 gpre[2][4];
+    u32x4 gpre[4][4];                                                  // coefficient quads of row block k in gpre[k & 3]
     auto issue_gu = [&](int b, u32x4 (&d)[4]) {
         const bf16_t* p = ep.gu + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldgu + 2 * (int64_t)ncol + 8 * hi;
 #pragma unroll
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         // lxt/efficient/rules.py:88-100, lxt/explicit/models/llama.py:84-86,273-281) -- so the rule here is Agu = Gm (*) (cg | cu): one multiply and
         // one pack per element, no v_exp / v_rcp (the round-5 epilogue recomputed act(g) from the stashed g: ~310 VALU instructions per 16 pairs,
         // 20 of the 26 us a tile's epilogue took).  Agu keeps the GEMM-operand layout [32 gate | 32 up] per 64 columns (v_permlane16_swap pairing).
-        // Software-pipelined over the 8 row blocks (a, i): the four 16-byte loads of block b + 2 are issued right after block b's
-        // stores, into the registers block b just released -- 8 loads in flight per wave.
+        // Software-pipelined over the 8 row blocks (a, i), DEEPER as the accumulators drain (as EPI 3 / 4 below): block 0 was requested ahead
+        // of the staging pieces, block 1 goes out first thing here; behind block 0's stores go the loads of blocks 2 AND 3 (into the registers
+        // block 0's accumulators and coefficients just released), behind block 1's those of 4 and 5, then one per block: up to four blocks =
+        // 16 x 16 B per lane in flight.  (With the rule reduced to a multiply the epilogue is bound by the coefficient stream itself: the 256
+        // CUs reach it together and pull 0.47 GB per round.)
         if (full) {
             bf16_t* adst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + 2 * (int64_t)ncol + epoff;
             auto& pre = gpre;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 f32x4 ag[4], au[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32x4 c = pre[b & 1][j];
+                    const u32x4 c = pre[b & 3][j];
                     const f32x4 gm4 = acc[b >> 2][b & 3][j];
                     ag[j] = f32x4{gm4[0] * bf16_lo(c[0]), gm4[1] * bf16_hi(c[0]), gm4[2] * bf16_lo(c[1]), gm4[3] * bf16_hi(c[1])};
                     au[j] = f32x4{gm4[0] * bf16_lo(c[2]), gm4[1] * bf16_hi(c[2]), gm4[2] * bf16_lo(c[3]), gm4[3] * bf16_hi(c[3])};
@@ -392,7 +395,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + 32 * k) = out[k];
-                if (b + 2 < 8) issue_gu(b + 2, pre[b & 1]);
+                if (b == 0) { issue_gu(2, pre[2]); issue_gu(3, pre[3]); }
+                else if (b == 1) { issue_gu(4, pre[0]); issue_gu(5, pre[1]); }
+                else if (b == 2) issue_gu(6, pre[2]);
+                else if (b == 3) issue_gu(7, pre[3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             done = true;

@@ -218,6 +218,12 @@ __global__ __launch_bounds__(256, (MBMAX <= 4) ? 2 : 1) void linear_stream_fwd_k
             __syncthreads();
             const unsigned nsp = gridDim.y;
             if (tk[0] != nsp - 1) return;
+            // last arriver.  Ordering: the producers' side is the hardware path -- sc1 write-through stores, drained by vmcnt(0) and a
+            // workgroup barrier BEFORE the ticket atomic is issued, so the slabs are at the device coherence point when the ticket moves (a RELEASE
+            // on the ticket would add a whole-L2 write-back per workgroup: round 3 measured that at more than the second launch it replaces); the
+            // consumer's side is made explicit: an agent-scope ACQUIRE fence (one L2 / vector-cache invalidate per column block) ahead of the
+            // slab loads, which are agent-scope atomics the compiler may not hoist above it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 #pragma unroll
             for (int i = 0; i < MBMAX; ++i) {
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(256, 1) void linear_stream_dgrad_kernel(
             __syncthreads();
             const unsigned nsp = gridDim.y;
             if (tk[0] != nsp - 1) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // (see lrp_linear_stream_fwd_tk's last arriver above)
             if (threadIdx.x == 0) __hip_atomic_store(tickets + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals of this launch are in: re-arm
 #pragma unroll
             for (int i = 0; i < MBMAX; ++i) {

@@ -63,20 +63,33 @@ def broadcast_weights(tensors, src=0):
 _CK_MOD = (1 << 61) - 1
 
 
-def checksum(t, chunk=1 << 26):
-    """exact, POSITION-SENSITIVE integer checksum of a tensor's BYTES: sum over its 16-bit words w_i (taken as unsigned) of w_i * (1 + i mod 65521)
-    in int64, chunk by chunk (no 4x-sized temporary for a 16-GB weight buffer), modulo 2^61 - 1 -> non-negative python int.  A plain word sum
-    (round 4) is blind to words or whole chunks delivered in the wrong order and to offsetting errors; the index weight is not.  Tensors of an
-    odd number of bytes get a zero byte appended.  Independent of device and dtype."""
+_CK_ROW = 65521
+
+
+def checksum(t, rows_per_pass=256):
+    """exact, POSITION-SENSITIVE integer checksum of a tensor's BYTES.  The 16-bit words (taken as unsigned) are laid out in rows of 65521; word j
+    of a row is weighted by (1 + j) and row r's sum by (1 + r): no two positions of the buffer carry the same pair of weights, so neither two
+    words a multiple of 65521 apart nor two whole blocks can be swapped unnoticed (the round-5 weight (1 + i mod 65521) alone repeated).
+    Row sums are formed on the device in int64 (< 2^16 * 2^16 * 2^16), `rows_per_pass` rows = 16.8 M words at a time (temporaries: 2 x 134 MB of
+    int64, not 4 x a 16-GB weight buffer; one host sync per pass), and combined in Python integers modulo 2^61 - 1 -> non-negative int.  Tensors
+    whose storage offset or byte count is odd are copied / zero-extended first.  Independent of device and dtype."""
     b = t.detach().contiguous().view(-1).view(torch.uint8)
     if b.numel() % 2:
         b = torch.cat([b, b.new_zeros(1)])
+    if b.data_ptr() % 2:                                       # (view(int16) needs 2-byte alignment: a uint8 slice may start on an odd byte)
+        b = b.clone()
     v = b.view(torch.int16)
-    tot = 0
-    for i in range(0, v.numel(), chunk):
-        w = v[i: i + chunk].to(torch.int64) & 0xFFFF
-        idx = (torch.arange(i, i + w.numel(), device=w.device, dtype=torch.int64) % 65521) + 1
-        tot = (tot + int((w * idx).sum())) % _CK_MOD           # < 2^16 * 2^16 * 2^26 = 2^58 per chunk: no int64 overflow
+    per = rows_per_pass * _CK_ROW
+    wgt = torch.arange(1, _CK_ROW + 1, device=v.device, dtype=torch.int64)
+    tot, row0 = 0, 0
+    for i in range(0, v.numel(), per):
+        w = v[i: i + per].to(torch.int64).bitwise_and_(0xFFFF)
+        if w.numel() % _CK_ROW:
+            w = torch.cat([w, w.new_zeros(_CK_ROW - w.numel() % _CK_ROW)])
+        sums = w.view(-1, _CK_ROW).mul_(wgt).sum(1).tolist()
+        for r, s_ in enumerate(sums):
+            tot = (tot + s_ * (row0 + r + 1)) % _CK_MOD
+        row0 += len(sums)
     return tot
 
 

@@ -175,8 +175,11 @@ FUSE_MLP = True           # module attribute (no environment knob): False = thre
 def _fused_mlp_weights(mlp):
     """-> (Wgu interleaved [2 I, H], Wd [H, I]) of an ADOPTED bf16 gated MLP, built once and kept on the module (rebuilt when a weight is replaced
     or written): the fused-epilogue GEMMs want gate and up as one operand with its rows in blocks of [32 gate | 32 up] (ops.interleave_gate_up),
-    and the long-K down weight with a row pitch that is no multiple of 4 KiB (engine.pitch_pad).  Costs a second copy of the MLP weights
-    (Llama-3-8B: 11 GB); None where the fused kernels do not apply (fp32, biases, I % 32, trainable or foreign modules)."""
+    and the long-K down weight with a row pitch that is no multiple of 4 KiB (engine.pitch_pad).  Memory: the interleaved gate/up
+    operand is a second copy of those two weights (Llama-3-8B: 7.5 GB; their row order cannot be expressed as a view); the pitch-padded down
+    weight REPLACES the module's own storage (down_proj.weight.data becomes the padded view: no second copy).  The copy is only made while it
+    leaves at least half of the device's currently free memory free -- a model that just fits keeps running, on the three-GEMM path --, and
+    release_fused(model) drops it.  None where the fused kernels do not apply (fp32, biases, I % 32, trainable or foreign modules)."""
     from .. import ops
     from ..engine import pitch_pad, weight_pitch_pad
     g, u, dn = mlp.gate_proj, mlp.up_proj, mlp.down_proj
@@ -190,18 +193,38 @@ def _fused_mlp_weights(mlp):
     hit = mlp.__dict__.get("_lrp_fused_mlp")
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
+    if hit is None and mlp.__dict__.get("_lrp_fused_mlp_refused"):
+        return None
     with torch.no_grad():
         wpad = weight_pitch_pad(wg.shape[1], wg.element_size(), 2 * wg.shape[0])      # NN (dgrad) reads stride over the rows: pitch off the 4-KiB grid
+        pad = pitch_pad(wd.shape[1], wd.element_size())
+        need = 2 * wg.shape[0] * (wg.shape[1] + wpad) * wg.element_size() + (wd.shape[0] * (wd.shape[1] + pad) * wd.element_size() if pad else 0)
+        if hit is None and need > torch.cuda.mem_get_info(wg.device)[0] // 2:
+            mlp.__dict__["_lrp_fused_mlp_refused"] = True                              # (decided once per module: no per-call memory query)
+            return None
         Wgu = ops.interleave_gate_up(wg.detach(), wu.detach(),
                                      out=torch.empty(2 * wg.shape[0], wg.shape[1] + wpad, device=wg.device, dtype=wg.dtype)[:, : wg.shape[1]])
-        pad = pitch_pad(wd.shape[1], wd.element_size())
         Wd = wd.detach()
-        if pad:
+        if pad and wd.stride(0) != wd.shape[1] + pad:
             buf = torch.empty(wd.shape[0], wd.shape[1] + pad, device=wd.device, dtype=wd.dtype)
             Wd = buf[:, : wd.shape[1]]
             Wd.copy_(wd)
+            dn.weight.data = Wd                       # the module keeps ONE down weight: the padded one (a strided view; F.linear and state_dict take it)
+            key = tuple((t.data_ptr(), t._version) for t in (wg, wu, dn.weight))
     mlp.__dict__["_lrp_fused_mlp"] = (key, Wgu, Wd)
     return Wgu, Wd
+
+
+def release_fused(model):
+    """drop what the drop-in path cached on the modules of `model` (the interleaved gate/up operands of _fused_mlp_weights; down_proj weights go
+    back to contiguous storage) -- the reference has no un-patch; this only returns the extra memory"""
+    for m in model.modules():
+        d = m.__dict__
+        if d.pop("_lrp_fused_mlp", None) is not None:
+            dn = getattr(m, "down_proj", None)
+            if dn is not None and not dn.weight.is_contiguous():
+                dn.weight.data = dn.weight.data.contiguous()
+        d.pop("_lrp_fused_mlp_refused", None)
 
 
 def gated_mlp_forward(self, x):
@@ -254,7 +277,8 @@ def _make_rotary(original):
 
 
 def patch_rotary(module):
-    """replace the modeling module's apply_rotary_pos_emb (a module-level function its attention forwards look up at call time)"""
+    """replace the modeling module's apply_rotary_pos_emb (a module-level function its attention forwards look up at call time); the original
+    stays reachable as .__wrapped__ and unpatch_rotary(module) puts it back"""
     orig = getattr(module, "apply_rotary_pos_emb", None)
     if orig is None:
         return False
@@ -262,6 +286,14 @@ def patch_rotary(module):
         return False
     module.apply_rotary_pos_emb = _make_rotary(orig)
     return True
+
+
+def unpatch_rotary(module):
+    cur = getattr(module, "apply_rotary_pos_emb", None)
+    if cur is not None and getattr(cur, "__module__", None) == __name__ and hasattr(cur, "__wrapped__"):
+        module.apply_rotary_pos_emb = cur.__wrapped__
+        return True
+    return False
 
 
 def mlp_forward(self, x):

@@ -126,5 +126,16 @@ def test_checksum_is_position_sensitive():
     b[[3, 4]] = b[[4, 3]]
     assert D.checksum(a) != D.checksum(b)                                   # two words swapped: same multiset of words
     assert D.checksum_list([a, b]) != D.checksum_list([b, a])               # the right bytes in the wrong tensor of the list
+    # long-range permutations: two words exactly 65521 apart, two whole chunks swapped, an odd storage offset
+    c = torch.arange(200000, dtype=torch.int32).to(torch.int16)
+    d = c.clone()
+    d[[7, 7 + 65521]] = d[[7 + 65521, 7]]
+    assert D.checksum(c) != D.checksum(d) and D.checksum(c, rows_per_pass=1) == D.checksum(c)
+    e = torch.arange(65521 * 6, dtype=torch.int32).to(torch.int16).view(6, 65521)
+    f = e.clone()
+    f[[1, 5]] = f[[5, 1]]
+    assert D.checksum(e) != D.checksum(f) and D.checksum(e, rows_per_pass=2) != D.checksum(f, rows_per_pass=2)
+    odd = torch.arange(64, dtype=torch.uint8)[1:33]
+    assert D.checksum(odd) == D.checksum(odd.clone())
     assert D.check_replicas([]) == [0]
     assert D.checksum(torch.tensor([1, 2, 3], dtype=torch.uint8)) == D.checksum(torch.tensor([1, 2, 3, 0], dtype=torch.uint8))

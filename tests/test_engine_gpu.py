@@ -290,9 +290,11 @@ def test_full_width_properties_bf16(eng_mod):
 
 
 @pytest.mark.parametrize("mode", ["explicit", "efficient"])
-def test_fused_gated_epilogues_equal_unfused_at_engine_level(eng_mod, mode):
-    """full layer width, bf16, both rule placements: the explanation with the gated-MLP rules inside the GEMM epilogues (lrp_gemm_gated_fwd /
-    _bwd, what the product runs) equals the one with GEMM + element-wise rule kernels bit for bit, and so does the padded-pitch layout"""
+def test_fused_gated_epilogues_vs_unfused_at_engine_level(eng_mod, mode):
+    """full layer width, bf16, both rule placements: the explanation with the gated-MLP rules inside the GEMM epilogues (round 6: the forward
+    stashes the backward's coefficients -- lrp_gemm_gated_fwd_coef / _bwd_coef, what the product runs) against the one with GEMM + element-wise
+    rule kernels on the stored gate/up output.  The two differ by bf16 rounding only (the fused form rounds the coefficient once where the pair
+    rounds g, u and act(g)); both are held against the fp32 engine on the same weights, and the fused form may not be the worse one."""
     import lxt_amd.ops as O
     cfg = dict(hidden=4096, inter=14336, n_layers=2, n_heads=32, n_kv=8, head_dim=128, vocab=2048, rope_theta=5e5, rms_eps=1e-5)
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -303,19 +305,25 @@ def test_fused_gated_epilogues_equal_unfused_at_engine_level(eng_mod, mode):
                           wu=rn(I, H), wd=rn(H, I)) for _ in range(2)])
     eng = eng_mod.LlamaLRP(cfg, W, dtype=torch.bfloat16, mode=mode, max_seq=1024, sparse_top=False)
     ids = torch.randint(0, 2048, (4, 1024), generator=torch.Generator().manual_seed(2))       # M = 4096 rows: the 256 x 256 ping-pong kernel
-    assert O.GATED_FUSION and O.TAIL_SPLIT
-    # the comparison is about the EPILOGUES: both runs with the plain one-launch GEMMs (at M = 4096 the un-fused down dgrad, 16 x 56 tiles =
-    # 3.5 rounds, would otherwise take the tail split -- another, equally valid, summation order for its last eight tile columns)
+    assert O.GATED_FUSION and eng._gated_coef(4096)
     try:
-        O.TAIL_SPLIT = False
         fused = eng.explain(ids, layer_relevance=True)
         O.GATED_FUSION = False
+        assert not eng._gated_coef(4096)
         plain = eng.explain(ids, layer_relevance=True)
+        plain = {k: v.clone() for k, v in plain.items()}
     finally:
         O.GATED_FUSION = True
-        O.TAIL_SPLIT = True
-    assert torch.isfinite(fused["R_tok"]).all() and float(fused["R_tok"].abs().max()) > 0
-    assert torch.equal(fused["R_tok"], plain["R_tok"]) and torch.equal(fused["layer_R"], plain["layer_R"]) and torch.equal(fused["logits"], plain["logits"])
+    eng.release()
+    ref = eng_mod.LlamaLRP(cfg, W, dtype=torch.float32, mode=mode, max_seq=1024, sparse_top=False).explain(ids, target=fused["idx"], layer_relevance=True)
+    assert torch.isfinite(fused["R_tok"]).all() and float(fused["R_tok"].abs().max()) > 0 and torch.equal(fused["idx"], plain["idx"])
+    e_f, e_p, e_fp = nmax(fused["R_tok"], ref["R_tok"]), nmax(plain["R_tok"], ref["R_tok"]), nmax(fused["R_tok"], plain["R_tok"])
+    print(f"[gated rules fused (coefficient stash) vs pair, {mode}] vs fp32 engine: fused {e_f:.2e} pair {e_p:.2e}; fused vs pair {e_fp:.2e}")
+    assert nmax(fused["logits"], plain["logits"]) < 2e-2
+    if mode == "efficient":
+        assert e_f < max(1.25 * e_p, 5e-3) and e_fp < 1e-2 and nmax(fused["layer_R"], plain["layer_R"]) < 1e-2
+    else:          # explicit placement in bf16 is pole noise (test_llama_bf16_explicit_seed_set): same order, no more
+        assert e_f < max(3 * e_p, 5e-2)
 
 
 @pytest.mark.parametrize("mode", ["explicit", "efficient"])

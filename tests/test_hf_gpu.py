@@ -267,6 +267,10 @@ def test_dropin_fused_mlp_and_hip_rope_match_the_unfused_dropin():
             idx = last.argmax(-1)
             last[torch.arange(2), idx].sum().backward()
             fused_used = any("_lrp_fused_mlp" in m.__dict__ for m in model.modules())
+            if fused_used:      # the extra memory can be handed back: the interleaved copies go, down weights return to contiguous storage
+                P.release_fused(model)
+                assert not any("_lrp_fused_mlp" in m.__dict__ for m in model.modules())
+                assert all(m.down_proj.weight.is_contiguous() for m in model.modules() if hasattr(m, "down_proj"))
             return idx.cpu(), (e * e.grad).float().sum(-1).double().cpu(), fused_used
         finally:
             P.FUSE_MLP, modeling_llama.apply_rotary_pos_emb = True, hip_rope

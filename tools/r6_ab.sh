@@ -12,7 +12,7 @@ for tree in "$@"; do
   if [ "$tree" = . ]; then root=$GRAFT_REPO_ROOT; tag=now; else root=$GRAFT_REPO_ROOT/tools/ab/$tree; tag=$tree; fi
   rm -rf /tmp/kt_$tag
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/kt_$tag -o kt -- python $root/bench.py $FLAGS --steps 4 --warmup 1 > $O/bench_${tag}_$rep.json 2> $O/bench_${tag}_$rep.log)
-  python tools/rocpd_stats.py $(find /tmp/kt_$tag -name "*.db" | head -1) > $O/stats_${tag}_$rep.txt 2>&1
+  python tools/rocpd_stats.py --by-grid $(find /tmp/kt_$tag -name "*.db" | head -1) > $O/stats_${tag}_$rep.txt 2>&1
   echo "=== $tag rep $rep: $(python -c "import json,sys; d=json.loads(open('$O/bench_${tag}_$rep.json').read().strip().splitlines()[-1]); print(d['value'], 'expl/s', d['ms_per_step'], 'ms/step')" 2>&1)"
   grep -E "gemm_pp_kernel|attn32|gqa_reduce|rmsnorm|rope|prep" $O/stats_${tag}_$rep.txt | head -14 | cut -c1-60,88-150
   rm -rf /tmp/kt_$tag
