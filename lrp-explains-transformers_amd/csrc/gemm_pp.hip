@@ -69,6 +69,18 @@ constexpr int PP_OPND = 256 * 128;                // one operand of one buffer (
 
 typedef __attribute__((address_space(3))) void* pp_lds_ptr_t;
 
+// Counted waits on the vector-memory counter as the BUILTIN, not as inline asm: the compiler's own wait insertion (SIInsertWaitcnts) reads an
+// s_waitcnt it finds in the instruction stream and updates its picture of what is still in flight; an inline-asm wait is opaque to it, so
+// every load the epilogues issue (row scales, residual / coefficient tiles) stayed "pending" in its model across the persistent tile loop and
+// it protected the K loop's fragment registers -- which those loads had re-used -- with a vmcnt(0) at the TOP OF THE K LOOP, draining the
+// staging pipeline every second K tile (round 6: found in the EPI 4 instantiation, -4 % on the K = 28672 gate/up dgrad; round 5's EPI 2 had the
+// same).  gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4, expcnt imm[6:4] = 7 and lgkmcnt imm[11:8] = 15 (no wait on those).
+#define PP_VMWAIT(N)                                                                              \
+    do {                                                                                          \
+        asm volatile("" ::: "memory");                                                            \
+        __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | 0xF00 | (((N) >> 4) << 14));               \
+        asm volatile("" ::: "memory");                                                            \
+    } while (0)
 #define PP_DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define PP_DSTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // ---- prologue of a tile: V0(0) V1(0) V2(0) V0(1) V1(1); V0(0), V1(0) landed = all but the newest 8 pieces
     auto issue_prologue = [&]() { stage_A(0, 0, 0); stage_B(0, 0); stage_A(1, 0, 0); stage_A(0, 1, 1); stage_B(1, 1); };
     issue_prologue();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    PP_VMWAIT(8);
     // persistent walk: one iteration per tile (PP_PERSIST 0, split-K slabs and the timeline build: exactly one)
     for (;;) {
     const int em0 = m0, en0 = n0;                                     // this tile = the epilogue's tile (m0 / n0 move on to the next one after the K loop)
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const int gm = mrow + (b >> 2) * 64 + (b & 3) * 16;
-            rsv[b] = gm < M ? ep.rs[gm] : 0.f;
+            rsv[b] = ep.rs[gm < M ? gm : M - 1];             // (rows past M are never stored; an unconditional load keeps the control flow flat)
         }
     };
     if constexpr (RS && EPI != 4) load_rs();
@@ -287,8 +299,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     {                                                                                             \
         /* ---- phase (t, 0): L */                                                                \
         PP_READ_B(BUF) PP_READ_A(BUF, 0)                                                          \
-        if (t + 1 < nkt) { stage_A(1, t + 1, (BUF) ^ 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        if (t + 1 < nkt) { stage_A(1, t + 1, (BUF) ^ 1); PP_VMWAIT(8); }   \
+        else PP_VMWAIT(0);                                     \
         PP_WAIT_A(); PP_WAIT_B(); PP_FENCE();                                                     \
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- M */                                                                              \
@@ -296,8 +308,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- phase (t, 1): L */                                                                \
         PP_READ_A(BUF, 1)                                                                         \
-        if (t + 2 < nkt) { stage_A(0, t + 2, BUF); stage_B(t + 2, BUF); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   \
-        else if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
+        if (t + 2 < nkt) { stage_A(0, t + 2, BUF); stage_B(t + 2, BUF); PP_VMWAIT(8); }   \
+        else if (t + 1 < nkt) PP_VMWAIT(2);                    \
         PP_WAIT_A(); PP_FENCE();                                                                  \
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- M */                                                                              \
@@ -603,6 +615,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             }
         }
     }
+    // (a last "use" of the row scales at the very end of the tile: it keeps their registers out of the K loop's fragment set until the compiler's
+    // wait model has seen them consumed on every path -- without it the EPI 4 instantiation carried a vmcnt wait at the top of the K loop, see
+    // PP_VMWAIT)
+    if constexpr (RS) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) asm volatile("" :: "v"(rsv[b]));
+    }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
     if (!has_next) break;
     // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
@@ -610,10 +629,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // the fused gated backward's own gu loads were issued after the pieces and waited for by the compiler, only its last stores remain;
     // ragged tiles and fp32 output (scalar / conditional stores): drain.
     if (full && sizeof(TO) == 2) {
-        if constexpr (EPI == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if constexpr (EPI == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (EPI == 0) PP_VMWAIT(24);
+        else if constexpr (EPI == 1) PP_VMWAIT(32);
+        else PP_VMWAIT(8);
+    } else PP_VMWAIT(0);
     }
     // (every LDS-DMA load was waited for inside the last K tile; the C stores may still be in flight when the wave ends)
 #undef PP_KTILE
