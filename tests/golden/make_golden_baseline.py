@@ -130,5 +130,7 @@ if __name__ == "__main__":
             s4096()
         elif w == "bf16":
             s2048_bf16()
+        elif w.startswith("bf16:"):       # round 6: more id seeds on weight seed 20 -- the batched (B = 4) bf16 test of the fused flow
+            s2048_bf16(20, int(w.split(":")[1]))
         else:
             s2048(int(w), int(w) + 1)
