@@ -130,6 +130,14 @@ class Composite:
             if node.target in fn_map:
                 self.function_summary.setdefault(where, {})[node.target] = "replaced"
                 node.target = fn_map[node.target]
+                # torch.nn.functional wrappers reach the graph through __torch_function__ with their PRIVATE keywords spelled out
+                # (F.softmax: _stacklevel); the rule function is called with the keywords it declares
+                try:
+                    params = inspect.signature(node.target).parameters
+                    if not any(p_.kind == p_.VAR_KEYWORD for p_ in params.values()):
+                        node.kwargs = {k: v for k, v in node.kwargs.items() if k in params}
+                except (TypeError, ValueError):
+                    pass
                 return True
             self.function_summary.setdefault(where, {}).setdefault(node.target, "not replaced")
         elif node.op == "call_method":      # as the reference: methods (tensor.add, ...) are reported, never replaced
