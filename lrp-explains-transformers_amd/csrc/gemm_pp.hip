@@ -61,9 +61,6 @@
 #ifndef PP_PERSIST
 #define PP_PERSIST 1
 #endif
-#ifndef PP_COEF_PREFETCH
-#define PP_COEF_PREFETCH 1
-#endif
 
 namespace {
 
@@ -297,24 +294,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     acc[AH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks].v, fa[i][ks], acc[AH][i][j], 0, 0, 0);
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-    // EPI 2 (PP_COEF_PREFETCH): the tile's coefficient block (256 rows x 1 KiB) is TOUCHED during its own K loop -- four 4-byte LDS-DMA loads per
-    // wave and tile, one per cache line, into a dump area above the tiles -- so that the epilogue's 0.47 GB per round, which all 256 CUs request
-    // at the same moment, comes out of the Infinity Cache / L2 instead of HBM.  Issued BEHIND the phase's staging pieces (youngest in the
-    // counter: the counted waits only get one piece more conservative).
-    auto coef_touch = [&](int q) {
-        if constexpr (EPI == 2) {
-            const int id = q * 64 + lane;                                  // 256 lines per wave: rows 32 wave .. + 31, eight 128-byte lines each
-            int row = em0 + 32 * wave + (id >> 3);
-            row = row < M ? row : M - 1;
-            const char* gp = reinterpret_cast<const char*>(ep.gu) + ((int64_t)row * ep.ldgu + 2 * (int64_t)en0) * 2 + (id & 7) * 128;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (pp_lds_ptr_t)(smem + 4 * PP_OPND + wave * 256), 4, 0, 0);
-        }
-    };
-#if PP_COEF_PREFETCH
-#define PP_COEF_TOUCH(T) if constexpr (EPI == 2) { if (((T) & 7) == 2 && (T) < 32) coef_touch((T) >> 3); }
-#else
-#define PP_COEF_TOUCH(T)
-#endif
     // one K tile out of buffer BUF (compile-time); t is the running K-tile index.  The M phases are BARE MFMA streams.
 #define PP_KTILE(BUF)                                                                             \
     {                                                                                             \
@@ -329,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
         /* ---- phase (t, 1): L */                                                                \
         PP_READ_A(BUF, 1)                                                                         \
-        if (t + 2 < nkt) { stage_A(0, t + 2, BUF); stage_B(t + 2, BUF); PP_COEF_TOUCH(t); PP_VMWAIT(8); }   \
+        if (t + 2 < nkt) { stage_A(0, t + 2, BUF); stage_B(t + 2, BUF); PP_VMWAIT(8); }   \
         else if (t + 1 < nkt) PP_VMWAIT(2);                    \
         PP_WAIT_A(); PP_FENCE();                                                                  \
         __builtin_amdgcn_s_barrier(); PP_FENCE();                                                 \
@@ -657,7 +636,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     }
     // (every LDS-DMA load was waited for inside the last K tile; the C stores may still be in flight when the wave ends)
 #undef PP_KTILE
-#undef PP_COEF_TOUCH
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_WAIT_A
@@ -678,7 +656,7 @@ int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, 
     }
 #endif
     dim3 grid(gx, splits), block(512);
-    const size_t lds = 4 * (size_t)PP_OPND + (EPI == 2 && PP_COEF_PREFETCH ? 8 * 256 : 0);
+    const size_t lds = 4 * (size_t)PP_OPND;
     auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
