@@ -173,6 +173,56 @@ def test_engine_bf16_full_width_vs_oracle(case):
     torch.cuda.empty_cache()
 
 
+BF16_ID_SEEDS = (21, 121, 122, 123)        # weight seed 20: tests/golden/make_golden_baseline.py bf16 / bf16:<id seed>
+
+
+def test_engine_bf16_full_width_batched_fused_vs_oracle(case):
+    """VERDICT r5 "do this" 4: the kernels the HEADLINE runs, anchored on the oracle.  B = 4 prompts x S = 2048 = M 8192 rows in ONE call -- the
+    row count at which K1n (RMSNorm / residual sums in the GEMM epilogues), the folded attn_bwd_prep, RoPE's backward in the dQ store and the
+    gated-MLP coefficient stash are all active (sparse_top off: both layers take the dense, fused path) -- against the cached fp64 oracle on the
+    bf16-rounded weights, per prompt (four id seeds on weight seed 20).  Beside it the SAME engine with every fusion off (stand-alone norm /
+    prep / rope / gated kernels).  Bars: per prompt nmax <= 1e-2 (the oracle's own bf16-storage floor on these instances is 3.6e-3 ... 7.4e-3),
+    and the fused flow may not be the less accurate one: geometric mean over the prompts <= 1.5 x the stand-alone flow's
+    (tools/k1n_error_parts.py, profiles/r06_fused_flow_error_parts.txt: over 12 prompts the fused flow is the MOST accurate configuration --
+    it rounds less; the 2 x of the round-5 verdict was one prompt's draw)."""
+    import lxt_amd.engine as E
+    import lxt_amd.ops as ops
+    from tests.util import GOLDEN
+    refs, idx, ids = [], [], []
+    for s_ in BF16_ID_SEEDS:
+        path = os.path.join(GOLDEN, f"baseline_s2048_seed20_{s_}_bf16.npz")
+        if not (case["cached"] and os.path.exists(path)):
+            pytest.skip("cached bf16 oracle fixtures not usable on this host (different CPU RNG stream)")
+        z = np.load(path)
+        i_ = torch.randint(0, CFG["vocab"], (S,), generator=torch.Generator().manual_seed(s_))
+        assert np.array_equal(z["ids"], i_.numpy())
+        refs.append(torch.from_numpy(z["efficient_R_tok"])); idx.append(int(z["idx"])); ids.append(i_)
+    ids, tgt = torch.stack(ids), torch.tensor(idx)
+    eng = E.LlamaLRP(CFG, case["W"], dtype=torch.bfloat16, mode="efficient", max_seq=S, sparse_top=False)
+    M = ids.numel()
+    assert eng._norm_fused(M) and eng._gated_coef(M) and ops.PREP_FUSION and ops.ROPE_BWD_FUSION
+    fused = eng.explain(ids, target=tgt)["R_tok"].double().cpu()
+    keep = (ops.NORM_FUSION, ops.PREP_FUSION, ops.ROPE_BWD_FUSION, ops.GATED_FUSION)
+    try:
+        ops.NORM_FUSION, ops.PREP_FUSION, ops.ROPE_BWD_FUSION, ops.GATED_FUSION = False, False, False, False
+        eng._nf_cache.clear()
+        assert not eng._norm_fused(M) and not eng._gated_coef(M)
+        plain = eng.explain(ids, target=tgt)["R_tok"].double().cpu()
+    finally:
+        ops.NORM_FUSION, ops.PREP_FUSION, ops.ROPE_BWD_FUSION, ops.GATED_FUSION = keep
+        eng._nf_cache.clear()
+    e_f = [nmax(fused[b], refs[b]) for b in range(len(refs))]
+    e_p = [nmax(plain[b], refs[b]) for b in range(len(refs))]
+    gm = lambda v: float(np.exp(np.mean(np.log(v))))      # noqa: E731
+    cos = [float((fused[b] * refs[b]).sum() / (fused[b].norm() * refs[b].norm())) for b in range(len(refs))]
+    print(f"[H4096/S2048 bf16, B = 4 in one call, fused flow] per prompt vs fp64 oracle {[f'{e:.2e}' for e in e_f]} (gmean {gm(e_f):.2e}); "
+          f"all fusions off {[f'{e:.2e}' for e in e_p]} (gmean {gm(e_p):.2e}); cosine min {min(cos):.6f}")
+    assert torch.isfinite(fused).all() and max(e_f) <= 1e-2 and min(cos) > 0.9995
+    assert gm(e_f) <= 1.5 * gm(e_p)
+    del eng
+    torch.cuda.empty_cache()
+
+
 def test_dropin_fp32_full_width_vs_oracle(case, tmp_path):
     """HF LlamaForCausalLM (fp32, eager and sdpa) under lxt_amd.efficient.monkey_patch on the same weights, in a fresh
     process (the patches are class-level), against the same fp64 oracle: the user protocol of
@@ -264,7 +314,7 @@ def test_engine_s4096_config5_efficient_vs_oracle():
         cons = abs(float(both["R_tok"][b].double().sum()) - float(both["layer_R"][0, b])) / abs(float(both["layer_R"][0, b]))
         e32 = nmax(both["R_tok"][b], R32[b])
         print(f"[H4096/S4096 bf16 efficient, prompt {b}] batched vs single {e_b:.2e} | sum_t R_t vs latent relevance at the embedding {cons:.2e} | vs fp32 {e32:.2e}")
-        assert e_b < 2e-2 and cons < 2e-2 and e32 < 5e-2 and torch.isfinite(both["R_tok"]).all()
+        assert e_b < 2e-2 and cons < 2e-2 and e32 < 2e-2 and torch.isfinite(both["R_tok"]).all()
 
 
 # ------------------------------------------------------------------------------ (d) attention kernels at S = 2048 / 4096
