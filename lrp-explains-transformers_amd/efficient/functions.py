@@ -117,6 +117,72 @@ class FusedGatedMLPFn(Function):
         return gx.view(*shp[:-1], Wgu.shape[1]), None, None, None
 
 
+class DecoderLayerFn(Function):
+    """ONE Llama-type decoder layer (pre-norm attention block + pre-norm gated MLP, both with residuals) as the launch sequence of
+    lxt_amd.engine.LlamaLRP's dense layer -- for an adopted bf16 HF model at M = B S rows: the two RMSNorms and both residual sums inside the GEMM
+    epilogues (K1n: norm weights folded into the fused [q;k;v] and gate/up weights by patches._fused_layer_weights), one fused QKV GEMM, the
+    gated rule as a coefficient stash, flash attention; backward: 7 GEMM launches, the dQ kernel forms D and applies RoPE's backward in its store,
+    dK's group sum carries RoPE's backward too -- no attn_bwd_prep / rope_bwd / norm passes.  Rules as lxt.efficient places them (ref
+    lxt/efficient/patches.py:111-123 rms_norm_forward, :145-157 gated_mlp_forward, :193-203 wrap_attention_forward; HF modeling_llama's
+    LlamaDecoderLayer.forward for the wiring).  h [B, S, H]; cos / sin fp32 [S, d] (one table for every prompt: plain causal, un-padded batches);
+    rstd1 fp32 [B S]: 1 / rms of h's rows (from the previous layer's epilogue, or computed by the caller).  Returns (h_out, rstd of h_out's rows)."""
+
+    @staticmethod
+    def forward(ctx, h, rstd1, Wqkv, Wo, Wgu, Wd, cos, sin, meta):
+        from ..engine import pitch_pad
+        nq, nk, d, eps, act, scale = meta
+        B, S, H = h.shape
+        M, I = B * S, Wd.shape[1]
+        nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
+        dev, dt, es = h.device, h.dtype, h.element_size()
+        new = lambda r, c, pad=0: torch.empty(r, c + pad, device=dev, dtype=dt)[:, :c]          # noqa: E731
+        h2 = h.reshape(M, H)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        qkv = ops.gemm_nt_rs(h2, Wqkv, rstd1, new(M, nqkv))
+        qkr = ops.rope_fwd(qkv, new(M, nqk), cos, sin, S, nq + nk, d)
+        q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
+        o, lse = new(M, nq * d), torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+        ops.attn_fwd(q, k, v, None, o, lse, B, S, nq, nk, d, scale, True, 0)
+        ssq = torch.empty(H // 64, M, device=dev, dtype=torch.float32)
+        h1 = ops.gemm_res_ssq(o, Wo, h2, new(M, H), ssq)
+        rstd2 = ops.rms_rstd(ssq, M, H, eps, torch.empty(M, device=dev, dtype=torch.float32))
+        coef, m = ops.gemm_gated_fwd_coef(h1, Wgu, new(M, 2 * I), new(M, I, pitch_pad(I, es)), 1e-10, 0.0, act, rs=rstd2)
+        out = ops.gemm_res_ssq(m, Wd, h1, new(M, H), ssq)
+        rstd_out = ops.rms_rstd(ssq, M, H, eps, torch.empty(M, device=dev, dtype=torch.float32))
+        ctx.save_for_backward(rstd1, rstd2, qkv, qkr, o, lse, coef, Wqkv, Wo, Wgu, Wd, cos, sin)
+        ctx.meta = (B, S, H, I, nq, nk, d, scale)
+        ctx.mark_non_differentiable(rstd_out)
+        return out.view(B, S, H), rstd_out
+
+    @staticmethod
+    def backward(ctx, gy, _g_rstd):
+        from ..engine import pitch_pad
+        rstd1, rstd2, qkv, qkr, o, lse, coef, Wqkv, Wo, Wgu, Wd, cos, sin = ctx.saved_tensors
+        B, S, H, I, nq, nk, d, scale = ctx.meta
+        M, rep = B * S, nq // nk
+        nqk, nqkv = (nq + nk) * d, (nq + 2 * nk) * d
+        dev, dt, es = gy.device, gy.dtype, gy.element_size()
+        new = lambda r, c, pad=0: torch.empty(r, c + pad, device=dev, dtype=dt)[:, :c]          # noqa: E731
+        G = gy.reshape(M, H)
+        if not G.is_contiguous():
+            G = G.contiguous()
+        Agu = ops.gemm_gated_bwd_coef(G, Wd, coef, new(M, 2 * I, pitch_pad(2 * I, es)))
+        Gs1 = ops.gemm_nn_rs_res(Agu, Wgu, rstd2, G, new(M, H))
+        half = ops.const_rows(M, 0.5, dev)
+        Gho = ops.gemm_nn_rs(Gs1, Wo, half, new(M, nq * d))                                       # 1/2 (uniform rule on P.V): exact row scale
+        q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
+        D = torch.empty(B, nq, S, device=dev, dtype=torch.float32)
+        Aqkv = new(M, nqkv, 64 if (nqkv * es) % 4096 == 0 else 0)
+        ops.attn_bwd_dq_d(q, k, v, Gho, o, lse, D, Aqkv[:, : nq * d], B, S, nq, nk, d, scale, rope=(cos, sin))
+        dk_h, dv_h = new(M, nq * d), new(M, nq * d)
+        ops.attn_bwd_dkv(q, k, v, None, Gho, None, lse, D, dk_h, dv_h, B, S, nq, nk, d, scale, 0.0, 0.0)
+        ops.gqa_reduce_rope(dk_h, Aqkv[:, nq * d: nqk], M, S, nk, rep, d, cos, sin)
+        ops.gqa_reduce(dv_h, Aqkv[:, nqk:], M, nk, rep, d)
+        Gh = ops.gemm_nn_rs_res(Aqkv, Wqkv, rstd1, Gs1, new(M, H))
+        return Gh.view(B, S, H), None, None, None, None, None, None, None, None
+
+
 class RopeFn(Function):
     """HF's apply_rotary_pos_emb on ONE tensor x [B, H, S, d] (a transposed view of the token-major projection output) as one launch of
     lrp_rope_fwd, its ordinary gradient as one launch of lrp_rope_bwd (lxt.efficient leaves RoPE un-patched: constant cos / sin, plain gradient;

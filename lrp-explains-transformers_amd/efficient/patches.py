@@ -10,7 +10,7 @@ from warnings import warn
 import torch
 
 from .rules import stop_gradient, divide_gradient, identity_rule_implicit, _act_name
-from .functions import RMSNormFn, LayerNormFn, GatedActFn, LinearFn, AttentionFn, FusedGatedMLPFn, RopeFn
+from .functions import RMSNormFn, LayerNormFn, GatedActFn, LinearFn, AttentionFn, FusedGatedMLPFn, RopeFn, DecoderLayerFn
 
 
 def check_already_patched(target_fn, new_fn):
@@ -216,11 +216,13 @@ def _fused_mlp_weights(mlp):
 
 
 def release_fused(model):
-    """drop what the drop-in path cached on the modules of `model` (the interleaved gate/up operands of _fused_mlp_weights; down_proj weights go
-    back to contiguous storage) -- the reference has no un-patch; this only returns the extra memory"""
+    """drop what the drop-in path cached on the modules of `model` (the folded / interleaved operands of _fused_layer_weights and
+    _fused_mlp_weights; down_proj weights go back to contiguous storage) -- the reference has no un-patch; this only returns the extra memory"""
     for m in model.modules():
         d = m.__dict__
-        if d.pop("_lrp_fused_mlp", None) is not None:
+        d.pop("_lrp_fused_layer_refused", None)
+        if (d.pop("_lrp_fused_mlp", None) is not None) | (d.pop("_lrp_fused_layer", None) is not None):
+            m = getattr(m, "mlp", m)
             dn = getattr(m, "down_proj", None)
             if dn is not None and not dn.weight.is_contiguous():
                 dn.weight.data = dn.weight.data.contiguous()
@@ -240,6 +242,141 @@ def gated_mlp_forward(self, x):
         if fused is not None:
             return FusedGatedMLPFn.apply(x, fused[0], fused[1], act)
     return self.down_proj(GatedActFn.apply(self.gate_proj(x), self.up_proj(x), act))
+
+
+FUSE_LAYER = True         # module attribute (no environment knob): False = per-module patches only (A/B measurements, equality tests)
+
+
+def _fold_rows(dst, srcs, ln):
+    """dst [sum rows, cols] <- concat(srcs) * ln[None, :] (fp32 product, ONE rounding), block by block"""
+    lnf = ln.detach().float()
+    r0 = 0
+    for w in srcs:
+        for b0 in range(0, w.shape[0], 4096):
+            blk = w[b0: b0 + 4096].detach()
+            dst[r0 + b0: r0 + b0 + blk.shape[0]].copy_((blk.float() * lnf).to(dst.dtype))
+        r0 += w.shape[0]
+    return dst
+
+
+def _fused_layer_weights(layer):
+    """-> dict(Wqkv, Wo, Wgu, Wd, meta) of an ADOPTED bf16 Llama-type decoder layer for DecoderLayerFn, built once and kept on the module: the
+    fused [q; k; v] weight and the interleaved gate/up weight with the layer's two RMSNorm weights FOLDED into their columns (W' = W diag(w):
+    the same network and the same relevance under every rule -- lxt_amd.engine.LlamaLRP does the same; the norm is then a row scale that runs in
+    the GEMM epilogues), stored-weight row pitches off the 4-KiB grid.  Memory: a second copy of q/k/v and gate/up (Llama-3-8B: 10.7 GB; the
+    padded down weight replaces the module's storage, o is used as stored), made only while it leaves half of the free device memory free;
+    release_fused(model) drops it.  None where the fused layer does not apply."""
+    from .. import ops
+    from ..engine import pitch_pad, weight_pitch_pad
+    hit = layer.__dict__.get("_lrp_fused_layer")
+    att, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+    lins = [getattr(att, n, None) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + [getattr(mlp, n, None) for n in ("gate_proj", "up_proj", "down_proj")]
+    n1, n2 = getattr(layer, "input_layernorm", None), getattr(layer, "post_attention_layernorm", None)
+    if not (FUSE_LAYER and all(isinstance(t, torch.nn.Linear) and _owned(t) and t.bias is None and not t.weight.requires_grad for t in lins)
+            and n1 is not None and n2 is not None and type(n1) is type(n2) and type(n1).__name__.endswith("RMSNorm")
+            and not any(hasattr(att, a) for a in ("q_norm", "k_norm"))):
+        return None
+    ws = [t.weight for t in lins] + [n1.weight, n2.weight]
+    key = tuple((t.data_ptr(), t._version) for t in ws)
+    if hit is not None and hit["key"] == key:
+        return hit
+    if hit is None and layer.__dict__.get("_lrp_fused_layer_refused"):
+        return None
+    wq, wk, wv, wo, wg, wu, wd = (t.weight for t in lins)
+    cfg = att.config
+    nq, nk = cfg.num_attention_heads, cfg.num_key_value_heads
+    d = getattr(att, "head_dim", None) or cfg.hidden_size // nq
+    H, I = wq.shape[1], wg.shape[0]
+    act = _act_name(mlp.act_fn)
+    eps1 = getattr(n1, "variance_epsilon", getattr(n1, "eps", None))
+    eps2 = getattr(n2, "variance_epsilon", getattr(n2, "eps", None))
+    ok = (wq.is_cuda and all(t.dtype == torch.bfloat16 for t in ws) and act in ("silu", "gelu_tanh") and I % ops.GATED_IL == 0 and H % 256 == 0
+          and wq.shape == (nq * d, H) and wk.shape == wv.shape == (nk * d, H) and wo.shape == (H, nq * d) and wu.shape == wg.shape
+          and wd.shape == (H, I) and d in (64, 128) and nq % nk == 0 and eps1 is not None and eps1 == eps2
+          and float(getattr(att, "scaling", d ** -0.5)) > 0 and not getattr(att, "sliding_window", None)
+          and ops.attn_dq_d_ok(torch.bfloat16, d) and not ops.attn_needs_transposed(wq, d))
+    if not ok:
+        layer.__dict__["_lrp_fused_layer_refused"] = True
+        return None
+    es, nqkv = wq.element_size(), (nq + 2 * nk) * d
+    with torch.no_grad():
+        pq, pg, pd = weight_pitch_pad(H, es, nqkv), weight_pitch_pad(H, es, 2 * I), pitch_pad(I, es)
+        need = (nqkv * (H + pq) + 2 * I * (H + pg)) * es + (H * (I + pd) * es if (pd and wd.stride(0) != I + pd) else 0)
+        if need > torch.cuda.mem_get_info(wq.device)[0] // 2:
+            layer.__dict__["_lrp_fused_layer_refused"] = True                        # (decided once per layer)
+            return None
+        Wqkv = _fold_rows(torch.empty(nqkv, H + pq, device=wq.device, dtype=wq.dtype)[:, :H], (wq, wk, wv), n1.weight)
+        tmp = _fold_rows(torch.empty(2 * I, H, device=wq.device, dtype=wq.dtype), (wg, wu), n2.weight)
+        Wgu = ops.interleave_gate_up(tmp[:I], tmp[I:], out=torch.empty(2 * I, H + pg, device=wq.device, dtype=wq.dtype)[:, :H])
+        del tmp
+        Wd = wd.detach()
+        if pd and wd.stride(0) != I + pd:
+            Wd = torch.empty(H, I + pd, device=wd.device, dtype=wd.dtype)[:, :I]
+            Wd.copy_(wd)
+            lins[6].weight.data = Wd                      # ONE down weight: the padded one (see _fused_mlp_weights)
+        mlp.__dict__.pop("_lrp_fused_mlp", None)          # the MLP-level copy (if an earlier call made one) is superseded
+    key = tuple((t.data_ptr(), t._version) for t in [t_.weight for t_ in lins] + [n1.weight, n2.weight])
+    hit = dict(key=key, Wqkv=Wqkv, Wo=wo.detach(), Wgu=Wgu, Wd=Wd, meta=(nq, nk, d, float(eps1), act, float(getattr(att, "scaling", d ** -0.5))),
+               H=H, I=I, ok_rows={})
+    layer.__dict__["_lrp_fused_layer"] = hit
+    return hit
+
+
+_LAYER_TABLES = {}
+
+
+def _layer_rope_table(cos, sin, S, d):
+    """HF's cos / sin [1, S, d] (model dtype) -> fp32 [S, d] tables for the kernels that index them by position, cached by tensor identity"""
+    key = (cos.data_ptr(), sin.data_ptr(), tuple(cos.shape), cos.dtype, cos._version)
+    hit = _LAYER_TABLES.get(key)
+    if hit is None:
+        if len(_LAYER_TABLES) >= 2:
+            _LAYER_TABLES.pop(next(iter(_LAYER_TABLES)))
+        hit = _LAYER_TABLES[key] = (cos.detach()[0].float().contiguous(), sin.detach()[0].float().contiguous(), cos, sin)
+    return hit[0], hit[1]
+
+
+def decoder_layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                          position_embeddings=None, **kwargs):
+    """HF LlamaDecoderLayer.forward for an adopted bf16 model at M = B S rows: the whole layer as ONE autograd node on the fused launch sequence
+    of the engine (DecoderLayerFn).  Anything the fused layer does not cover -- fp32, biases, padded / packed batches, sliding windows, KV caches,
+    few rows, extra keyword arguments that change the computation -- runs HF's own forward over the per-module patches, as before."""
+    from .. import ops
+    h = hidden_states
+    fw = None
+    if (FUSE_LAYER and torch.is_tensor(h) and h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and past_key_values is None
+            and position_embeddings is not None and not kwargs.get("output_attentions")):
+        fw = _fused_layer_weights(self)
+    if fw is not None:
+        B, S, H = h.shape
+        cos, sin = position_embeddings
+        nq, nk, d, eps, act, scale = fw["meta"]
+        ok = fw["ok_rows"].get((B, S))
+        if ok is None:
+            M, I = B * S, fw["I"]
+            ok = fw["ok_rows"][(B, S)] = bool(
+                ops.gated_coef_ok(M, I, H, H, fw["Wgu"].stride(0), H, fw["Wd"].stride(0), act, h.dtype)
+                and all(ops.norm_fused_ok(*a, h.dtype) for a in (
+                    (M, H, nq * d, nq * d, fw["Wo"].stride(0), False), (M, H, I, fw["Wd"].stride(0), fw["Wd"].stride(0), False),
+                    (M, (nq + 2 * nk) * d, H, H, fw["Wqkv"].stride(0), False), (M, 2 * I, H, H, fw["Wgu"].stride(0), False),
+                    (M, H, (nq + 2 * nk) * d, (nq + 2 * nk) * d, fw["Wqkv"].stride(0), True), (M, H, 2 * I, 2 * I, fw["Wgu"].stride(0), True),
+                    (M, nq * d, H, H, fw["Wo"].stride(0), True))))
+        if ok and cos.dim() == 3 and cos.shape[0] == 1 and cos.shape[1] == S and cos.shape[2] == d and not cos.requires_grad:
+            causal, window, row_iv = _mask_plan(attention_mask, S, self.self_attn, 0)
+            if causal and not window and row_iv is None:
+                ct, st = _layer_rope_table(cos, sin, S, d)
+                rstd = getattr(h, "_lrp_rstd", None)              # (rstd, eps, tensor version when it was formed)
+                if rstd is None or rstd[1] != eps or rstd[0].shape[0] != B * S or rstd[2] != h._version:
+                    ones = ops.const_rows(H, 1.0, h.device).to(h.dtype)
+                    h2 = h.reshape(B * S, H)
+                    _, r = ops.add_rmsnorm_fwd(h2 if h2.is_contiguous() else h2.contiguous(), None, ones, eps)
+                else:
+                    r = rstd[0]
+                out, rstd_out = DecoderLayerFn.apply(h, r, fw["Wqkv"], fw["Wo"], fw["Wgu"], fw["Wd"], ct, st, fw["meta"])
+                out._lrp_rstd = (rstd_out, eps, out._version)     # the next layer's 1 / rms, left by this layer's down-projection epilogue
+                return out
+    return self.original_forward(hidden_states, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
+                                 use_cache=use_cache, position_embeddings=position_embeddings, **kwargs)
 
 
 _ROPE_TABLES = {}

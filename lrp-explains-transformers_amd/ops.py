@@ -545,6 +545,20 @@ def _timed(flops, tag, fn, name):
     check(rc, name)
 
 
+_CONST_ROWS = {}
+
+
+def const_rows(M, value, device):
+    """cached fp32 [M] vector of one value (row scales of the K1n entry points: 1/2 for the o-projection's dgrad)"""
+    key = (str(device), M, float(value))
+    t = _CONST_ROWS.get(key)
+    if t is None:
+        if len(_CONST_ROWS) > 16:
+            _CONST_ROWS.clear()
+        t = _CONST_ROWS[key] = torch.full((M,), float(value), device=device, dtype=torch.float32)
+    return t
+
+
 def gemm_res_ssq(x, W, res, out, ssq):
     """out = res + x @ W^T (bf16 rounding once) and ssq[p, m] = sum of out[m, 64 p : 64 p + 64]^2 -- the residual add and RMSNorm's sum of
     squares in the producing GEMM's epilogue; ssq [N / 64, >= M] fp32"""

@@ -284,3 +284,57 @@ def test_dropin_fused_mlp_and_hip_rope_match_the_unfused_dropin():
     print(f"[drop-in bf16, fused MLP + HIP RoPE vs un-fused] nmax {nmax(Ra, Rb):.2e} cos {cos(Ra, Rb):.6f} | vs fp32 drop-in: fused {nmax(Ra, R32):.2e} "
           f"(cos {cos(Ra, R32):.6f}), un-fused {nmax(Rb, R32):.2e} (cos {cos(Rb, R32):.6f})")
     assert cos(Ra, Rb) > 0.999 and cos(Ra, R32) > 0.995 and nmax(Ra, R32) < 3 * max(nmax(Rb, R32), 1e-2)
+
+
+def test_dropin_fused_decoder_layer_matches_the_per_module_dropin():
+    """Round 6: for an adopted bf16 Llama at M = B S rows the drop-in path runs each decoder layer as ONE autograd node on the engine's fused launch
+    sequence (patches.decoder_layer_forward / DecoderLayerFn: fused QKV, K1n norm + residual epilogues, coefficient-stash gated rule, D and RoPE's
+    backward inside the attention backward) -- the reference's user protocol (docs/source/quickstart.rst:120-141) unchanged.  Same explanation as
+    the per-module drop-in up to bf16 rounding, both against the fp32 drop-in (which never takes the fused layer); a left-padded batch falls back
+    to the per-module path and still runs."""
+    _need_gpu()
+    from transformers.models.llama import modeling_llama
+    from lxt_amd.efficient import monkey_patch
+    import lxt_amd.efficient.patches as P
+    from oracle import llama as ol
+    from tests.golden.hf_models import build_llama_from_weights
+    cfg = dict(hidden=2048, inter=5632, n_layers=3, n_heads=16, n_kv=4, head_dim=128, vocab=1024, rope_theta=1e4, rms_eps=1e-5)
+    W = ol.random_weights(cfg, seed=77)
+    g = torch.Generator().manual_seed(78)
+    for L in W["layers"]:
+        L["ln1"] = (0.25 + 1.5 * torch.rand(cfg["hidden"], generator=g))
+        L["ln2"] = (0.25 + 1.5 * torch.rand(cfg["hidden"], generator=g))
+    B, S = 3, 2048
+    ids = torch.randint(0, cfg["vocab"], (B, S), generator=g).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkey_patch(modeling_llama)
+    assert modeling_llama.LlamaDecoderLayer.forward is P.decoder_layer_forward
+
+    def run(dtype, fuse_layer, tgt=None, mask=None):
+        model = build_llama_from_weights(cfg, W, attn="sdpa", dtype=dtype).cuda()
+        P.FUSE_LAYER = fuse_layer
+        try:
+            e = model.get_input_embeddings()(ids).detach().requires_grad_()
+            last = model(inputs_embeds=e, attention_mask=mask, use_cache=False).logits[:, -1]
+            idx = last.argmax(-1) if tgt is None else tgt
+            last[torch.arange(B), idx].sum().backward()
+            used = [bool(L.__dict__.get("_lrp_fused_layer", {}).get("ok_rows", {}).get((B, S), False)) for L in model.model.layers]
+            return idx, (e * e.grad).float().sum(-1).double().cpu(), used
+        finally:
+            P.FUSE_LAYER = True
+    i32, R32, u32 = run(torch.float32, True)
+    assert not any(u32)                                               # fp32: HF's forward over the per-module patches, as before
+    ia, Ra, ua = run(torch.bfloat16, True, tgt=i32)
+    ib, Rb, ub = run(torch.bfloat16, False, tgt=i32)
+    assert all(ua) and not any(ub)
+    e_a, e_b = [nmax(Ra[b], R32[b]) for b in range(B)], [nmax(Rb[b], R32[b]) for b in range(B)]
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))   # noqa: E731
+    print(f"[drop-in bf16, fused decoder layer vs per-module] vs the fp32 drop-in per prompt: fused layer {[f'{x:.2e}' for x in e_a]} (cos {cos(Ra, R32):.6f}), "
+          f"per-module {[f'{x:.2e}' for x in e_b]} (cos {cos(Rb, R32):.6f}); fused vs per-module {nmax(Ra, Rb):.2e}")
+    assert torch.isfinite(Ra).all() and cos(Ra, R32) > 0.999 and max(e_a) < max(2e-2, 1.5 * max(e_b))
+    # a left-padded batch: the fused layer declines (per-row key intervals), HF's forward over the per-module patches takes over
+    mask = torch.ones(B, S, dtype=torch.long, device="cuda")
+    mask[0, :100] = 0
+    _, Rp, up = run(torch.bfloat16, True, tgt=i32, mask=mask)
+    assert torch.isfinite(Rp).all() and float(Rp[0, :100].abs().max()) == 0.0
