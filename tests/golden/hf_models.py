@@ -180,9 +180,11 @@ def build_mini_vit(seed=31):
     return m
 
 
-def build_llama_from_weights(cfg, W, attn="eager", dtype=torch.float32):
+def build_llama_from_weights(cfg, W, attn="eager", dtype=torch.float32, rotary_fp32=False):
     """HF LlamaForCausalLM carrying the oracle-format weights W of config cfg (oracle/llama.py: random_weights) -- the model the Llama fixtures
-    (tests/golden/llama_*.npz) were captured on, as a user of the drop-in APIs would hold it"""
+    (tests/golden/llama_*.npz) were captured on, as a user of the drop-in APIs would hold it.  rotary_fp32: `model.to(bfloat16)` also rounds the
+    rotary embedding's inv_freq BUFFER to bf16 (positions up to S x 2^-9 relative off in phase: ~4 rad at S = 2048 for the fastest pair) -- the
+    model then computes a different network; `from_pretrained(..., dtype=bfloat16)` keeps that buffer in fp32, and True restores it the same way."""
     from transformers import LlamaConfig, LlamaForCausalLM
     hc = LlamaConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["inter"], num_hidden_layers=cfg["n_layers"],
                      num_attention_heads=cfg["n_heads"], num_key_value_heads=cfg["n_kv"], head_dim=cfg["head_dim"], vocab_size=cfg["vocab"],
@@ -201,7 +203,11 @@ def build_llama_from_weights(cfg, W, attn="eager", dtype=torch.float32):
             L.mlp.gate_proj.weight.copy_(Lw["wg"]); L.mlp.up_proj.weight.copy_(Lw["wu"]); L.mlp.down_proj.weight.copy_(Lw["wd"])
     for p_ in model.parameters():
         p_.requires_grad_(False)
-    return model.to(dtype)
+    inv = model.model.rotary_emb.inv_freq.detach().clone()
+    model = model.to(dtype)
+    if rotary_fp32:
+        model.model.rotary_emb.inv_freq = inv.to(model.model.rotary_emb.inv_freq.device)
+    return model
 
 
 def build_llama(seed=5, attn="eager"):

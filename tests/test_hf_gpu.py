@@ -312,7 +312,7 @@ def test_dropin_fused_decoder_layer_matches_the_per_module_dropin():
     assert modeling_llama.LlamaDecoderLayer.forward is P.decoder_layer_forward
 
     def run(dtype, fuse_layer, tgt=None, mask=None):
-        model = build_llama_from_weights(cfg, W, attn="sdpa", dtype=dtype).cuda()
+        model = build_llama_from_weights(cfg, W, attn="sdpa", dtype=dtype, rotary_fp32=True).cuda()      # (inv_freq as from_pretrained keeps it)
         P.FUSE_LAYER = fuse_layer
         try:
             e = model.get_input_embeddings()(ids).detach().requires_grad_()
