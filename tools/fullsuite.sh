@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round validation as the driver runs it: pytest -m gpu, smoke(), default bench
-O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5full}; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-full}; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 ( time timeout 2400 python -m pytest tests -m gpu -q -s > $O/test_all.txt 2>&1 ) 2> $O/test_time.txt; echo "pytest rc=$?" >> $O/test_all.txt; tail -4 $O/test_all.txt; cat $O/test_time.txt

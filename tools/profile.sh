@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5 profiling call: (1) rocprofv3 kernel-trace stats of the judged bench command (tails skipped: same kernel names at other shapes),
-# (2) FETCH_SIZE / WRITE_SIZE PMC passes of a 4-layer run -> GEMM traffic per launch (stamped with the kernel source hash by r5_traffic.py),
+# profiling call: (1) rocprofv3 kernel-trace stats of the judged bench command (tails skipped: same kernel names at other shapes),
+# (2) FETCH_SIZE / WRITE_SIZE PMC passes of a 4-layer run -> GEMM traffic per launch (stamped with the kernel source hash by tools/traffic.py),
 # (3) SQ counter passes of the d = 128 attention kernels.
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5prof}
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --no-config4 --no-smallm --no-extra-modes --no-dropin"

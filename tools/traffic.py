@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/<dir>/pmc_summary.json (tools/r5_profile.sh: FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1 --layers 4`) ->
-profiles/r05_gemm_traffic.json: fabric-side bytes per launch of the ping-pong GEMM instantiations next to their algorithmic bytes, STAMPED
+"""gpurun_out/<dir>/pmc_summary.json (tools/profile.sh: FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1 --layers 4`) ->
+profiles/r06_gemm_traffic.json: fabric-side bytes per launch of the ping-pong GEMM instantiations next to their algorithmic bytes, STAMPED
 with the sha256 of the kernel source they were measured on (bench.py reports the traffic only while that hash matches the tree's gemm_pp.hip)."""
 import hashlib
 import json
@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5prof3", "pmc_summary.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof", "pmc_summary.json")
 d = json.load(open(src))
 M, out = 8192, {}
 
@@ -65,9 +65,9 @@ with open(os.path.join(ROOT, "lrp-explains-transformers_amd", "csrc", "gemm_pp.h
 res = {"gemm_pp_sha16": sha, "traffic_bytes_per_launch": tt / tn, "algorithmic_bytes_per_launch": (a_nt + a_nn) / 2,
        "ratio": tt / tn / ((a_nt + a_nn) / 2), "per_kernel": out,
        "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction: 128-B requests tallied at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE x 1024; separate --pmc "
-               "passes of `bench.py --steps 1 --warmup 1 --layers 4 --no-smallm --no-config5 --no-config4 --no-extra-modes` (tools/r5_profile.sh); "
+               "passes of `bench.py --steps 1 --warmup 1 --layers 4 --no-smallm --no-config5 --no-config4 --no-extra-modes` (tools/profile.sh); "
                "fabric-side bytes of the eight per-XCD L2s (Infinity-Cache hits included): every XCD fetches its own copy of the operand panels its 32 "
                "resident 256x256 tiles share (8 + 4 panels per 32 tiles), so ~2x the algorithmic bytes is the floor of this tiling.  gemm_pp_sha16 = "
                "sha256 of csrc/gemm_pp.hip at measurement time: bench.py nulls roofline.traffic when the tree's kernel differs."}
-json.dump(res, open(os.path.join(ROOT, "profiles", "r05_gemm_traffic.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "profiles", "r06_gemm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v if k != "per_kernel" else {n: round(x["ratio"], 2) for n, x in v.items()}) for k, v in res.items() if k != "note"}))
