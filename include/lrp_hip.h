@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -283,6 +283,15 @@ int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, f
 int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);
 int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout,
                    int dtype, void* stream);
+/* lrp_gemm_nt_rs_rope (round 6; K5 of SURVEY.md 2.3 folded into K1): the fused QKV forward  out = rs[m] * (x W^T)  with HF's RoPE
+ * (apply_rotary_pos_emb: q cos + rotate_half(q) sin; constant tables, un-patched in lxt.efficient; explicit form lxt/explicit/models/llama.py:226-260)
+ * applied to the q / k head columns [0, rope_cols) in the epilogue, in fp32 on the un-rounded accumulators; columns >= rope_cols (v) only take the
+ * row scale.  cos / sin: fp32 [>= seq, 128], row p = position p (both halves of a row equal); the position of output row m is m % seq.  Heads of
+ * 128 columns, M and N multiples of 256, the 256 x 256 ping-pong kernel only: lrp_gemm_nt_rs_rope_ok() -> 1 when the entry point takes the problem,
+ * LRP_ESHAPE otherwise (the caller keeps lrp_gemm_nt_rs + lrp_rope_fwd for such shapes).  Weights and outputs stay in the standard head-dim order. */
+int lrp_gemm_nt_rs_rope_ok(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, int head_dim, int dtype);
+int lrp_gemm_nt_rs_rope(const void* x, const void* W, const float* rs, const float* cos, const float* sin, void* out, int M, int N, int K,
+                        int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, int head_dim, int dtype, void* stream);
 int lrp_gemm_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds, int64_t ldw, int64_t ldout,
                    int dtype, void* stream);      /* out[M,N] = bf16(rs[m] * (s W)), W [K,N] as stored (rs = 1/2 everywhere: the o-projection's dgrad
                                                      with the uniform rule's factor of the P.V product, lxt/efficient/patches.py:193-203) */

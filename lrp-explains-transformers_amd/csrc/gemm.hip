@@ -27,6 +27,8 @@ int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void
                              int64_t ldout, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
                              int64_t ldout, hipStream_t st);
+int lrp_launch_gemm_pp_nt_rs_rope(const void* x, const void* W, const float* rs, const float* cos, const float* sin, void* out, int M, int N, int K,
+                                  int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
                                  int64_t ldw, int64_t ldres, int64_t ldout, hipStream_t st);
 
@@ -673,6 +675,31 @@ extern "C" int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, voi
     for (int m0 = 0; m0 < M; m0 += chunk) {
         const int rc = lrp_launch_gemm_pp_nt_rs((const char*)x + (int64_t)m0 * ldx * 2, W, rs + m0, (char*)out + (int64_t)m0 * ldout * 2,
                                                 M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw, ldout, (hipStream_t)stream);
+        if (rc != LRP_OK) return rc;
+    }
+    return LRP_OK;
+}
+
+extern "C" int lrp_gemm_nt_rs_rope_ok(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, int head_dim, int dtype) {
+    if (head_dim != 128 || seq <= 0 || (seq % 16) || rope_cols < 0 || rope_cols > N || (rope_cols % 128) || (M % 256) || (ldout % 8)) return 0;
+    const int chunk = pp_row_chunk(ldx);
+    if (M > chunk && (chunk % seq) && (seq % chunk)) return 0;                // (row chunks of a huge batch must start on a prompt boundary modulo seq)
+    return lrp_gemm_norm_fused_ok(M, N, K, ldx, ldw, 0, dtype);
+}
+
+extern "C" int lrp_gemm_nt_rs_rope(const void* x, const void* W, const float* rs, const float* cos, const float* sin, void* out, int M, int N, int K,
+                                   int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, int head_dim, int dtype, void* stream) {
+    if (!x || !W || !rs || !cos || !sin || !out || M < 0 || N < 0 || K < 0) return LRP_EINVAL;
+    if (M == 0 || N == 0) return LRP_OK;
+    if (!lrp_gemm_nt_rs_rope_ok(M, N, K, ldx, ldw, ldout, seq, rope_cols, head_dim, dtype)) return LRP_ESHAPE;
+    if (!a16(x) || !a16(W) || !a16(out) || !a16(cos) || !a16(sin)) return LRP_EALIGN;
+    const int chunk = pp_row_chunk(ldx);
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+        // (the kernel takes positions as row % seq: a chunk that starts inside a prompt is shifted by handing it tables that start at that position)
+        const int p0 = m0 % seq;
+        const int rc = lrp_launch_gemm_pp_nt_rs_rope((const char*)x + (int64_t)m0 * ldx * 2, W, rs + m0, cos + (int64_t)p0 * 128, sin + (int64_t)p0 * 128,
+                                                     (char*)out + (int64_t)m0 * ldout * 2, M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw, ldout,
+                                                     seq, rope_cols, (hipStream_t)stream);
         if (rc != LRP_OK) return rc;
     }
     return LRP_OK;

@@ -98,6 +98,11 @@ struct PPEpi {
     int64_t ldres;
     float* ssq;            // EPI 3: partial sums of squares of the bf16-rounded output rows, [N / 64][ldssq] (one 64-column block per wave)
     int64_t ldssq;
+    // round 6, EPI 5: RoPE on the q / k columns of the fused QKV forward (lrp_gemm_nt_rs_rope)
+    const float* cos;      // fp32 [>= seq, 128] tables (rotate-half convention: both halves of a row equal; only the first is read)
+    const float* sin;
+    int seq;               // rows per prompt: the position of output row m is m % seq
+    int rope_cols;         // columns [0, rope_cols) are q / k heads of 128; the rest (v) pass through
 };
 
 // SK ("skinny"): the problem has ONE row of tiles and fewer than 241 rows (the HBM-bound regime of the Linear eps-rule, M <~ 160): 16-row
@@ -106,6 +111,12 @@ struct PPEpi {
 // EPI 3: C = bf16(acc + res), ssq partials (the residual add + the sum of squares of RMSNorm in the producing GEMM);  EPI 4: C = bf16(rs acc + res)
 // (RMSNorm's identity-rule backward + the residual gradient in the dgrad GEMM);  RS with EPI 0 / 1: acc scaled by rs[row] first (the norm's
 // 1 / rms applied to the consumer's OUTPUT rows: (rstd x) W^T = rstd (x W^T); the norm's weight is folded into W by the host).
+// EPI 5 (NT, RS): the fused QKV forward with RoPE in the epilogue (K5 of SURVEY.md 2.3; HF apply_rotary_pos_emb, ref
+// lxt/explicit/models/llama.py:226-260 -- constant cos / sin: the reference leaves it un-patched).  A rotate-half pair (c, c + 64) of a 128-wide
+// head sits 64 columns apart, i.e. in TWO waves of the standard tile mapping; here the wave reads its B fragments from the rows
+// {32 w .. 32 w + 31} and {64 + 32 w .. 64 + 32 w + 31} of its head (w = wave & 1) -- two immediates of the fragment read change, nothing else --
+// so that column tiles j and j + 2 of ONE lane are a rotation pair, and stores its two 32-column segments where they belong.  Weights,
+// activations and every other kernel keep the standard head-dim order.
 template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         for (int j = 0; j < 4; ++j)
             cB[j] = (unsigned)(2 * PP_OPND + (8 * hi + (i16 >> 2)) * 512 + (((8 * wc + 2 * j + ((i16 & 3) >> 1)) ^ f) << 4) + 8 * (i16 & 1));
     } else {
-        const unsigned rowB = (unsigned)(2 * PP_OPND + (wc * 64 + (lane & 15)) * 128);
+        const unsigned rowB = (unsigned)(2 * PP_OPND + ((EPI == 5 ? (wc >> 1) * 128 + (wc & 1) * 32 : wc * 64) + (lane & 15)) * 128);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) cB[ks] = rowB + (unsigned)(((4 * ks + hi) ^ (lane & 7)) << 4);
         cB[2] = cB[3] = 0;
@@ -250,6 +261,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     if constexpr (EPI == 3) {
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
+    // EPI 5: cos / sin of row block k in tpre[k & 1] = {cos tile 0, cos tile 1, sin tile 0, sin tile 1} of the lane's 2 x 4 table columns
+    const int w5 = wc & 1, hb5 = (wc >> 1) * 128;
+    const bool rot5 = (EPI == 5) && en0 < ep.rope_cols;              // q / k tile (tile-uniform); v tiles only take the row scale
+    f32x4 tpre[2][4];
+    // (seq is a multiple of 16 -- lrp_gemm_nt_rs_rope_ok -- so the 16 rows of a row block share one prompt and their positions are
+    // consecutive: the block's first position is WAVE-UNIFORM, scalar arithmetic incl. the modulo, and the lane part of the address one register)
+    const int lane_tab = (lane & 15) * 128 + 32 * w5 + 4 * hi;
+    auto issue_tab = [&](int b, f32x4 (&d)[4]) {
+        const int pos = (em0 + g * 128 + (b >> 2) * 64 + (b & 3) * 16) % ep.seq;
+        const float* pc = ep.cos + (int64_t)pos * 128;
+        const float* ps = ep.sin + (int64_t)pos * 128;
+        d[0] = *reinterpret_cast<const f32x4*>(pc + lane_tab);
+        d[1] = *reinterpret_cast<const f32x4*>(pc + lane_tab + 16);
+        d[2] = *reinterpret_cast<const f32x4*>(ps + lane_tab);
+        d[3] = *reinterpret_cast<const f32x4*>(ps + lane_tab + 16);
+    };
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -278,8 +305,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
             PP_DSRD(fb[0][ks].v, cB[ks], (BUF) * PP_OPND);                                        \
             PP_DSRD(fb[1][ks].v, cB[ks], (BUF) * PP_OPND + 2048);                                 \
-            PP_DSRD(fb[2][ks].v, cB[ks], (BUF) * PP_OPND + 4096);                                 \
-            PP_DSRD(fb[3][ks].v, cB[ks], (BUF) * PP_OPND + 6144);                                 \
+            PP_DSRD(fb[2][ks].v, cB[ks], (BUF) * PP_OPND + (EPI == 5 ? 8192 : 4096));             \
+            PP_DSRD(fb[3][ks].v, cB[ks], (BUF) * PP_OPND + (EPI == 5 ? 10240 : 6144));            \
         }                                                                                         \
     }
 #define PP_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),   \
@@ -336,6 +363,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     }
     if constexpr (EPI == 3) {
         asm volatile("" : "+v"(rpre[0][0]), "+v"(rpre[0][1]), "+v"(rpre[1][0]), "+v"(rpre[1][1]));
+    }
+    if constexpr (EPI == 5) {        // (the tables of the first two row blocks: requested here, ahead of the next tile's staging pieces, like EPI 4's operands)
+        issue_tab(0, tpre[0]); issue_tab(1, tpre[1]);              // (v tiles load them too and ignore them: flat control flow, no spills)
     }
     // EPI 2: the coefficient loads of the first row block, likewise ahead of the staging pieces.  Lane (row l & 15, hi) reads, for column tile j,
     // the 16 bytes {cg x 4 | cu x 4} of ITS four intermediate indices ncol + 16 j + 4 hi .. + 3: the stash is in accumulator order (no cross-lane
@@ -468,6 +498,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 else if (b == 1) { issue_res(4, rpre[0]); issue_res(5, rpre[1]); }
                 else if (b == 2) issue_res(6, rpre[2]);
                 else if (b == 3) issue_res(7, rpre[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = true;
+        }
+    }
+    if constexpr (EPI == 5) {
+        // ---- row scale + RoPE + bf16 pack, full tiles (the host admits only M, N multiples of 256).  Tables software-pipelined two row blocks
+        // deep: blocks 0 and 1 were requested right after the K loop, block b + 2 goes out behind block b's stores (8 x 16 B per lane in flight;
+        // the tables are L2-resident: 1 MB).
+        if (full) {
+            bf16_t* cdst = reinterpret_cast<bf16_t*>(C) + (int64_t)mrow * ldc + en0 + hb5 + 32 * w5 + epoff;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[b >> 2][b & 3][j] * rsv[b];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x4 cs = tpre[b & 1][jj], sn = tpre[b & 1][2 + jj];
+                    if (!rot5) { cs = f32x4{1.f, 1.f, 1.f, 1.f}; sn = f32x4{0.f, 0.f, 0.f, 0.f}; }      // v tile: the identity rotation
+                    const f32x4 x1 = v[jj], x2 = v[jj + 2];
+                    v[jj] = x1 * cs - x2 * sn;
+                    v[jj + 2] = x2 * cs + x1 * sn;
+                }
+                u32x4 out[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bf16x2 x0 = {(bf16_t)v[2 * jj][0], (bf16_t)v[2 * jj][1]}, x1 = {(bf16_t)v[2 * jj][2], (bf16_t)v[2 * jj][3]};
+                    bf16x2 y0 = {(bf16_t)v[2 * jj + 1][0], (bf16_t)v[2 * jj + 1][1]}, y1 = {(bf16_t)v[2 * jj + 1][2], (bf16_t)v[2 * jj + 1][3]};
+                    auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, y0), false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, y1), false, false);
+                    out[jj] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16_t* dst = cdst + (int64_t)((b >> 2) * 64 + (b & 3) * 16) * ldc;
+                *reinterpret_cast<u32x4*>(dst) = out[0];                 // head-dim columns 32 w .. + 31 of the wave's head
+                *reinterpret_cast<u32x4*>(dst + 64) = out[1];            // their rotate-half partners 64 + 32 w .. + 31
+                if (b + 2 < 8) issue_tab(b + 2, tpre[b & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             done = true;
@@ -622,6 +690,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
         for (int b = 0; b < 8; ++b) asm volatile("" :: "v"(rsv[b]));
     }
+    if constexpr (EPI == 5) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(tpre[0][k]), "v"(tpre[1][k]));
+    }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
     if (!has_next) break;
     // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
@@ -629,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     // the fused gated backward's own gu loads were issued after the pieces and waited for by the compiler, only its last stores remain;
     // ragged tiles and fp32 output (scalar / conditional stores): drain.
     if (full && sizeof(TO) == 2) {
-        if constexpr (EPI == 0) PP_VMWAIT(24);
+        if constexpr (EPI == 0 || EPI == 5) PP_VMWAIT(24);
         else if constexpr (EPI == 1) PP_VMWAIT(32);
         else PP_VMWAIT(8);
     } else PP_VMWAIT(0);
@@ -736,6 +808,13 @@ int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void
     PPEpi ep{};
     ep.rs = rs;
     return launch_pp_t<bf16_t, false, 0, 0, false, false, true>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
+}
+// out = RoPE(rs (.) (x W^T)) on the q / k head columns [0, rope_cols), rs (.) (x W^T) on the rest (NT; heads of 128; M, N multiples of 256)
+int lrp_launch_gemm_pp_nt_rs_rope(const void* x, const void* W, const float* rs, const float* cos, const float* sin, void* out, int M, int N, int K,
+                                  int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, hipStream_t st) {
+    PPEpi ep{};
+    ep.rs = rs; ep.cos = cos; ep.sin = sin; ep.seq = seq; ep.rope_cols = rope_cols;
+    return launch_pp_t<bf16_t, false, 5, 0, false, false, true>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
 }
 // out = rs (.) (s W) (NN: W [K, N] as stored)
 int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,

@@ -139,8 +139,11 @@ class DecoderLayerFn(Function):
         h2 = h.reshape(M, H)
         if not h2.is_contiguous():
             h2 = h2.contiguous()
-        qkv = ops.gemm_nt_rs(h2, Wqkv, rstd1, new(M, nqkv))
-        qkr = ops.rope_fwd(qkv, new(M, nqk), cos, sin, S, nq + nk, d)
+        qkv = new(M, nqkv)
+        if ops.gemm_nt_rs_rope_ok(h2, Wqkv, qkv, S, nqk, d):
+            qkr = ops.gemm_nt_rs_rope(h2, Wqkv, rstd1, cos, sin, qkv, S, nqk, d)[:, :nqk]      # RoPE in the GEMM's epilogue
+        else:
+            qkr = ops.rope_fwd(ops.gemm_nt_rs(h2, Wqkv, rstd1, qkv), new(M, nqk), cos, sin, S, nq + nk, d)
         q, k, v = qkr[:, : nq * d], qkr[:, nq * d:], qkv[:, nqk:]
         o, lse = new(M, nq * d), torch.empty(B, nq, S, device=dev, dtype=torch.float32)
         ops.attn_fwd(q, k, v, None, o, lse, B, S, nq, nk, d, scale, True, 0)

@@ -357,11 +357,18 @@ class LlamaLRP:
         nL = len(self.layers)
         for li, Lw in enumerate(self.layers):
             st = {}
+            rotated = False
             top = self.sparse_top and li == nL - 1
             if ready is not None:
                 st["h"], st["rstd1"] = ready
                 ready = None
-                qkv = ops.gemm_nt_rs(st["h"], Lw["wqkv"], st["rstd1"], new(("qkv", li), M, nqkv))
+                qkv = new(("qkv", li), M, nqkv)
+                if S <= self.max_seq and ops.gemm_nt_rs_rope_ok(st["h"], Lw["wqkv"], qkv, S, nqk, d):
+                    # RoPE in the QKV GEMM's epilogue: q and k leave the kernel rotated (no rope_fwd pass, no second copy of q / k)
+                    ops.gemm_nt_rs_rope(st["h"], Lw["wqkv"], st["rstd1"], self.cos, self.sin, qkv, S, nqk, d)
+                    rotated = True
+                else:
+                    ops.gemm_nt_rs(st["h"], Lw["wqkv"], st["rstd1"], qkv)
             else:
                 x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
                 if branch is None:
@@ -371,7 +378,7 @@ class LlamaLRP:
                     st["h"] = new(("h", li), M, H)
                     ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln1"], c["rms_eps"], hsum_out=st["h"], y=x, rstd=st["rstd1"])
                 qkv = self._lin_fwd(x, Lw["wqkv"], new(("qkv", li), M, nqkv))
-            qkr = ops.rope_fwd(qkv, new(("qkr", li), M, nqk), self.cos, self.sin, S, nq + nk, d)
+            qkr = qkv[:, :nqk] if rotated else ops.rope_fwd(qkv, new(("qkr", li), M, nqk), self.cos, self.sin, S, nq + nk, d)
             v = qkv[:, nqk:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o = new(("o", li), M, nq * d)

@@ -589,6 +589,28 @@ def gemm_nt_rs(x, W, rs, out):
     return out
 
 
+ROPE_FWD_FUSION = True   # module attribute (A/B): False = lrp_gemm_nt_rs + the stand-alone lrp_rope_fwd pass
+
+
+def gemm_nt_rs_rope_ok(x, W, out, seq, rope_cols, head_dim):
+    M, K = x.shape
+    return bool(ROPE_FWD_FUSION and NORM_FUSION and x.dtype == torch.bfloat16 and
+                lib.lrp_gemm_nt_rs_rope_ok(M, W.shape[0], K, x.stride(0), W.stride(0), out.stride(0), seq, rope_cols, head_dim, _DT[x.dtype]))
+
+
+def gemm_nt_rs_rope(x, W, rs, cos, sin, out, seq, rope_cols, head_dim):
+    """out = rs[:, None] * (x @ W^T) with RoPE applied to the head columns [0, rope_cols) in the GEMM's epilogue (the fused QKV forward: q and k
+    leave the kernel rotated, v untouched); cos / sin fp32 [>= seq, head_dim], position of row m = m % seq"""
+    M, K = x.shape
+    N = W.shape[0]
+    same(x, W, out)
+    f32(rs, cos, sin)
+    assert cos.shape[0] >= seq and cos.stride(0) == head_dim and sin.stride(0) == head_dim
+    _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_nt_rs_rope(p(x), p(W), p(rs), p(cos), p(sin), p(out), M, N, K, x.stride(0), W.stride(0),
+                                                                          out.stride(0), seq, rope_cols, head_dim, dt(x), stream()), "lrp_gemm_nt_rs_rope")
+    return out
+
+
 def gemm_nn_rs(s, W, rs, out):
     """out = rs[:, None] * (s @ W) from the STORED weight W [K, N] (rs = 1/2: the o-projection's dgrad with the uniform rule's factor)"""
     M, K = s.shape

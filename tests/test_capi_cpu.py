@@ -51,6 +51,12 @@ def test_round5_host_side_queries_and_layout_rules():
     # dQ with D (and RoPE's backward): the bf16 32x32 kernels of head dims 64 / 96 / 128
     assert [lib.lrp_attn_bwd_dq_d_ok(BF16, d) for d in (64, 96, 128, 256, 32)] == [1, 1, 1, 0, 0] and lib.lrp_attn_bwd_dq_d_ok(F32, 128) == 0
     assert lib.lrp_gqa_reduce_rope(None, None, 8, 8, 2, 2, 64, 256, 128, None, None, BF16, None) == -1
+    # RoPE in the QKV forward's epilogue: heads of 128, M and N multiples of 256, seq a multiple of 16
+    assert lib.lrp_gemm_nt_rs_rope_ok(8192, 6144, 4096, 4096, 4224, 6144, 2048, 5120, 128, BF16) == 1
+    assert lib.lrp_gemm_nt_rs_rope_ok(8192, 6144, 4096, 4096, 4224, 6144, 2048, 5120, 64, BF16) == 0
+    assert lib.lrp_gemm_nt_rs_rope_ok(8200, 6144, 4096, 4096, 4224, 6144, 2050, 5120, 128, BF16) == 0
+    assert lib.lrp_gemm_nt_rs_rope_ok(8192, 6144, 4096, 4096, 4224, 6144, 2048, 5000, 128, BF16) == 0
+    assert lib.lrp_gemm_nt_rs_rope(None, None, None, None, None, None, 256, 256, 128, 128, 128, 256, 256, 256, 128, BF16, None) == -1
     # the fused gated-MLP pair (coefficient stash): both launches must be >= 190-tile bf16 problems
     assert lib.lrp_gemm_gated_coef_ok(8192, 14336, 4096, 4096, 4224, 4096, 14400, 0, BF16) == 1
     assert lib.lrp_gemm_gated_coef_ok(2048, 14336, 4096, 4096, 4224, 4096, 14400, 0, BF16) == 1        # 8 x 56 = 448 tiles in the backward

@@ -428,6 +428,40 @@ def test_gemm_gated_coef_epilogues(ops, M, I, K, act, scaled):
             assert nmax(torch.where(live_u, Au.double(), z), torch.where(live_u, Au2, z)) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K,seq,rope_cols", [(2048, 6144, 256, 512, 5120), (2304, 5632, 192, 192, 4608), (8192, 6144, 128, 2048, 5120)])
+def test_gemm_nt_rs_rope(ops, M, N, K, seq, rope_cols):
+    """lrp_gemm_nt_rs_rope (round 6): the fused QKV forward with RoPE in the epilogue -- HF's apply_rotary_pos_emb (q cos + rotate_half(q) sin) on
+    the head columns [0, rope_cols), the K1n row scale everywhere, v columns untouched; positions = row % seq (prompts that end inside a 256-row
+    tile included).  Against fp64 on the same bf16 operands, and against the two-launch form lrp_gemm_nt_rs + lrp_rope_fwd to bf16 rounding (the
+    fused form rounds once)."""
+    g_ = torch.Generator().manual_seed(M + N + seq)
+    bf, d = torch.bfloat16, 128
+    x = torch.randn(M, K, generator=g_).to(bf).cuda()
+    W = (torch.randn(N, K, generator=g_) * K ** -0.5).to(bf).cuda()
+    rs = (torch.rand(M, generator=g_) + 0.5).cuda()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.arange(seq + 7, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos().to(bf).float().cuda().contiguous(), emb.sin().to(bf).float().cuda().contiguous()
+    out = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
+    assert ops.gemm_nt_rs_rope_ok(x, W, out, seq, rope_cols, d)
+    assert not ops.gemm_nt_rs_rope_ok(x, W, out, seq, rope_cols, 64) and not ops.gemm_nt_rs_rope_ok(x[:300], W, out[:300], seq, rope_cols, d)
+    assert not ops.gemm_nt_rs_rope_ok(x, W, out, seq + 8, rope_cols, d)                      # seq must be a multiple of 16
+    ops.gemm_nt_rs_rope(x, W, rs, cos, sin, out, seq, rope_cols, d)
+    z = rs.double()[:, None] * (f64(x) @ f64(W).T)
+    zr = z[:, :rope_cols].view(M, rope_cols // d, d)
+    pos = torch.arange(M, device="cuda") % seq
+    c, s_ = cos.double()[pos][:, None, :], sin.double()[pos][:, None, :]
+    rot = torch.cat((-zr[..., d // 2:], zr[..., : d // 2]), -1)
+    ref = torch.cat(((zr * c + rot * s_).view(M, rope_cols), z[:, rope_cols:]), 1)
+    assert not torch.isnan(out).any() and nmax(out, ref) < 1e-2
+    assert (out.double() - ref).abs().max() <= ref.abs().max() * 2.0 ** -8                     # ONE bf16 rounding of the fp32 result
+    two = torch.empty(M, N, dtype=bf, device="cuda")
+    ops.gemm_nt_rs(x, W, rs, two)
+    two_r = ops.rope_fwd(two, torch.empty(M, rope_cols, dtype=bf, device="cuda"), cos, sin, seq, rope_cols // d, d)
+    assert nmax(out[:, :rope_cols], two_r.double()) < 1.5e-2 and torch.equal(out[:, rope_cols:], two[:, rope_cols:])
+
+
 @pytest.mark.parametrize("M,H,K,I", [(2304, 5632, 512, 2816), (2100, 5632, 256, 3072)])
 def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     """K1n (include/lrp_hip.h): Llama-type RMSNorm (ref lxt/efficient/patches.py:111-123, variance detached = identity rule) and the residual
