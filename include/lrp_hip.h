@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; stream-K for tile counts off the CU grid -- lrp_gemm_streamk[_ok|_ws|_flags]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -128,18 +128,6 @@ int lrp_linear_stream_dgrad_tk(const void* s, const void* z, const void* W, void
  *   nn = 0: C = A[M,K] . B[N,K]^T (forward z = x W^T);   nn = 1: C = A[M,K] . B[K,N] (redistribution c = s W, W as stored).
  * Same operand restrictions as lrp_gemm_nn.  ref: lxt/explicit/functional.py:351 (forward), :355-364 (backward). */
 int64_t lrp_gemm_skinny_ws(int M, int N, int K);
-/* lrp_gemm_streamk (round 6): C[M,N] = A . B^T (nn = 0) or A . Bt (nn = 1) (+ bias), bf16, for problems of MORE than 256 rows whose 256 x 256
- * tile count is no whole number of rounds of the CUs (one prompt per step: 192 / 448 / 896 tiles on 256 CUs; Gemma-3's N = 2560: 320; SigLIP).
- * ONE launch of one workgroup per CU; every workgroup gets an equal share of the (tile, K-tile) iterations; a tile split between workgroups is
- * summed by the one that reaches its K end, from fp32 partials the others park in `ws` (lrp_gemm_streamk_ws() bytes) behind one flag word each
- * (`flags`: lrp_gemm_streamk_flags() zero-initialised 32-bit words, private to the stream, re-armed by the kernel).  Deterministic (fixed
- * summation order).  lrp_gemm_streamk_ok() -> 1 when the entry point takes the problem (K % 128 == 0, >= 128 tiles, the last round of the plain
- * walk would waste >= 8 %), LRP_ESHAPE otherwise.  Same product as lrp_gemm_nt / lrp_gemm_nn (ref lxt/explicit/functional.py:345-364). */
-int lrp_gemm_streamk_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype);
-int64_t lrp_gemm_streamk_ws(void);
-int lrp_gemm_streamk_flags(void);
-int lrp_gemm_streamk(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                     int nn, int dtype, void* ws, void* flags, void* stream);
 int lrp_gemm_skinny_splits(int M, int N, int K);      /* K splits lrp_gemm_skinny would use (1: the plain GEMM serves the problem as well) */
 int lrp_gemm_skinny(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
                     int64_t ldc, int nn, int dtype, int out_dtype, void* ws, void* stream);

@@ -27,8 +27,6 @@ int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void
                              int64_t ldout, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
                              int64_t ldout, hipStream_t st);
-int lrp_launch_gemm_pp_streamk(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                               int64_t ldc, int nn, void* ws, void* flags, hipStream_t st);
 int lrp_launch_gemm_pp_nt_rs_rope(const void* x, const void* W, const float* rs, const float* cos, const float* sin, void* out, int M, int N, int K,
                                   int64_t ldx, int64_t ldw, int64_t ldout, int seq, int rope_cols, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs_res(const void* s, const void* W, const float* rs, const void* res, void* out, int M, int N, int K, int64_t lds_,
@@ -516,30 +514,6 @@ extern "C" int lrp_gemm_nn(const void* A, const void* Bt, void* C, const void* b
         if (rc != LRP_OK) return rc;
     }
     return LRP_OK;
-}
-
-// ---- stream-K (round 6): bf16 problems of MORE than 256 rows whose 256 x 256 tile count is no whole number of rounds of the CUs
-namespace {
-bool streamk_fits(int M, int N, int K, int64_t lda, int64_t ldb, int nn) {
-    if (M <= 256 || K % 128 || K < 256 || !pp_ok(M, N, K, lda, ldb, nn) || M > pp_row_chunk(lda)) return false;
-    const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    const int g = lrp_num_cus() / 8 * 8;
-    if (g < 8 || tiles < g / 2) return false;                                // every workgroup's share >= half a tile: at most two partners per tile
-    const int64_t rounds = (tiles + g - 1) / g;
-    return tiles % g != 0 && (rounds * g - tiles) * 100 >= 8 * tiles;        // the last round wastes at least 8 % of the launch
-}
-}  // namespace
-extern "C" int lrp_gemm_streamk_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype) {
-    return (dtype == LRP_BF16 && M > 0 && N > 0 && K > 0 && !(lda % 8) && !(ldb % 8) && streamk_fits(M, N, K, lda, ldb, nn)) ? 1 : 0;
-}
-extern "C" int64_t lrp_gemm_streamk_ws(void) { return (int64_t)(lrp_num_cus() / 8 * 8) * 256 * 256 * 4; }
-extern "C" int lrp_gemm_streamk_flags(void) { return lrp_num_cus() / 8 * 8; }
-extern "C" int lrp_gemm_streamk(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                                int64_t ldc, int nn, int dtype, void* ws, void* flags, void* stream) {
-    if (!A || !B || !C || !ws || !flags || M <= 0 || N <= 0 || K <= 0) return LRP_EINVAL;
-    if (!lrp_gemm_streamk_ok(M, N, K, lda, ldb, nn, dtype)) return LRP_ESHAPE;
-    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return LRP_EALIGN;
-    return lrp_launch_gemm_pp_streamk(A, B, C, bias, M, N, K, lda, ldb, ldc, nn, ws, flags, (hipStream_t)stream);
 }
 
 extern "C" int lrp_gemm_skinny_splits(int M, int N, int K) {

@@ -117,59 +117,23 @@ struct PPEpi {
 // {32 w .. 32 w + 31} and {64 + 32 w .. 64 + 32 w + 31} of its head (w = wave & 1) -- two immediates of the fragment read change, nothing else --
 // so that column tiles j and j + 2 of ONE lane are a rotation pair, and stores its two 32-column segments where they belong.  Weights,
 // activations and every other kernel keep the standard head-dim order.
-// STK (round 6, stream-K): for problems whose tile count is no multiple of the CU count (one prompt per step: 192 / 448 / 896 tiles on 256 CUs;
-// Gemma-3's N = 2560: 320; SigLIP) the launch is one workgroup per CU and every workgroup gets an EQUAL share of the (tile, K-tile pair)
-// iterations instead of whole tiles.  The tiles are first dealt to the eight XCDs in whole tiles (the grouped order: a XCD's tiles are a compact
-// block, as in the plain walk); inside a XCD its 32 workgroups split that XCD's iterations evenly.  A workgroup walks its range from the END:
-// the head part of its last tile first -- K tiles [2 a, 2 b) with b short of the tile's end: the partial sums are PARKED in its workspace slot
-// (fp32, lane-linear, agent-scope stores) and its flag is raised --, then whole tiles, last the tail part of its first tile, which reaches the
-// tile's K end: that workgroup is the tile's REDUCER -- it adds the parked partials of the workgroups below it (local index - 1, - 2, ...: they
-// parked theirs at the very start of the launch and were dispatched earlier, so the wait cannot deadlock) in that fixed order and runs the
-// epilogue.  Deterministic: a tile's sum is always (own K tail, in order) + (partials in workgroup order).  Flags are caller-owned zeros and
-// are re-armed by the reducer.
-template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false, bool STK = false>
+template <typename TO, bool NN, int EPI, int ACT, bool SK = false, bool LEAN = false, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C, const bf16_t* __restrict__ bias,
-    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep,
-    float* __restrict__ stk_ws, unsigned* __restrict__ stk_flags) {
+    int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int kt_per_split, int64_t slab_stride, PPEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wc = wave & 3;
     // this workgroup's range of K tiles (split-K: blockIdx.y), host guarantees >= 2 tiles per split
     const int nkt_all = K / PP_KT;
-    int kt0 = blockIdx.y * kt_per_split;                               // (mutable only in the stream-K instantiations: one value per segment)
-    int nkt = min(kt_per_split, nkt_all - kt0);
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int nkt = min(kt_per_split, nkt_all - kt0);
     C += (int64_t)blockIdx.y * slab_stride;
     const int ntiles = tiles_m * tiles_n;
     int tile = blockIdx.x;
     int m0, n0;                                                        // the tile whose K loop runs / ran last (epilogue coordinates)
-    // stream-K: this workgroup's range [sk_lo, sk_cur) of its XCD's (tile, K-tile pair) iterations, walked from the end; the running segment is
-    // pairs [sk_a, sk_b) of local tile sk_tl
-    int sk_lo = 0, sk_cur = 0, sk_base = 0, sk_np = 1, sk_a = 0, sk_b = 0, sk_tl = 0, sk_total = 0, sk_nloc = 1;
-    auto sk_segment = [&]() {
-        sk_tl = (sk_cur - 1) / sk_np;
-        const int s_lo = max(sk_lo, sk_tl * sk_np);
-        sk_a = s_lo - sk_tl * sk_np; sk_b = sk_cur - sk_tl * sk_np;
-        kt0 = 2 * sk_a; nkt = 2 * (sk_b - sk_a);
-        tile = sk_base + sk_tl;
-        int tm, tn;
-        grouped_tile(tile, tiles_m, tiles_n, tm, tn);
-        m0 = tm * 256; n0 = tn * 256;
-        sk_cur = s_lo;
-    };
-    if constexpr (STK) {
-        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-        const int q = ntiles >> 3, r = ntiles & 7;
-        sk_nloc = gridDim.x >> 3;
-        sk_base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;          // the XCD's tiles: a contiguous block of the grouped order
-        sk_np = nkt_all >> 1;
-        sk_total = (q + (xcd < r ? 1 : 0)) * sk_np;
-        sk_lo = (int)((int64_t)li * sk_total / sk_nloc);
-        sk_cur = (int)((int64_t)(li + 1) * sk_total / sk_nloc);
-        if (sk_cur <= sk_lo) return;                                  // (more workgroups than iterations)
-        sk_segment();
-    } else {
+    {
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
         m0 = tm * 256; n0 = tn * 256;
@@ -420,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         if (full) { issue_res(0, rpre[0]); issue_res(1, rpre[1]); }
     }
 #if PP_PERSIST
-    if (!STK && tile + (int)gridDim.x < ntiles) {
+    if (tile + (int)gridDim.x < ntiles) {
         tile += gridDim.x;
         int tm, tn;
         grouped_tile(xcd_remap(tile, ntiles), tiles_m, tiles_n, tm, tn);
@@ -431,51 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         issue_prologue();
     }
 #endif
-    bool sk_parked = false;
-    int sk_np_ = 0;                                                    // partners whose parked partial sums belong to this tile (0, 1 or 2)
-    if constexpr (STK) {
-        // lane-linear fp32 image of the accumulators: quad q of thread tid at slot + (q 512 + tid) 16 B, as two 8-byte agent-scope accesses
-        // (write-through stores, loads that bypass this XCD's non-coherent L2 lines: the partner runs on the same XCD here, but the protocol
-        // does not rely on it)
-        if (sk_b < sk_np) {
-            // (inline asm on the accumulator quads themselves: through f32x2 temporaries the compiler copied all 128 registers first and spilled;
-            // sc1 = agent scope: write-through.  ONE running address, made opaque per step: hoisted, the 32 addresses are 64 live registers.
-            // s_nop: a store of more than 8 bytes reads its data registers one wait state after issue, and the compiler does not see hazards of
-            // inline asm)
-            uint64_t pa = reinterpret_cast<uint64_t>(stk_ws + (size_t)blockIdx.x * (256 * 256) + 4 * tid);
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pa), "v"(acc[q >> 4][(q >> 2) & 3][q & 3]) : "memory");
-                pa += 8192;
-                asm volatile("" : "+v"(pa));
-            }
-            PP_VMWAIT(0);
-            __builtin_amdgcn_s_barrier();                              // every wave's part of the partial has left (both groups: one barrier each)
-            if (tid == 0) __hip_atomic_store(stk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk_parked = true;
-        } else if (sk_a > 0) {
-            // reducer: the workgroups below this one (same XCD: blockIdx.x - 8, - 16) hold the K tiles [0, 2 sk_a) of this tile.  The host only
-            // launches shares of at least half a tile, so there are at most TWO of them.  Here only the WAIT for their flags; their partials are
-            // added while the epilogue reads the accumulators (adding them in place makes the accumulators path-dependent values: the compiler
-            // reconciled the register assignments of the three paths with 128 copies and spilled).
-            const int li = blockIdx.x >> 3, tstart = sk_tl * sk_np;
-            sk_np_ = ((int)((int64_t)(li - 1) * sk_total / sk_nloc) > tstart) ? 2 : 1;      // (the first partner began inside the tile: a second one)
-            if (tid == 0) {
-                for (int k = 1; k <= sk_np_; ++k) {
-                    unsigned* fl = stk_flags + ((int)blockIdx.x - 8 * k);
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                        __builtin_amdgcn_s_sleep(16);
-                        if (++spins > (1u << 26)) __builtin_trap();    // (minutes: a lost partner must not hang the device)
-                    }
-                    __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // re-arm for the next launch
-                }
-            }
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-    if (!sk_parked) {
+    {
     // ---- epilogue
     const bool vec4 = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     bool done = false;
@@ -621,12 +541,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
             done = true;
         }
     }
-    uint64_t* sk_p1 = nullptr;
-    uint64_t* sk_p2 = nullptr;
-    if constexpr (STK) {
-        if (sk_np_ > 0) sk_p1 = reinterpret_cast<uint64_t*>(stk_ws + (size_t)((int)blockIdx.x - 8) * (256 * 256)) + 2 * tid;
-        if (sk_np_ > 1) sk_p2 = reinterpret_cast<uint64_t*>(stk_ws + (size_t)((int)blockIdx.x - 16) * (256 * 256)) + 2 * tid;
-    }
     if (!done)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -637,25 +551,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = acc[a][i][j];
-                if constexpr (STK) {
-                    // the partners' parked partial sums of this quad (lane-linear image: quad q = 16 a + 4 i + j of thread tid at (q 512 + tid) 16 B;
-                    // the loop visits the quads in that order: ONE running address per partner, opaque to the compiler -- hoisted, the 64 addresses
-                    // are 128 registers), added in workgroup order: the tile's sum is the same whoever arrives when
-                    if (sk_np_ > 0) {
-                        const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(sk_p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        const f32x2 hi2 = __builtin_bit_cast(f32x2, __hip_atomic_load(sk_p1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        v[j] += f32x4{lo[0], lo[1], hi2[0], hi2[1]};
-                        sk_p1 += 1024;
-                        asm volatile("" : "+v"(sk_p1));
-                        if (sk_np_ > 1) {
-                            const f32x2 lo2 = __builtin_bit_cast(f32x2, __hip_atomic_load(sk_p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            const f32x2 hi3 = __builtin_bit_cast(f32x2, __hip_atomic_load(sk_p2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            v[j] += f32x4{lo2[0], lo2[1], hi3[0], hi3[1]};
-                            sk_p2 += 1024;
-                            asm volatile("" : "+v"(sk_p2));
-                        }
-                    }
-                }
                 if constexpr (RS) v[j] *= rsv[a * 4 + i];
                 if constexpr (EPI == 3 || EPI == 4) {
 #pragma unroll
@@ -800,16 +695,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
         for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(tpre[0][k]), "v"(tpre[1][k]));
     }
     if (g == 0) __builtin_amdgcn_s_barrier();                          // balances group 1's extra barrier
-    if constexpr (STK) {
-        if (sk_cur <= sk_lo) break;
-        PP_VMWAIT(0);                                                  // (stream-K segments do not overlap the next prologue with the epilogue)
-        sk_segment();
-        set_soA(m0);
-        set_soB(n0);
-        issue_prologue();
-        PP_VMWAIT(8);
-        continue;
-    }
     if (!has_next) break;
     // the new tile's V0(0), V1(0) have landed = everything but the newest 8 staging pieces AND the stores issued behind them (loads and stores
     // retire in issue order through vmcnt on gfx9; the counter has 6 bits).  Full bf16 tiles: 16 stores per wave (+ 8 of m in the gated forward);
@@ -831,24 +716,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #undef PP_FENCE
 }
 
-template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false, bool RS = false, bool STK = false>
+template <typename TO, bool NN, int EPI, int ACT = 0, bool SK = false, bool LEAN = false, bool RS = false>
 int launch_pp_t(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st, float* stk_ws = nullptr, unsigned* stk_flags = nullptr) {
+                int splits, int kt_per_split, int64_t slab_stride, PPEpi ep, hipStream_t st) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     int gx = tiles_m * tiles_n;
-    if constexpr (STK) gx = lrp_num_cus() / 8 * 8;                     // one workgroup per CU, whole XCD groups
 #if PP_PERSIST
-    if (!STK && splits == 1) {
+    if (splits == 1) {
         const int ncu = lrp_num_cus();
         if (gx > ncu) gx = ncu;
     }
 #endif
     dim3 grid(gx, splits), block(512);
     const size_t lds = 4 * (size_t)PP_OPND;
-    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS, STK>;
+    auto kern = gemm_pp_kernel<TO, NN, EPI, ACT, SK, LEAN, RS>;
     LRP_SET_MAX_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, st, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, (const bf16_t*)bias, M, N, K, lda,
-                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep, stk_ws, stk_flags);
+                       ldb, ldc, tiles_m, tiles_n, kt_per_split, slab_stride, ep);
     return lrp_check_launch();
 }
 
@@ -874,14 +758,6 @@ int lrp_launch_gemm_pp(const void* A, const void* B, void* C, const void* bias, 
     }
     if (nn) return launch_pp_t<bf16_t, true, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
     return launch_pp_t<bf16_t, false, 0>(A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kt_per_split, slab_stride, ep, st);
-}
-
-// stream-K launch of the plain product (bf16 out; + bias): ws = one 256 KiB fp32 slot per workgroup, flags = one zero word per workgroup
-int lrp_launch_gemm_pp_streamk(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, int64_t lda, int64_t ldb,
-                               int64_t ldc, int nn, void* ws, void* flags, hipStream_t st) {
-    const PPEpi ep{};
-    if (nn) return launch_pp_t<bf16_t, true, 0, 0, false, false, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, 1, K / PP_KT, 0, ep, st, (float*)ws, (unsigned*)flags);
-    return launch_pp_t<bf16_t, false, 0, 0, false, false, false, true>(A, B, C, bias, M, N, K, lda, ldb, ldc, 1, K / PP_KT, 0, ep, st, (float*)ws, (unsigned*)flags);
 }
 
 // gate/up forward with the gated rule in the epilogue: m[M, I] = act(g) (*) u and the backward's coefficient stash coef[M, 2 I] (accumulator order,

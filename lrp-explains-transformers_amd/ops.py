@@ -252,37 +252,6 @@ def tickets(n, ref):
     return t
 
 
-STREAMK = True           # module attribute (A/B measurements): False = the round-4 handling (tail split / split-K slabs + reduce / partial last round)
-_SKF = {}
-
-
-def streamk_ok(a, b, nn=False):
-    M, K = a.shape
-    N = b.shape[1] if nn else b.shape[0]
-    return bool(STREAMK and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(1) == 1 and b.stride(1) == 1
-                and lib.lrp_gemm_streamk_ok(M, N, K, a.stride(0), b.stride(0), int(nn), _DT[a.dtype]))
-
-
-def gemm_streamk(a, b, out, nn=False, bias=None):
-    """out[M,N] = a @ b^T (nn=False) / a @ b (nn=True) as ONE stream-K launch of the ping-pong GEMM (lrp_gemm_streamk): every CU gets an equal share
-    of the K-tile iterations, split tiles are summed in a fixed order from partials parked in a stream-local workspace"""
-    M, K = a.shape
-    N = b.shape[1] if nn else b.shape[0]
-    same(a, b, out)
-    ws = workspace(lib.lrp_gemm_streamk_ws(), a)
-    if torch.cuda.is_current_stream_capturing():
-        fl = torch.zeros(int(lib.lrp_gemm_streamk_flags()), device=a.device, dtype=torch.int32)
-    else:
-        key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
-        fl = _SKF.get(key)
-        if fl is None:
-            fl = _SKF[key] = torch.zeros(int(lib.lrp_gemm_streamk_flags()), device=a.device, dtype=torch.int32)
-    _timed(2.0 * M * N * K, "streamk", lambda: lib.lrp_gemm_streamk(a.data_ptr(), b.data_ptr(), out.data_ptr(), p(aux(bias, a, N)), M, N, K, a.stride(0),
-                                                                    b.stride(0), out.stride(0), int(nn), dt(a), ws.data_ptr(), fl.data_ptr(), stream()),
-           "lrp_gemm_streamk")
-    return out
-
-
 def gemm_skinny(a, b, out, nn=False, bias=None):
     """out[M,N] = a[M,K] @ b[N,K]^T (nn=False) or a[M,K] @ b[K,N] (nn=True) for M <= 256 rows: split-K over the CUs, the weight
     streamed exactly once; fp32 partial slabs in a stream-local workspace.  The library addresses the activation through ONE 32-bit buffer
@@ -918,8 +887,6 @@ def linear_fwd(x2, W, bias=None, out=None, out_dtype=None):
     odt = out_dtype or (out.dtype if out is not None else x2.dtype)
     if M <= SKINNY_MAX and linear_stream_ok(x2, W) and (out is None or (out.stride(1) == 1 and out.dtype in _DT)):
         return linear_stream_fwd(x2, W, bias, out=out, out_dtype=odt)
-    if M > SKINNY_MAX and odt == torch.bfloat16 and streamk_ok(x2, W) and (out is None or (out.stride(1) == 1 and out.dtype == torch.bfloat16)):
-        return gemm_streamk(x2, W, torch.empty(M, N, device=x2.device, dtype=odt) if out is None else out, nn=False, bias=bias)
     if gemm_nn_ok(x2, W) and M > SKINNY_MAX:
         main = tail_split_cols(M, N, K)
         if main is not None and (out is None or out.stride(1) == 1):
@@ -998,9 +965,6 @@ def linear_dgrad(s2, W, out=None, out_dtype=None):
     nn = gemm_nn_ok(s2, W)
     if (M <= 2 or (M <= SMALLM_MAX and not nn)) and N >= 16 and smallm_ok(M, W) and s2.stride(1) == 1 and s2.dtype == W.dtype:
         return linear_smallm_dgrad(s2, W, out=out, out_dtype=odt)
-    if nn and M > SKINNY_MAX and odt == torch.bfloat16 and streamk_ok(s2, W, nn=True) and W.data_ptr() % 16 == 0 \
-            and (out is None or (out.stride(1) == 1 and out.dtype == torch.bfloat16)):
-        return gemm_streamk(s2, W, torch.empty(M, K, device=s2.device, dtype=odt) if out is None else out, nn=True)
     if nn and M > SKINNY_MAX:
         main = tail_split_cols(M, K, N)
         if main is not None and (out is None or out.stride(1) == 1) and W.data_ptr() % 16 == 0:

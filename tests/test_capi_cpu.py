@@ -51,13 +51,6 @@ def test_round5_host_side_queries_and_layout_rules():
     # dQ with D (and RoPE's backward): the bf16 32x32 kernels of head dims 64 / 96 / 128
     assert [lib.lrp_attn_bwd_dq_d_ok(BF16, d) for d in (64, 96, 128, 256, 32)] == [1, 1, 1, 0, 0] and lib.lrp_attn_bwd_dq_d_ok(F32, 128) == 0
     assert lib.lrp_gqa_reduce_rope(None, None, 8, 8, 2, 2, 64, 256, 128, None, None, BF16, None) == -1
-    # stream-K: more than 256 rows, K % 128 == 0, tile count off the CU grid with >= 8 % of the last round wasted, >= half a tile per workgroup
-    assert lib.lrp_gemm_streamk_ok(2048, 6144, 4096, 4096, 4096, 0, BF16) == 1 and lib.lrp_gemm_streamk_ok(8192, 2560, 10240, 10304, 10304, 0, BF16) == 1
-    assert lib.lrp_gemm_streamk_ok(8192, 4096, 4096, 4096, 4096, 0, BF16) == 0 and lib.lrp_gemm_streamk_ok(256, 14336, 4096, 4096, 4096, 0, BF16) == 0
-    assert lib.lrp_gemm_streamk_ok(2048, 2048, 4096, 4096, 4096, 0, BF16) == 0                         # 64 tiles: shares under half a tile
-    assert lib.lrp_gemm_streamk_ok(2048, 6144, 4160, 4160, 4160, 0, BF16) == 0 and lib.lrp_gemm_streamk_ok(2048, 6144, 4096, 4096, 4096, 0, F32) == 0
-    assert lib.lrp_gemm_streamk_ws() == lib.lrp_gemm_streamk_flags() * 256 * 256 * 4 and lib.lrp_gemm_streamk_flags() % 8 == 0
-    assert lib.lrp_gemm_streamk(None, None, None, None, 2048, 6144, 4096, 4096, 4096, 6144, 0, BF16, None, None, None) == -1
     # RoPE in the QKV forward's epilogue: heads of 128, M and N multiples of 256, seq a multiple of 16
     assert lib.lrp_gemm_nt_rs_rope_ok(8192, 6144, 4096, 4096, 4224, 6144, 2048, 5120, 128, BF16) == 1
     assert lib.lrp_gemm_nt_rs_rope_ok(8192, 6144, 4096, 4096, 4224, 6144, 2048, 5120, 64, BF16) == 0

@@ -321,42 +321,6 @@ def test_gemm_skinny_single_split_and_big_n(ops):
     assert ops.splitk_ok(8192, 2560, 8192) and nmax(ops.linear_fwd(a, w)[:512], f64(a[:512]) @ f64(w).T) < TOL[torch.bfloat16]
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 6144, 4096), (2048, 4096, 1024), (2048, 28672, 512), (8192, 2560, 1024), (16384, 3456, 1152),
-                                   (2100, 4100, 768), (4096, 2560, 256)])
-def test_gemm_streamk(ops, M, N, K):
-    """lrp_gemm_streamk (round 6): tile counts that are no whole number of rounds of the 256 CUs -- 192, 128, 896, 320, 896 (ragged N), ragged both,
-    160 -- as ONE launch with equal K-iteration shares per CU; split tiles are summed from parked fp32 partials in a fixed order.  NT and NN forms,
-    with and without bias, against fp64 on the same bf16 operands and against the plain kernel to bf16 rounding; repeated launches on the same
-    flags are bit-identical (the reducer re-arms them; the summation order does not depend on arrival)."""
-    g_ = torch.Generator().manual_seed(M + N + K)
-    bf = torch.bfloat16
-    a = torch.randn(M, K, generator=g_).to(bf).cuda()
-    w = (torch.randn(N, K, generator=g_) * K ** -0.5).to(bf).cuda()
-    wn = (torch.randn(K, N, generator=g_) * K ** -0.5).to(bf).cuda()
-    bias = torch.randn(N, generator=g_).to(bf).cuda()
-    assert ops.streamk_ok(a, w) and ops.streamk_ok(a, wn, nn=True)
-    assert not ops.streamk_ok(a[:200], w) and not ops.streamk_ok(torch.empty(8192, K, dtype=bf, device="cuda"), torch.empty(4096, K, dtype=bf, device="cuda"))
-    for nn, b_, bb in ((False, w, None), (False, w, bias), (True, wn, None)):
-        out = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
-        ops.gemm_streamk(a, b_, out, nn=nn, bias=bb)
-        ref = f64(a) @ (f64(b_) if nn else f64(b_).T) + (f64(bb) if bb is not None else 0.0)
-        assert not torch.isnan(out).any() and nmax(out, ref) < 1e-2
-        assert (out.double() - ref).abs().max() <= ref.abs().max() * 2.0 ** -7
-        for _ in range(3):
-            again = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
-            ops.gemm_streamk(a, b_, again, nn=nn, bias=bb)
-            assert torch.equal(again, out)
-    # through the dispatchers: the product path takes it for these shapes
-    keep = ops.STREAMK
-    try:
-        z1, c1 = ops.linear_fwd(a, w), ops.linear_dgrad(a, wn)
-        ops.STREAMK = False
-        z0, c0 = ops.linear_fwd(a, w), ops.linear_dgrad(a, wn)
-    finally:
-        ops.STREAMK = keep
-    assert nmax(z1, z0.double()) < 1e-2 and nmax(c1, c0.double()) < 1e-2
-
-
 def _act64(x, act):
     if act == "silu":
         return x * torch.sigmoid(x)
