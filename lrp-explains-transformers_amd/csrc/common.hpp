@@ -201,23 +201,6 @@ LRP_DEVICE void gated_coef(float g, float u, float eps_g, float eps_lin, float& 
         cu = hy * eps_ratio_t<true>(u, 1.f, eps_lin);
     }
 }
-// act(x) = x * s(x) for the two gated activations, s = a logistic function (SiLU: sigmoid(x); tanh-GELU: sigmoid(2 k0 (x + k1 x^3))): rcp / exp forms
-template <int ACT_CT> LRP_DEVICE float act_gate_factor(float x) {
-    if constexpr (ACT_CT == LRP_ACT_SILU) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
-    else {
-        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-        return __builtin_amdgcn_rcpf(1.f + __expf(-2.f * k0 * (x + k1 * x * x * x)));
-    }
-}
-// LEAN coefficients for |g| >= 2^-16 (the caller checks, wave-uniformly): y / (g + 1e-10) = s g / (g + 1e-10) = s (1 - O(1e-5)) -- below half a
-// bf16 ulp of the stored coefficient by a factor of 100 -- so the identity rule's division drops out: cg = 1/2 u s.  One v_rcp instead of two per
-// pair (the forward epilogue is transcendental-bound: ~6 us per tile for 128 pairs per lane at quarter rate).
-template <int ACT_CT> LRP_DEVICE void gated_coef_fast(float g, float u, float& m, float& cg, float& cu) {
-    const float sg = act_gate_factor<ACT_CT>(g), y = g * sg;
-    m = y * u;
-    cg = 0.5f * u * sg;
-    cu = 0.5f * y;
-}
 // the two bf16 halves of a 32-bit word as fp32 (one VALU each)
 LRP_DEVICE float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 LRP_DEVICE float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }

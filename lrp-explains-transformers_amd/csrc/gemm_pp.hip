@@ -575,38 +575,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                 // (common.hpp: gated_coef).  act(g) is evaluated ONCE per explanation; g and u themselves are never written.  Stash layout
                 // [M, 2 I] in ACCUMULATOR order: the 16 bytes {cg x 4 | cu x 4} of intermediate indices 4 t .. 4 t + 3 at columns 8 t .. 8 t + 7.
                 f32x4 mv[2], cgv[2], cuv[2];
-                bool exact = true;
-                if constexpr (LEAN) {
-                    // lxt.efficient placement: unless one of the wave's gate values of this row block is within 2^-16 of zero (once in ~1e4 blocks)
-                    // the stabilised division y / (g + 1e-10) equals the activation's logistic factor to 1e-5 -- far below the bf16 rounding of
-                    // the stored coefficient -- and costs nothing (common.hpp: gated_coef_fast); the exact form stays for those blocks
-                    bool tiny = false;
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tiny |= fabsf(v[jj][e]) < 1.52587890625e-5f;
-                    exact = __builtin_amdgcn_ballot_w64(tiny) != 0;
-                    if (!exact) {
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float m_, cg_, cu_;
-                                gated_coef_fast<ACT>(v[jj][e], v[jj + 2][e], m_, cg_, cu_);
-                                mv[jj][e] = m_; cgv[jj][e] = cg_; cuv[jj][e] = cu_;
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        float m_, cg_, cu_;
+                        gated_coef<LEAN, ACT>(v[jj][e], v[jj + 2][e], ep.eps_g, ep.eps_lin, m_, cg_, cu_);
+                        mv[jj][e] = m_; cgv[jj][e] = cg_; cuv[jj][e] = cu_;
                     }
-                }
-                if (exact) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float m_, cg_, cu_;
-                            gated_coef<LEAN, ACT>(v[jj][e], v[jj + 2][e], ep.eps_g, ep.eps_lin, m_, cg_, cu_);
-                            mv[jj][e] = m_; cgv[jj][e] = cg_; cuv[jj][e] = cu_;
-                        }
-                }
                 const int mcol = ncol / 2;                               // first intermediate index of this wave's block
                 if (full) {
 #pragma unroll
