@@ -279,7 +279,9 @@ int lrp_gemm_gated_bwd_coef(const void* Adn, const void* Wdn, const void* coef, 
  * --------------------------------------------------------------------------------------- */
 int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t ldb, int nn, int dtype);
 int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx, int64_t ldw,
-                     int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream);
+                     int64_t ldres, int64_t ldout, int64_t ldssq, void* raw, int64_t ldraw, int dtype, void* stream);
+                     /* raw (may be NULL; round 6): bf16 [M, N], row pitch ldraw -- the Linear's own output x W^T is stored as well: the lxt.explicit
+                        placement divides by it in the backward (stabilisers z / (z + eps) of lxt/explicit/functional.py:355-364,430-459) */
 int lrp_rms_rstd(const float* ssq, int parts, int64_t ldssq, int M, int H, float eps, float* rstd, void* stream);
 int lrp_gemm_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldout,
                    int dtype, void* stream);

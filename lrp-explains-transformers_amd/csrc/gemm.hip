@@ -22,7 +22,7 @@ int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* c
                                  int64_t ldw, int64_t ldcoef, int64_t ldagu, hipStream_t st);
 
 int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
-                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st);
+                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, void* raw, int64_t ldraw, hipStream_t st);
 int lrp_launch_gemm_pp_nt_rs(const void* x, const void* W, const float* rs, void* out, int M, int N, int K, int64_t ldx, int64_t ldw,
                              int64_t ldout, hipStream_t st);
 int lrp_launch_gemm_pp_nn_rs(const void* s, const void* W, const float* rs, void* out, int M, int N, int K, int64_t lds_, int64_t ldw,
@@ -650,16 +650,16 @@ extern "C" int lrp_gemm_norm_fused_ok(int M, int N, int K, int64_t lda, int64_t 
 }
 
 extern "C" int lrp_gemm_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
-                                int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, int dtype, void* stream) {
+                                int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, void* raw, int64_t ldraw, int dtype, void* stream) {
     if (!x || !W || !res || !out || !ssq || M < 0 || N < 0 || K < 0 || ldssq < M) return LRP_EINVAL;
     if (M == 0 || N == 0) return LRP_OK;
     if (!lrp_gemm_norm_fused_ok(M, N, K, ldx, ldw, 0, dtype)) return LRP_ESHAPE;
-    if (!a16(x) || !a16(W) || (ldout % 8) || (ldres % 8)) return LRP_EALIGN;
+    if (!a16(x) || !a16(W) || (ldout % 8) || (ldres % 8) || (raw && (!a16(raw) || (ldraw % 8)))) return LRP_EALIGN;
     const int chunk = pp_row_chunk(ldx);
     for (int m0 = 0; m0 < M; m0 += chunk) {
         const int rc = lrp_launch_gemm_pp_res_ssq((const char*)x + (int64_t)m0 * ldx * 2, W, (const char*)res + (int64_t)m0 * ldres * 2,
                                                   (char*)out + (int64_t)m0 * ldout * 2, ssq + m0, M - m0 < chunk ? M - m0 : chunk, N, K, ldx, ldw,
-                                                  ldres, ldout, ldssq, (hipStream_t)stream);
+                                                  ldres, ldout, ldssq, raw ? (char*)raw + (int64_t)m0 * ldraw * 2 : nullptr, ldraw, (hipStream_t)stream);
         if (rc != LRP_OK) return rc;
     }
     return LRP_OK;

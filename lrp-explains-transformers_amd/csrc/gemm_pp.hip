@@ -470,6 +470,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
                     const f32x4 r1 = {(float)b0[0], (float)b0[1], (float)b1[0], (float)b1[1]};
                     f32x4 v0 = acc[b >> 2][b & 3][2 * jj], v1 = acc[b >> 2][b & 3][2 * jj + 1];
                     if constexpr (RS) { v0 *= rsv[b]; v1 *= rsv[b]; }
+                    if constexpr (EPI == 3) {
+                        // lxt.explicit placement: the Linear's own output z = x W^T is kept as well (its stabiliser z / (z + eps) and the add2
+                        // rule's h / (h + eps) both need their operand; ref lxt/explicit/functional.py:355-364,430-459) -- one more 16-byte store per half block
+                        if (ep.c2 != nullptr) {
+                            bf16x2 p0 = {(bf16_t)v0[0], (bf16_t)v0[1]}, p1 = {(bf16_t)v0[2], (bf16_t)v0[3]};
+                            bf16x2 q0 = {(bf16_t)v1[0], (bf16_t)v1[1]}, q1 = {(bf16_t)v1[2], (bf16_t)v1[3]};
+                            auto w0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, q0), false, false);
+                            auto w1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, p1), __builtin_bit_cast(uint32_t, q1), false, false);
+                            *reinterpret_cast<u32x4*>(ep.c2 + (int64_t)(mrow + (b >> 2) * 64 + (b & 3) * 16) * ep.ldc2 + ncol + epoff + 32 * jj) =
+                                u32x4{w0[0], w1[0], w0[1], w1[1]};
+                        }
+                    }
                     v0 += r0; v1 += r1;
                     bf16x2 x0 = {(bf16_t)v0[0], (bf16_t)v0[1]}, x1 = {(bf16_t)v0[2], (bf16_t)v0[3]};
                     bf16x2 y0 = {(bf16_t)v1[0], (bf16_t)v1[1]}, y1 = {(bf16_t)v1[2], (bf16_t)v1[3]};
@@ -556,7 +568,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int gn = ncol + j * 16 + 4 * hi + e;
-                        if (gm < M && gn < N) v[j][e] += to_f32(ep.res[(int64_t)gm * ep.ldres + gn]);
+                        if (gm < M && gn < N) {
+                            if constexpr (EPI == 3) { if (ep.c2 != nullptr) ep.c2[(int64_t)gm * ep.ldc2 + gn] = (bf16_t)v[j][e]; }
+                            v[j][e] += to_f32(ep.res[(int64_t)gm * ep.ldres + gn]);
+                        }
                     }
                 }
                 if (bias) {
@@ -797,9 +812,9 @@ int lrp_launch_gemm_pp_gated_bwd(const void* Adn, const void* Wdn, const void* c
 // ---- RMSNorm folded into the GEMMs around it (round 5; include/lrp_hip.h "K1n").  Same kernel, three more epilogue forms.
 // out = res + x W^T (NT) and the partial sums of squares of out's rows, one per 64-column block: ssq [N / 64][ldssq]
 int lrp_launch_gemm_pp_res_ssq(const void* x, const void* W, const void* res, void* out, float* ssq, int M, int N, int K, int64_t ldx,
-                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, hipStream_t st) {
+                               int64_t ldw, int64_t ldres, int64_t ldout, int64_t ldssq, void* raw, int64_t ldraw, hipStream_t st) {
     PPEpi ep{};
-    ep.res = (const bf16_t*)res; ep.ldres = ldres; ep.ssq = ssq; ep.ldssq = ldssq;
+    ep.res = (const bf16_t*)res; ep.ldres = ldres; ep.ssq = ssq; ep.ldssq = ldssq; ep.c2 = (bf16_t*)raw; ep.ldc2 = ldraw;
     return launch_pp_t<bf16_t, false, 3>(x, W, out, nullptr, M, N, K, ldx, ldw, ldout, 1, K / PP_KT, 0, ep, st);
 }
 // out = rs (.) (x W^T) (NT), rs [M] fp32

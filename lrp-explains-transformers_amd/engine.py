@@ -254,10 +254,11 @@ class LlamaLRP:
             self._nf_cache[key] = hit
         return hit
 
-    def _norm_fused(self, M):
+    def _norm_fused(self, M, fwd_only=False):
         """K1n applies: folded norm weights, efficient placement (no stabiliser on the residual add / the Linears: eps = 0), and every GEMM on
-        both sides of the two norms is a problem the ping-pong kernel's fused epilogues take (bf16, >= 190 tiles, N % 256 == 0)"""
-        if not (self.folded and self.mode == "efficient" and ops.NORM_FUSION):
+        both sides of the two norms is a problem the ping-pong kernel's fused epilogues take (bf16, >= 190 tiles, N % 256 == 0).  fwd_only: the
+        FORWARD half is the same computation under both placements (the explicit one additionally keeps each Linear's own output: round 6)"""
+        if not (self.folded and ops.NORM_FUSION and (self.mode == "efficient" or fwd_only)):
             return False
         key = ("nf", M, PITCH_PAD, repr(ops.NORM_FUSION), ops.GATED_FUSION)
         hit = self._nf_cache.get(key)
@@ -352,7 +353,8 @@ class LlamaLRP:
         h_prev, branch = emb, None
         last = torch.arange(B, device=dev) * S + (S - 1)
         coef = self._gated_coef(M)
-        nf = self._norm_fused(M) and ops.norm_fusion_part("fwd")          # K1n: the two norms + residual sums of a layer inside the GEMM epilogues around them
+        explicit = self.mode == "explicit"
+        nf = self._norm_fused(M, fwd_only=True) and ops.norm_fusion_part("fwd")          # K1n: the two norms + residual sums of a layer inside the GEMM epilogues around them
         ready = None                      # (h, rstd1) of this layer, left by the previous layer's down-projection epilogue
         nL = len(self.layers)
         for li, Lw in enumerate(self.layers):
@@ -363,7 +365,7 @@ class LlamaLRP:
                 st["h"], st["rstd1"] = ready
                 ready = None
                 qkv = new(("qkv", li), M, nqkv)
-                if S <= self.max_seq and ops.gemm_nt_rs_rope_ok(st["h"], Lw["wqkv"], qkv, S, nqk, d):
+                if not explicit and S <= self.max_seq and ops.gemm_nt_rs_rope_ok(st["h"], Lw["wqkv"], qkv, S, nqk, d):
                     # RoPE in the QKV GEMM's epilogue: q and k leave the kernel rotated (no rope_fwd pass, no second copy of q / k)
                     ops.gemm_nt_rs_rope(st["h"], Lw["wqkv"], st["rstd1"], self.cos, self.sin, qkv, S, nqk, d)
                     rotated = True
@@ -401,15 +403,17 @@ class LlamaLRP:
                 # rows by rstd2; the down projection leaves the next layer's input sum and ITS statistics the same way (the last layer's keeps
                 # the stand-alone form: the tail below wants h1 and dn of the explained rows separately)
                 h1, ssq = new(("h1", li), M, H), ar.get("ssq", (H // 64, M), torch.float32)
-                ops.gemm_res_ssq(o, Lw["wo"], st["h"], h1, ssq)
+                a_raw = new(("a", li), M, H) if explicit else None      # explicit placement: the o-projection's own output (its stabiliser divides by it)
+                ops.gemm_res_ssq(o, Lw["wo"], st["h"], h1, ssq, raw=a_raw)
                 st["rstd2"] = ops.rms_rstd(ssq, M, H, c["rms_eps"], f32(("rstd2", li), M))
                 gu, m = ops.gemm_gated_fwd_coef(h1, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.eps_g, self.eps["lin"], self.act,
                                                 rs=st["rstd2"])
-                st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=None, h1=h1, gu=gu, coef=True, dn=None)
+                st.update(qkv=qkv, qkr=qkr, o=o, lse=lse, a=a_raw, h1=h1, gu=gu, coef=True, dn=None)
                 stash.append(st)
                 if li + 1 < nL:
                     hn = new(("h", li + 1), M, H)
-                    ops.gemm_res_ssq(m, Lw["wd"], h1, hn, ssq)
+                    st["dn"] = new(("dn", li), M, H) if explicit else None
+                    ops.gemm_res_ssq(m, Lw["wd"], h1, hn, ssq, raw=st["dn"])
                     ready = (hn, ops.rms_rstd(ssq, M, H, c["rms_eps"], f32(("rstd1", li + 1), M)))
                     h_prev, branch = hn, None
                 else:

@@ -559,7 +559,7 @@ def const_rows(M, value, device):
     return t
 
 
-def gemm_res_ssq(x, W, res, out, ssq):
+def gemm_res_ssq(x, W, res, out, ssq, raw=None):
     """out = res + x @ W^T (bf16 rounding once) and ssq[p, m] = sum of out[m, 64 p : 64 p + 64]^2 -- the residual add and RMSNorm's sum of
     squares in the producing GEMM's epilogue; ssq [N / 64, >= M] fp32"""
     M, K = x.shape
@@ -567,8 +567,11 @@ def gemm_res_ssq(x, W, res, out, ssq):
     same(x, W, res, out)
     f32(ssq)
     assert ssq.shape[0] * 64 == N and ssq.stride(0) >= M and ssq.stride(1) == 1
+    if raw is not None:      # the explicit placement keeps the Linear's own output too (its stabiliser divides by it)
+        same(x, raw)
     _timed(2.0 * M * N * K, "plain_norm", lambda: lib.lrp_gemm_res_ssq(p(x), p(W), p(res), p(out), p(ssq), M, N, K, x.stride(0), W.stride(0),
-                                                                       res.stride(0), out.stride(0), ssq.stride(0), dt(x), stream()), "lrp_gemm_res_ssq")
+                                                                       res.stride(0), out.stride(0), ssq.stride(0), p(raw),
+                                                                       raw.stride(0) if raw is not None else 0, dt(x), stream()), "lrp_gemm_res_ssq")
     return out
 
 

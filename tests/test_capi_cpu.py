@@ -39,7 +39,7 @@ def test_round5_host_side_queries_and_layout_rules():
     assert lib.lrp_gemm_norm_fused_ok(8192, 4096 + 64, 4096, 4096, 4096, 0, BF16) == 0          # N % 256
     assert lib.lrp_gemm_norm_fused_ok(2048, 4096, 4096, 4096, 4096, 0, BF16) == 0               # 128 tiles
     assert lib.lrp_gemm_norm_fused_ok(8192, 4096, 4096, 4096, 4096, 0, F32) == 0
-    assert lib.lrp_gemm_res_ssq(None, None, None, None, None, 8, 256, 128, 128, 128, 256, 256, 8, BF16, None) == -1
+    assert lib.lrp_gemm_res_ssq(None, None, None, None, None, 8, 256, 128, 128, 128, 256, 256, 8, None, 0, BF16, None) == -1
     assert lib.lrp_rms_rstd(None, 4, 8, 8, 256, 1e-5, None, None) == -1
     # stream forward: wide weights run full K (1 split), narrow ones 2 ... 8 splits with whole 8-tile rings; ws = splits * M * N * 4 bytes
     assert lib.lrp_linear_stream_fwd_splits(4, 14336, 4096) == 1 and lib.lrp_linear_stream_fwd_ws(4, 14336, 4096) == 0

@@ -484,6 +484,11 @@ def test_gemm_norm_fused_epilogues(ops, M, H, K, I):
     assert (out.double() - ref).abs().max() <= (ref.abs().max() * 2.0 ** -8)          # one bf16 rounding of the fp32 sum
     ssq_ref = (out.double() ** 2).view(M, H // 64, 64).sum(-1).T                       # from the STORED rows: exact up to fp32 summation
     assert torch.allclose(ssq.double(), ssq_ref, rtol=1e-5, atol=1e-6)
+    # the explicit placement's form: the Linear's own output is kept beside the sum (its stabiliser divides by it); everything else unchanged
+    out_x, ssq_x, raw = torch.empty_like(out), torch.empty_like(ssq), torch.full((M, H), float("nan"), dtype=bf, device="cuda")
+    ops.gemm_res_ssq(x, W, res, out_x, ssq_x, raw=raw)
+    assert torch.equal(out_x, out) and torch.equal(ssq_x, ssq) and not torch.isnan(raw).any()
+    assert nmax(raw, f64(x) @ f64(W).T) < 1e-2 and torch.equal(raw, ops.linear_fwd(x, W))
     eps = 1e-5
     rstd = ops.rms_rstd(ssq, M, H, eps, torch.empty(M, dtype=torch.float32, device="cuda"))
     rstd_ref = torch.rsqrt((out.double() ** 2).mean(-1) + eps)

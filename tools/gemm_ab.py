@@ -42,7 +42,8 @@ class Lib:
         L.lrp_gemm_nn.argtypes = [VP] * 4 + [I32] * 3 + [I64] * 3 + [I32, I32, VP]
         L.lrp_gemm_nt_rs.argtypes = [VP] * 4 + [I32] * 3 + [I64] * 3 + [I32, VP]
         L.lrp_gemm_nn_rs.argtypes = [VP] * 4 + [I32] * 3 + [I64] * 3 + [I32, VP]
-        L.lrp_gemm_res_ssq.argtypes = [VP] * 5 + [I32] * 3 + [I64] * 5 + [I32, VP]
+        self.v7 = L.lrp_version() >= 7                # ABI 7: lrp_gemm_res_ssq takes (raw, ldraw) ahead of dtype
+        L.lrp_gemm_res_ssq.argtypes = [VP] * 5 + [I32] * 3 + [I64] * 5 + ([VP, I64] if self.v7 else []) + [I32, VP]
         L.lrp_gemm_nn_rs_res.argtypes = [VP] * 5 + [I32] * 3 + [I64] * 4 + [I32, VP]
 
     def run(self, kind, a, w, out, rs, res, ssq):
@@ -60,7 +61,8 @@ class Lib:
         elif kind == "nn_rs":
             rc = L.lrp_gemm_nn_rs(p(a), p(w), p(rs), p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), 1, st)
         elif kind == "res_ssq":
-            rc = L.lrp_gemm_res_ssq(p(a), p(w), p(res), p(out), p(ssq), M, N, K, a.stride(0), w.stride(0), res.stride(0), out.stride(0), ssq.stride(0), 1, st)
+            rc = L.lrp_gemm_res_ssq(p(a), p(w), p(res), p(out), p(ssq), M, N, K, a.stride(0), w.stride(0), res.stride(0), out.stride(0), ssq.stride(0),
+                                    *((None, 0) if self.v7 else ()), 1, st)
         else:
             rc = L.lrp_gemm_nn_rs_res(p(a), p(w), p(rs), p(res), p(out), M, N, K, a.stride(0), w.stride(0), res.stride(0), out.stride(0), 1, st)
         assert rc == 0, (kind, rc)
