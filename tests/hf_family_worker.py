@@ -215,7 +215,7 @@ def bert_explicit_padded():
         print(f"[bert-base explicit padded batch, row {b}, length {L}] token vs oracle fp64 {err:.2e} (the reference's own fp32 on this prompt "
               f"{fx['gap']:.1e}) logit {float(sel[b]):+.6f} vs oracle {o64['logit']:+.6f}")
         ok = ok and int(idx[b]) == fx["idx"] and nmax(o64["R_tok"], fx["R_tok"]) < 1e-9
-        ok = ok and abs(float(sel[b]) - o64["logit"]) < 1e-4 and err < ref_bar(fx["gap"], prompt_set="bert_explicit_prompts.npz")
+        ok = ok and abs(float(sel[b]) - o64["logit"]) < 1e-4 and err < ref_bar(fx["gap"], factor=10.0)
         worst = max(worst, err)
     print(f"WORST {worst:.3e}")
     return 0 if ok else 1

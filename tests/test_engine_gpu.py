@@ -75,7 +75,7 @@ def test_llama_bf16_norm_folded_into_gemms(eng_mod):
         assert eng.folded and eng._norm_fused(B * S) and not eng._norm_fused(S // 2)
         assert all(bool((Lw["ln1"] == 1).all()) and bool((Lw["ln2"] == 1).all()) for Lw in eng.layers)
         keep = ops.NORM_FUSION
-        ops.NORM_FUSION = True                                   # every part, also the gate/up dgrad epilogue the default leaves out
+        ops.NORM_FUSION = True                                   # (the default: every part)
         try:
             fused = eng.explain(ids, target=tgt)
             ops.NORM_FUSION = False
@@ -85,10 +85,13 @@ def test_llama_bf16_norm_folded_into_gemms(eng_mod):
         e_f, e_p = nmax(fused["R_tok"], ref["R_tok"]), nmax(plain["R_tok"], ref["R_tok"])
         d_fp = nmax(fused["R_tok"], plain["R_tok"])
         print(f"[K1n sparse_top={sparse_top}] vs the fp32 engine: fused {e_f:.2e}, stand-alone {e_p:.2e}; fused vs stand-alone {d_fp:.2e}")
-        assert torch.isfinite(fused["R_tok"]).all() and e_f < 5e-2 and e_p < 5e-2 and d_fp < 5e-2
+        # one prompt set of one instance (B = 3): a few bf16 ulps of the largest token relevance; which flow is the more accurate one is a
+        # statement over many prompts (tools/k1n_error_parts.py, profiles/r06_fused_flow_error_parts.txt: the fused one) and is anchored on the
+        # oracle at full width in test_baseline_size_gpu.py::test_engine_bf16_full_width_batched_fused_vs_oracle
+        assert torch.isfinite(fused["R_tok"]).all() and e_f < 2e-2 and e_p < 2e-2 and d_fp < 1.5e-2
         if sparse_top:
             fused = eng.explain(ids, target=tgt)                 # the default parts
-            assert nmax(fused["R_tok"], ref["R_tok"]) < 5e-2
+            assert nmax(fused["R_tok"], ref["R_tok"]) < 2e-2
             again = eng.explain(ids, target=tgt, graph=True)
             again = eng.explain(ids, target=tgt, graph=True)
             assert torch.equal(again["R_tok"], fused["R_tok"])
