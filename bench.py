@@ -122,7 +122,7 @@ def _sha16(path):
 
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE; tools/r4_traffic.py -> profiles/r0N_gemm_traffic.json); PMC counters cannot be collected inside the timed run itself.
+    WRITE_SIZE; tools/traffic.py -> profiles/r0N_gemm_traffic.json); PMC counters cannot be collected inside the timed run itself.
     The JSON is stamped with the hash of the kernel source it was measured on (`gemm_pp_sha16`): the newest file whose stamp matches
     the gemm_pp.hip of THIS tree is used; a stale measurement is reported as null (+ `traffic_note`), never as a number."""
     import glob
@@ -681,7 +681,7 @@ def main():
                        "activation_policy": "stash: every Linear output z, q/k before and after RoPE, o, lse and the residual sums are kept in HBM "
                                             "by the forward (~0.3 GB per layer and prompt); the backward recomputes no GEMM (DESIGN.md section 3)",
                        "parallelism": f"dp{world} (prompt sharding, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<bf16, NT | NN, EPI 0 | 3 | 4> (8-wave ping-pong GEMM: Linear forward z = x W^T and "
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<bf16, NT | NN, EPI 0 | 3 | 4 | 5> (8-wave ping-pong GEMM: Linear forward z = x W^T and "
                                                     "eps-rule dgrad c = s W from the stored weight), 6 launches per layer"
                                                     + (f"; {n_norm} of the {n_launch} launches carry a K1n epilogue (RMSNorm's row scale / residual add / "
                                                        "row sums of squares: +67 MB per launch)" if n_norm else ""),

@@ -42,10 +42,13 @@ def add(tag, key, algb):
 keys = {classify(k): k for k in d if classify(k) is not None}
 R = 2 * M * 4096                                   # one [M, 4096] bf16 operand of an epilogue (residual / residual gradient)
 # one step of the 4-layer run (top layer: o-proj / MLP on one row per prompt; K1n parts fwd + bwd_qkv, the o-projection's dgrad with the 1/2 row
-# scale): layer 0's qkv forward is the plain kernel, layers 1-3 take the row-scale form; o-proj + down forward of layers 0-2 carry the residual +
+# scale): layer 0's qkv forward is the plain kernel, layers 1-3 take the row-scale + RoPE form; o-proj + down forward of layers 0-2 carry the residual +
 # sum-of-squares epilogue; qkv dgrad x 4 and gate/up dgrad x 3 the residual one; o dgrad x 3 NN + row scale
 add("nt_plain (qkv fwd, layer 0)", keys[(0, 0, 0, 0)], alg(6144, 4096))
-add("nt_rowscale (qkv fwd)", keys[(0, 0, 0, 1)], alg(6144, 4096))
+if (0, 5, 0, 1) in keys:                       # QKV forward + row scale + RoPE in the epilogue (cos/sin table: 1 MB, not counted)
+    add("nt_rowscale_rope (qkv fwd)", keys[(0, 5, 0, 1)], alg(6144, 4096))
+else:
+    add("nt_rowscale (qkv fwd)", keys[(0, 0, 0, 1)], alg(6144, 4096))
 add("nt_residual_ssq (o-proj, down fwd)", keys[(0, 3, 0, 0)], (alg(4096, 4096) + alg(4096, 14336)) / 2 + R)
 if (1, 0, 0, 0) in keys:                       # (gate/up dgrad as the plain kernel: ops.NORM_FUSION without "bwd_gu")
     add("nn_plain (gate/up dgrad)", keys[(1, 0, 0, 0)], alg(4096, 28672))
