@@ -201,7 +201,13 @@ def test_engine_bf16_full_width_batched_fused_vs_oracle(case):
     eng = E.LlamaLRP(CFG, case["W"], dtype=torch.bfloat16, mode="efficient", max_seq=S, sparse_top=False)
     M = ids.numel()
     assert eng._norm_fused(M) and eng._gated_coef(M) and ops.PREP_FUSION and ops.ROPE_BWD_FUSION
-    fused = eng.explain(ids, target=tgt)["R_tok"].double().cpu()
+    fused_dev = eng.explain(ids, target=tgt)["R_tok"].clone()
+    fused = fused_dev.double().cpu()
+    # the headline's row count since round 6 (8 prompts per step, M = 16384): the same four prompts twice in ONE call must reproduce the
+    # four-prompt call bit for bit (no kernel's per-row arithmetic depends on how many rows the launch carries)
+    both = eng.explain(torch.cat([ids, ids]), target=torch.cat([tgt, tgt]))["R_tok"]
+    assert both.shape[0] == 8 and torch.equal(both[:4], fused_dev) and torch.equal(both[4:], fused_dev)
+    del both
     keep = (ops.NORM_FUSION, ops.PREP_FUSION, ops.ROPE_BWD_FUSION, ops.GATED_FUSION)
     try:
         ops.NORM_FUSION, ops.PREP_FUSION, ops.ROPE_BWD_FUSION, ops.GATED_FUSION = False, False, False, False
