@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 8 (round 6, second step: + the Gemma-3 site kernels lrp_sandwich_norm_fwd / _bwd / _ok, lrp_qk_norm_rope_fwd, lrp_qkv_bwd_pack; nothing else changed).  Version 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -189,6 +189,34 @@ int lrp_rmsnorm_bwd_add2(const void* Gres, const void* Gx, const void* w, const 
                          const void* hsum, const void* branch, void* Gs_out, void* A_out,
                          float* rel_out, int M, int H, float w_offset, float eps_add,
                          float eps_lin, int dtype, void* stream);
+
+/* Gemma-3's row work fused per SITE (round 6, ABI 8; csrc/sandwich.hip).  Every entry reproduces the arithmetic of the launch sequence it
+ * replaces, including the roundings to the storage type where that sequence went through memory: bit-identical results.
+ *   lrp_sandwich_norm_fwd: a sub-layer output between its post-norm and the next pre-norm (HF Gemma3DecoderLayer: h1 = h + post_attention_layernorm(a),
+ *     x2 = pre_feedforward_layernorm(h1); likewise post_feedforward_layernorm / the next layer's input_layernorm; identity rules with detached
+ *     rstd, ref lxt/efficient/models/gemma3.py:11-19, lxt/efficient/patches.py:111-123):
+ *       hsum_out = res + T(w_post' (*) x rstd_post),  y = w_pre' (*) hsum_out rstd_pre   (w' = w + w_offset; y / w_pre may be NULL)
+ *     = lrp_add_rmsnorm_fwd(x, NULL, w_post) + lrp_add_rmsnorm_fwd(res, branch, w_pre) in one pass; the normed branch never goes to memory.
+ *     lrp_sandwich_norm_ok(H, dtype): the row fits the kernel's registers (H <= 8192 bf16 / 4096 fp32, H a multiple of 16 bytes).
+ *   lrp_sandwich_norm_bwd: Gs_out = T(Gres + Gx w_pre' rstd_pre) (gradient w.r.t. the residual sum; Gres may be NULL),
+ *     Ga_out = Gs_out w_post' rstd_post (gradient w.r.t. the sub-layer output)  = two lrp_rmsnorm_bwd_add2 launches.
+ *   lrp_qk_norm_rope_fwd: per-head q / k RMSNorm + RoPE on the fused projection output qkv [rows, >= (nq + nk) d] (HF Gemma3Attention q_norm /
+ *     k_norm / apply_rotary_pos_emb): qr [rows, nq d], kr [rows, nk d], rstd_q [rows nq], rstd_k [rows nk]; cos / sin tables [seq, d] fp32,
+ *     position = row % seq  = 2 x lrp_head_rmsnorm_fwd + 2 x lrp_rope_fwd.
+ *   lrp_qkv_bwd_pack: the qkv dgrad's operand A [rows, (nq + 2 nk) d] in one pass: q part = rope^T(dq) (*) wq' rstd_q, k part = rope^T(sum of the
+ *     group's query heads of dk_h [rows, nq d]) (*) wk' rstd_k, v part = the group sum of dv_h   = 2 x lrp_gqa_reduce + 2 x lrp_rope_bwd (eps = 0) +
+ *     2 x lrp_head_rmsnorm_bwd.  d sizeof(T) / 16 a power of two in 2 .. 64. */
+int lrp_sandwich_norm_ok(int H, int dtype);
+int lrp_sandwich_norm_fwd(const void* x, const void* res, const void* w_post, const void* w_pre, void* hsum_out, void* y,
+                          float* rstd_post, float* rstd_pre, int M, int H, float eps, float w_offset, int dtype, void* stream);
+int lrp_sandwich_norm_bwd(const void* Gres, const void* Gx, const void* w_pre, const float* rstd_pre, const void* w_post,
+                          const float* rstd_post, void* Gs_out, void* Ga_out, int M, int H, float w_offset, int dtype, void* stream);
+int lrp_qk_norm_rope_fwd(const void* qkv, const void* wq, const void* wk, void* qr, void* kr, float* rstd_q, float* rstd_k,
+                         const float* cos_t, const float* sin_t, int64_t rows, int seq, int nq, int nk, int d, int64_t ldqkv,
+                         int64_t ldq, int64_t ldk, float eps, float w_offset, int dtype, void* stream);
+int lrp_qkv_bwd_pack(const void* dq, const void* dk_h, const void* dv_h, const void* wq, const void* wk, const float* rstd_q,
+                     const float* rstd_k, const float* cos_t, const float* sin_t, void* A, int64_t rows, int seq, int nq, int nk, int d,
+                     int64_t lddq, int64_t lddk, int64_t lddv, int64_t lda, float w_offset, int dtype, void* stream);
 
 /* K7 LayerNorm (BERT/GPT-2/ViT).  ref: lxt/efficient/patches.py:126-142,
  *   lxt/explicit/functional.py:606-635.   y = (x-mean)/std * w + b ; std detached.

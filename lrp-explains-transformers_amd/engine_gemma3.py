@@ -177,26 +177,35 @@ class Gemma3LRP:
         f32 = lambda tag, *s: ar.get(tag, s, torch.float32)  # noqa: E731
         eps = c["rms_eps"]
         stash = []
-        h_prev, branch = emb, None
+        h_prev, branch, nxt = emb, None, None
+        site = ops.sandwich_norm_ok(emb)      # Gemma-3's norms / q-k norm / RoPE fused per site (ops.SITE_FUSION; results bit-identical)
         for li, Lw in enumerate(self.layers):
             st = {}
             cos, sin = self.rope[c["layer_types"][li]]
-            # input norm (fused with the previous layer's residual add: h = h1_prev + post_ff_norm(dn_prev))
-            x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
-            if branch is None:
-                h = h_prev
-                ops.add_rmsnorm_fwd(h_prev, None, Lw["ln_in"], eps, 1.0, y=x, rstd=st["rstd1"])
+            # input norm (fused with the previous layer's residual add: h = h1_prev + post_ff_norm(dn_prev); with the site kernels the previous
+            # layer's tail has produced h, x and rstd1 already)
+            if nxt is not None:
+                h, x, st["rstd1"] = nxt
             else:
-                h = new(("h", li & 1), M, H)
-                ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln_in"], eps, 1.0, hsum_out=h, y=x, rstd=st["rstd1"])
+                x, st["rstd1"] = new("x", M, H), f32(("rstd1", li), M)
+                if branch is None:
+                    h = h_prev
+                    ops.add_rmsnorm_fwd(h_prev, None, Lw["ln_in"], eps, 1.0, y=x, rstd=st["rstd1"])
+                else:
+                    h = new(("h", li & 1), M, H)
+                    ops.add_rmsnorm_fwd(h_prev, branch, Lw["ln_in"], eps, 1.0, hsum_out=h, y=x, rstd=st["rstd1"])
             qkv = ops.linear_fwd(x, Lw["wqkv"], out=new(("qkv", li), M, nqkv))
             # per-head q / k norm straight out of the fused projection output (strided rows), then RoPE with this layer type's table
-            qn, st["rstd_q"] = new("qn", M, nqd), f32(("rstd_q", li), M * nq)
-            kn, st["rstd_k"] = new("kn", M, nkd), f32(("rstd_k", li), M * nk)
-            ops.head_rmsnorm_fwd(qkv[:, :nqd], Lw["qn"], qn, st["rstd_q"], nq, d, eps, 1.0)
-            ops.head_rmsnorm_fwd(qkv[:, nqd: nqd + nkd], Lw["kn"], kn, st["rstd_k"], nk, d, eps, 1.0)
-            qr = ops.rope_fwd(qn, new(("qr", li), M, nqd), cos, sin, S, nq, d)
-            kr = ops.rope_fwd(kn, new(("kr", li), M, nkd), cos, sin, S, nk, d)
+            st["rstd_q"], st["rstd_k"] = f32(("rstd_q", li), M * nq), f32(("rstd_k", li), M * nk)
+            if site:      # one pass: q / k norm + RoPE (bit-identical to the four launches below)
+                qr, kr = ops.qk_norm_rope_fwd(qkv, Lw["qn"], Lw["kn"], new(("qr", li), M, nqd), new(("kr", li), M, nkd), st["rstd_q"], st["rstd_k"],
+                                              cos, sin, S, nq, nk, d, eps, 1.0)
+            else:
+                qn, kn = new("qn", M, nqd), new("kn", M, nkd)
+                ops.head_rmsnorm_fwd(qkv[:, :nqd], Lw["qn"], qn, st["rstd_q"], nq, d, eps, 1.0)
+                ops.head_rmsnorm_fwd(qkv[:, nqd: nqd + nkd], Lw["kn"], kn, st["rstd_k"], nk, d, eps, 1.0)
+                qr = ops.rope_fwd(qn, new(("qr", li), M, nqd), cos, sin, S, nq, d)
+                kr = ops.rope_fwd(kn, new(("kr", li), M, nkd), cos, sin, S, nk, d)
             v = qkv[:, nqd + nkd:]
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o, lse = new(("o", li), M, nqd), f32(("lse", li), B, nq, S)
@@ -204,20 +213,31 @@ class Gemma3LRP:
             ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], causal, win, row_iv=iv)
             a = ops.linear_fwd(o, Lw["wo"], out=new("a", M, H))
             # post-attention norm, residual add, pre-feed-forward norm
-            pa, st["rstd_pa"] = new("pa", M, H), f32(("rstd_pa", li), M)
-            ops.add_rmsnorm_fwd(a, None, Lw["ln_pa"], eps, 1.0, y=pa, rstd=st["rstd_pa"])
+            st["rstd_pa"] = f32(("rstd_pa", li), M)
             h1, x2, st["rstd2"] = new(("h1", li & 1), M, H), new("x2", M, H), f32(("rstd2", li), M)
-            ops.add_rmsnorm_fwd(h, pa, Lw["ln_pf"], eps, 1.0, hsum_out=h1, y=x2, rstd=st["rstd2"])
+            if site:      # one pass (the normed branch never goes to memory)
+                ops.sandwich_norm_fwd(a, h, Lw["ln_pa"], Lw["ln_pf"], eps, 1.0, h1, x2, st["rstd_pa"], st["rstd2"])
+            else:
+                pa = new("pa", M, H)
+                ops.add_rmsnorm_fwd(a, None, Lw["ln_pa"], eps, 1.0, y=pa, rstd=st["rstd_pa"])
+                ops.add_rmsnorm_fwd(h, pa, Lw["ln_pf"], eps, 1.0, hsum_out=h1, y=x2, rstd=st["rstd2"])
             coef = ops.gated_coef_ok(M, I, H, H, Lw["wgu"].stride(0), H, Lw["wd"].stride(0), self.act, dt)
             if coef:      # gated rules inside the two GEMMs: the backward's coefficients are stashed in gu's place (ops.gemm_gated_fwd_coef)
                 gu, m = ops.gemm_gated_fwd_coef(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.eps_g, self.eps["lin"], self.act)
             else:
                 gu, m = ops.gemm_gated_fwd(x2, Lw["wgu"], new(("gu", li), M, 2 * I), wide("m", M, I), self.act)
             dn = ops.linear_fwd(m, Lw["wd"], out=new("dn", M, H))
-            pff, st["rstd_pff"] = new("pff", M, H), f32(("rstd_pff", li), M)
-            ops.add_rmsnorm_fwd(dn, None, Lw["ln_pff"], eps, 1.0, y=pff, rstd=st["rstd_pff"])
+            st["rstd_pff"] = f32(("rstd_pff", li), M)
             st.update(qkv=qkv, qr=qr, kr=kr, o=o, lse=lse, gu=gu, coef=coef)
             stash.append(st)
+            if site and li + 1 < len(self.layers):
+                # post-feed-forward norm, residual add and the NEXT layer's input norm in one pass
+                nxt = (new(("h", (li + 1) & 1), M, H), new("x", M, H), f32(("rstd1", li + 1), M))
+                ops.sandwich_norm_fwd(dn, h1, Lw["ln_pff"], self.layers[li + 1]["ln_in"], eps, 1.0, nxt[0], nxt[1], st["rstd_pff"], nxt[2])
+                continue
+            nxt = None
+            pff = new("pff", M, H)
+            ops.add_rmsnorm_fwd(dn, None, Lw["ln_pff"], eps, 1.0, y=pff, rstd=st["rstd_pff"])
             h_prev, branch = h1, pff
         last = torch.arange(B, device=dev) * S + (S - 1)
         h_last = h_prev.index_select(0, last)
@@ -225,7 +245,7 @@ class Gemma3LRP:
         hL_last = new("hL_last", B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h_last, b_last, self.norm, eps, 1.0, hsum_out=hL_last)
         logits = ops.linear_fwd(xn, self.lm_head, out=f32("logits", B, c["vocab"]))
-        return dict(stash=stash, last=last, rstd_f=rstd_f, logits=logits, row_iv=row_iv)
+        return dict(stash=stash, last=last, rstd_f=rstd_f, logits=logits, row_iv=row_iv, site=site)
 
     # ---------------------------------------------------------------------------------------------
     def backward(self, fw, idx, B, S):
@@ -241,23 +261,27 @@ class Gemma3LRP:
         # LM head (gradient of the explained logit) + final (1 + w) norm on the one explained row of each prompt, scattered into [M, H]
         Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new("Gh_last", B, H), 1.0, E["lin"])
         Gs = zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, fw["last"], Gh_last)       # gradient w.r.t. h_L = h1 + pff
+        site, Gdn = fw["site"], None
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
             cos, sin = self.rope[c["layer_types"][li]]
             causal, win, iv = self._attn_mask(li, fw["row_iv"])
             # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
-            Gdn = new("Gdn", M, H)
-            ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
+            if Gdn is None:      # (with the site kernels the layer above has produced Gdn together with Gs)
+                Gdn = new("Gdn", M, H)
+                ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
             if st["coef"]:
                 Agu = ops.gemm_gated_bwd_coef(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I))
             else:
                 Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
             Gx2 = ops.linear_dgrad(Agu, Lw["wgu"], out=new("Gx2", M, H))
-            Gs1 = new("Gs1", M, H)
-            ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1
-            # ---- post-attention norm, o-proj, attention
-            Ga = new("Ga", M, H)
-            ops.rmsnorm_bwd_add2(None, Gs1, Lw["ln_pa"], st["rstd_pa"], None, None, Ga, None, None, 1.0, 0.0, 0.0)
+            Gs1, Ga = new("Gs1", M, H), new("Ga", M, H)
+            if site:      # pre-feed-forward norm + residual (gradient w.r.t. h1) and the post-attention norm in one pass
+                ops.sandwich_norm_bwd(Gs, Gx2, Lw["ln_pf"], st["rstd2"], Lw["ln_pa"], st["rstd_pa"], Gs1, Ga, 1.0)
+            else:
+                ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1
+                # ---- post-attention norm, o-proj, attention
+                ops.rmsnorm_bwd_add2(None, Gs1, Lw["ln_pa"], st["rstd_pa"], None, None, Ga, None, None, 1.0, 0.0, 0.0)
             Gof = ops.linear_dgrad(Ga, Lw["wo"], out=new("Gof", M, nqd))
             Gho, D = new("Gho", M, nqd), f32("D", B, nq, S)
             ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
@@ -271,18 +295,27 @@ class Gemma3LRP:
             ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win, row_iv=iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win,
                              row_iv=iv)
-            dk = ops.gqa_reduce(dk_h, new("dk", M, nkd), M, nk, rep, d)
             Aqkv = new("Aqkv", M, nqkv)
-            ops.gqa_reduce(dv_h, Aqkv[:, nqd + nkd:], M, nk, rep, d)
-            # RoPE backward (a rotation: plain gradient), then the q / k norms' row-constant scale, written into the fused [q | k | v] operand
-            Gqn = ops.rope_bwd(dq, None, None, new("Gqn", M, nqd), cos, sin, S, nq, d, 0.0, 0.0)
-            Gkn = ops.rope_bwd(dk, None, None, new("Gkn", M, nkd), cos, sin, S, nk, d, 0.0, 0.0)
-            ops.head_rmsnorm_bwd(Gqn, Lw["qn"], st["rstd_q"], Aqkv[:, :nqd], nq, d, 1.0)
-            ops.head_rmsnorm_bwd(Gkn, Lw["kn"], st["rstd_k"], Aqkv[:, nqd: nqd + nkd], nk, d, 1.0)
+            if site:      # the group sums, RoPE's backward and the q / k norms' scale in one pass over dq / dk_h / dv_h
+                ops.qkv_bwd_pack(dq, dk_h, dv_h, Lw["qn"], Lw["kn"], st["rstd_q"], st["rstd_k"], cos, sin, Aqkv, S, nq, nk, d, 1.0)
+            else:
+                dk = ops.gqa_reduce(dk_h, new("dk", M, nkd), M, nk, rep, d)
+                ops.gqa_reduce(dv_h, Aqkv[:, nqd + nkd:], M, nk, rep, d)
+                # RoPE backward (a rotation: plain gradient), then the q / k norms' row-constant scale, written into the fused [q | k | v] operand
+                Gqn = ops.rope_bwd(dq, None, None, new("Gqn", M, nqd), cos, sin, S, nq, d, 0.0, 0.0)
+                Gkn = ops.rope_bwd(dk, None, None, new("Gkn", M, nkd), cos, sin, S, nk, d, 0.0, 0.0)
+                ops.head_rmsnorm_bwd(Gqn, Lw["qn"], st["rstd_q"], Aqkv[:, :nqd], nq, d, 1.0)
+                ops.head_rmsnorm_bwd(Gkn, Lw["kn"], st["rstd_k"], Aqkv[:, nqd: nqd + nkd], nk, d, 1.0)
             Gx = ops.linear_dgrad(Aqkv, Lw["wqkv"], out=new("Gx", M, H))
-            # ---- input norm + residual
+            # ---- input norm + residual (and, with the site kernels, the post-feed-forward norm of the layer below)
             Gs = new(("Gs", li & 1), M, H)
-            ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln_in"], st["rstd1"], None, None, Gs, None, None, 1.0, 0.0, 0.0)
+            if site and li > 0:
+                below = fw["stash"][li - 1]
+                Gdn = new("Gdn", M, H)
+                ops.sandwich_norm_bwd(Gs1, Gx, Lw["ln_in"], st["rstd1"], self.layers[li - 1]["ln_pff"], below["rstd_pff"], Gs, Gdn, 1.0)
+            else:
+                Gdn = None
+                ops.rmsnorm_bwd_add2(Gs1, Gx, Lw["ln_in"], st["rstd1"], None, None, Gs, None, None, 1.0, 0.0, 0.0)
         return Gs
 
     # ---------------------------------------------------------------------------------------------

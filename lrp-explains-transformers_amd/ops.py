@@ -681,6 +681,60 @@ def head_rmsnorm_bwd(G, w, rstd, out, heads, d, w_offset=0.0):
     return out
 
 
+SITE_FUSION = True      # module attribute (A/B measurements, tests): False keeps Gemma-3's norms / q-k norm / RoPE on the per-module launch sequences
+
+
+def sandwich_norm_ok(x):
+    """can lrp_sandwich_norm_fwd / _bwd take rows of this width and dtype (the row stays in one workgroup's registers)?"""
+    return bool(SITE_FUSION and x.dtype in _DT and x.dim() == 2 and x.is_contiguous() and lib.lrp_sandwich_norm_ok(x.shape[1], dt(x)))
+
+
+def sandwich_norm_fwd(x, res, w_post, w_pre, eps, w_offset, hsum_out, y, rstd_post, rstd_pre):
+    """hsum_out = res + norm_post(x), y = norm_pre(hsum_out) in one pass (Gemma-3's post-norm / residual add / next pre-norm; y, w_pre may be
+    None): bit-identical to add_rmsnorm_fwd(x, None, w_post) followed by add_rmsnorm_fwd(res, branch, w_pre, hsum_out=...)"""
+    M, H = x.shape
+    same(x, res, hsum_out, y)
+    f32(rstd_post, rstd_pre)
+    w_post = aux(w_post, x, H)
+    w_pre = aux(w_pre, x, H) if w_pre is not None else None
+    check(lib.lrp_sandwich_norm_fwd(p(x), p(res), p(w_post), p(w_pre), p(hsum_out), p(y), p(rstd_post), p(rstd_pre), M, H, eps, w_offset, dt(x),
+                                    stream()), "lrp_sandwich_norm_fwd")
+    return hsum_out, y
+
+
+def sandwich_norm_bwd(Gres, Gx, w_pre, rstd_pre, w_post, rstd_post, Gs_out, Ga_out, w_offset=0.0):
+    """Gs_out = Gres + Gx w_pre' rstd_pre (Gres may be None), Ga_out = Gs_out w_post' rstd_post: the backward of sandwich_norm_fwd's site with both
+    rstd detached = two rmsnorm_bwd_add2 launches"""
+    M, H = Gx.shape
+    same(Gx, Gres, Gs_out, Ga_out)
+    f32(rstd_pre, rstd_post)
+    check(lib.lrp_sandwich_norm_bwd(p(Gres), p(Gx), p(aux(w_pre, Gx, H)), p(rstd_pre), p(aux(w_post, Gx, H)), p(rstd_post), p(Gs_out), p(Ga_out), M, H,
+                                    w_offset, dt(Gx), stream()), "lrp_sandwich_norm_bwd")
+    return Gs_out, Ga_out
+
+
+def qk_norm_rope_fwd(qkv, wq, wk, qr, kr, rstd_q, rstd_k, cos_t, sin_t, seq, nq, nk, d, eps, w_offset=0.0):
+    """per-head q / k RMSNorm + RoPE straight out of the fused projection output qkv [rows, >= (nq + nk) d] into qr [rows, nq d], kr [rows, nk d]
+    (= 2 x head_rmsnorm_fwd + 2 x rope_fwd, bit-identical)"""
+    rows = qkv.shape[0]
+    same(qkv, qr, kr)
+    f32(rstd_q, rstd_k, cos_t, sin_t)
+    check(lib.lrp_qk_norm_rope_fwd(p(qkv), p(aux(wq, qkv, d)), p(aux(wk, qkv, d)), p(qr), p(kr), p(rstd_q), p(rstd_k), p(cos_t), p(sin_t), rows, seq,
+                                   nq, nk, d, qkv.stride(0), qr.stride(0), kr.stride(0), eps, w_offset, dt(qkv), stream()), "lrp_qk_norm_rope_fwd")
+    return qr, kr
+
+
+def qkv_bwd_pack(dq, dk_h, dv_h, wq, wk, rstd_q, rstd_k, cos_t, sin_t, A, seq, nq, nk, d, w_offset=0.0):
+    """A [rows, (nq + 2 nk) d] = [rope^T(dq) wq' rstd_q | rope^T(group sum of dk_h) wk' rstd_k | group sum of dv_h]: the qkv dgrad's operand in one
+    pass (= 2 x gqa_reduce + 2 x rope_bwd + 2 x head_rmsnorm_bwd, bit-identical)"""
+    rows = dq.shape[0]
+    same(dq, dk_h, dv_h, A)
+    f32(rstd_q, rstd_k, cos_t, sin_t)
+    check(lib.lrp_qkv_bwd_pack(p(dq), p(dk_h), p(dv_h), p(aux(wq, dq, d)), p(aux(wk, dq, d)), p(rstd_q), p(rstd_k), p(cos_t), p(sin_t), p(A), rows, seq,
+                               nq, nk, d, dq.stride(0), dk_h.stride(0), dv_h.stride(0), A.stride(0), w_offset, dt(dq), stream()), "lrp_qkv_bwd_pack")
+    return A
+
+
 def head_norm_bwd(g_xn, w, rstd, out, w_offset=0.0):
     """final-norm identity rule on the head rows: out = g_xn * (w + w_offset) * rstd  (g_xn fp32 or model dtype [B,H])"""
     g = g_xn if g_xn.dtype == out.dtype else cast(g_xn, out.dtype)

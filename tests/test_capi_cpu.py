@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     raw = ctypes.CDLL(L.LIB_PATH)
     for name in decls:
         assert hasattr(raw, name), f"{name} declared in lrp_hip.h but not exported"
-    assert L.lib.lrp_version() == 7 and L.lib.lrp_build_arch() == b"gfx950"
+    assert L.lib.lrp_version() == 8 and L.lib.lrp_build_arch() == b"gfx950"
 
 
 def test_argument_validation_without_gpu():

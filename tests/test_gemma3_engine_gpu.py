@@ -150,3 +150,24 @@ def test_gemma3_engine_full_dims_bf16(g3):
         assert float(cos) > 0.99
     print(f"[gemma3 4B dims, 2 layers, S=2048, bf16] fused driver vs fp32 engine {e_eng:.2e} | drop-in path vs fp32 engine {e_hf:.2e}")
     assert e_eng < 5e-2 and e_eng < 3 * e_hf + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemma3_engine_site_kernels_equal_the_per_module_sequence(g3, dtype):
+    """round 6: the post-norm / residual / pre-norm sites, q / k norm + RoPE and the qkv dgrad's operand run as ONE kernel each
+    (csrc/sandwich.hip, ops.SITE_FUSION).  They reproduce the per-module launch sequences rounding for rounding: the engine's explanation is
+    bit-identical with the switch on and off (tiny model: sliding + global layers, several layers so that the layer-boundary site is live)"""
+    import lxt_amd.ops as ops
+    fx = load("gemma3_tiny.npz")
+    ids = torch.as_tensor(fx["ids"]).long()
+    model = build_gemma3(seed=3, attn="eager")
+    eng = g3.Gemma3LRP.from_hf(model, dtype=dtype, max_seq=512)
+    batch = torch.stack([ids, ids.flip(0)])
+    assert ops.SITE_FUSION
+    on = eng.explain(batch, return_G=True)
+    try:
+        ops.SITE_FUSION = False
+        off = eng.explain(batch, target=on["idx"].cpu(), return_G=True)
+    finally:
+        ops.SITE_FUSION = True
+    assert torch.equal(on["logits"], off["logits"]) and torch.equal(on["G_emb"], off["G_emb"]) and torch.equal(on["R_tok"], off["R_tok"])

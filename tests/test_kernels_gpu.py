@@ -748,6 +748,78 @@ def test_head_rmsnorm_fwd_bwd(ops, dtype, heads, d):
     assert float(outb[:, :lead].abs().max()) == 0.0 and float(outb[:, lead + heads * d:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,H,w_off", [(5, 256, 1.0), (131, 2560, 1.0), (67, 4096, 0.0), (9, 1152, 1.0)])
+def test_sandwich_norm_site_kernels_bit_identical(ops, dtype, M, H, w_off):
+    """Gemma-3's post-norm / residual add / next pre-norm as ONE pass (lrp_sandwich_norm_fwd / _bwd; ref HF Gemma3DecoderLayer, identity rules of
+    lxt/efficient/models/gemma3.py:11-19): bit-identical to the two add_rmsnorm_fwd / two rmsnorm_bwd_add2 launches it replaces (which are
+    tested against fp64 above), both weight conventions, rows of 1 / 2 / 4 chunks per thread"""
+    x, res = rnd(M, H, dtype=dtype, seed=1), rnd(M, H, dtype=dtype, seed=2)
+    w1, w2 = rnd(H, dtype=dtype, seed=3) * 0.1, rnd(H, dtype=dtype, seed=4) * 0.1
+    if not ops.sandwich_norm_ok(x):
+        pytest.skip("row too wide for the in-register kernel")
+    e = lambda: torch.empty(M, H, dtype=dtype, device="cuda")      # noqa: E731
+    r = lambda: torch.empty(M, dtype=torch.float32, device="cuda")      # noqa: E731
+    pa, r1 = ops.add_rmsnorm_fwd(x, None, w1, 1e-6, w_off)
+    h_ref, y_ref, r2 = e(), e(), r()
+    ops.add_rmsnorm_fwd(res, pa, w2, 1e-6, w_off, hsum_out=h_ref, y=y_ref, rstd=r2)
+    h1, y, q1, q2 = e(), e(), r(), r()
+    ops.sandwich_norm_fwd(x, res, w1, w2, 1e-6, w_off, h1, y, q1, q2)
+    assert torch.equal(h1, h_ref) and torch.equal(y, y_ref) and torch.equal(q1, r1) and torch.equal(q2, r2)
+    h1b, q1b, q2b = e(), r(), r()
+    ops.sandwich_norm_fwd(x, res, w1, None, 1e-6, w_off, h1b, None, q1b, q2b)                # without the pre-norm output
+    assert torch.equal(h1b, h_ref) and torch.equal(q2b, r2)
+    # backward: Gs = Gres + Gx w_pre' rstd_pre, Ga = Gs w_post' rstd_post
+    Gres, Gx = rnd(M, H, dtype=dtype, seed=5), rnd(M, H, dtype=dtype, seed=6)
+    for gr in (Gres, None):
+        Gs_ref, Ga_ref, Gs, Ga = e(), e(), e(), e()
+        ops.rmsnorm_bwd_add2(gr, Gx, w2, r2, None, None, Gs_ref, None, None, w_off, 0.0, 0.0)
+        ops.rmsnorm_bwd_add2(None, Gs_ref, w1, r1, None, None, Ga_ref, None, None, w_off, 0.0, 0.0)
+        ops.sandwich_norm_bwd(gr, Gx, w2, r2, w1, r1, Gs, Ga, w_off)
+        assert torch.equal(Gs, Gs_ref) and torch.equal(Ga, Ga_ref)
+        gs64 = (f64(gr) if gr is not None else 0.0) + f64(Gx) * (f64(w2) + w_off) * f64(r2)[:, None]
+        assert nmax(Gs, gs64) < TOL[dtype] * 5 and nmax(Ga, gs64 * (f64(w1) + w_off) * f64(r1)[:, None]) < TOL[dtype] * 5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nq,nk,d", [(8, 4, 256), (4, 1, 128), (6, 2, 64)])
+def test_qk_norm_rope_site_kernels_bit_identical(ops, dtype, nq, nk, d):
+    """per-head q / k RMSNorm + RoPE on the fused projection output in one pass, and the qkv dgrad's operand (group sums of dK / dV, RoPE's
+    backward, the norms' scale) in one pass: bit-identical to the 4- and 6-launch sequences of stand-alone kernels (each tested against fp64
+    above); strided rows on both sides"""
+    B, S = 2, 53
+    rows = B * S
+    g = torch.Generator().manual_seed(nq * d)
+    qkv = torch.randn(rows, (nq + 2 * nk) * d + 16, generator=g).to(dtype).cuda()[:, : (nq + 2 * nk) * d]
+    wq, wk = (torch.randn(d, generator=g) * 0.1).to(dtype).cuda(), (torch.randn(d, generator=g) * 0.1).to(dtype).cuda()
+    pos = torch.arange(S, dtype=torch.float64)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+    emb = torch.cat((pos[:, None] * inv, pos[:, None] * inv), -1)
+    cos, sin = emb.cos().float().cuda(), emb.sin().float().cuda()
+    e = lambda n: torch.empty(rows, n, dtype=dtype, device="cuda")      # noqa: E731
+    rq, rk = torch.empty(rows * nq, device="cuda"), torch.empty(rows * nk, device="cuda")
+    qn, kn = e(nq * d), e(nk * d)
+    ops.head_rmsnorm_fwd(qkv[:, : nq * d], wq, qn, rq, nq, d, 1e-6, 1.0)
+    ops.head_rmsnorm_fwd(qkv[:, nq * d: (nq + nk) * d], wk, kn, rk, nk, d, 1e-6, 1.0)
+    qr_ref, kr_ref = ops.rope_fwd(qn, e(nq * d), cos, sin, S, nq, d), ops.rope_fwd(kn, e(nk * d), cos, sin, S, nk, d)
+    rq2, rk2 = torch.empty_like(rq), torch.empty_like(rk)
+    qr, kr = ops.qk_norm_rope_fwd(qkv, wq, wk, e(nq * d), e(nk * d), rq2, rk2, cos, sin, S, nq, nk, d, 1e-6, 1.0)
+    assert torch.equal(qr, qr_ref) and torch.equal(kr, kr_ref) and torch.equal(rq, rq2) and torch.equal(rk, rk2)
+    # backward
+    rep = nq // nk
+    dq, dk_h, dv_h = (torch.randn(rows, nq * d, generator=g).to(dtype).cuda() for _ in range(3))
+    A_ref = torch.zeros(rows, (nq + 2 * nk) * d + 8, dtype=dtype, device="cuda")[:, : (nq + 2 * nk) * d]
+    dk = ops.gqa_reduce(dk_h, e(nk * d), rows, nk, rep, d)
+    ops.gqa_reduce(dv_h, A_ref[:, (nq + nk) * d:], rows, nk, rep, d)
+    Gqn = ops.rope_bwd(dq, None, None, e(nq * d), cos, sin, S, nq, d, 0.0, 0.0)
+    Gkn = ops.rope_bwd(dk, None, None, e(nk * d), cos, sin, S, nk, d, 0.0, 0.0)
+    ops.head_rmsnorm_bwd(Gqn, wq, rq, A_ref[:, : nq * d], nq, d, 1.0)
+    ops.head_rmsnorm_bwd(Gkn, wk, rk, A_ref[:, nq * d: (nq + nk) * d], nk, d, 1.0)
+    A = torch.zeros(rows, (nq + 2 * nk) * d + 8, dtype=dtype, device="cuda")[:, : (nq + 2 * nk) * d]
+    ops.qkv_bwd_pack(dq, dk_h, dv_h, wq, wk, rq, rk, cos, sin, A, S, nq, nk, d, 1.0)
+    assert torch.equal(A, A_ref)
+
+
 def test_readout_argmax_headseed(ops):
     e, G = rnd(50, 264, seed=1), rnd(50, 264, seed=2)
     assert nmax(ops.readout(e, G), (f64(e) * f64(G)).sum(-1)) < 1e-5
