@@ -35,6 +35,14 @@ template <typename T> LRP_DEVICE float norm_scale(float x, float rs, float w, fl
     return (w_off == 0.f) ? w * to_f32(from_f32<T>(x * rs)) : (x * rs) * (w_off + w);
 }
 template <typename T> LRP_DEVICE float rnd(float x) { return to_f32(from_f32<T>(x)); }
+// W consecutive fp32 table entries as 16-byte loads (tables [seq, d] fp32, column a multiple of W = 4 or 8, base 16-byte aligned: checked by the host)
+template <int W> LRP_DEVICE void load_tab(float (&t)[W], const float* p) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        t[4 * q] = v[0]; t[4 * q + 1] = v[1]; t[4 * q + 2] = v[2]; t[4 * q + 3] = v[3];
+    }
+}
 
 // hsum = res + T(w_post' (*) x rstd(x));  y = w_pre' (*) hsum rstd(hsum).  One workgroup per row, the row stays in registers (CH chunks per thread)
 template <typename T, int W, int CH>
@@ -149,8 +157,9 @@ __global__ void qk_norm_rope_fwd_kernel(const T* __restrict__ qkv, const T* __re
             else rstd_k[row * nk + (h - nq)] = rs;
         }
         const int pos = (int)(row % seq);
-        const float* pc = cs + (int64_t)pos * d + lg * W;
-        const float* ps = sn + (int64_t)pos * d + lg * W;
+        float pc[W], ps[W];
+        load_tab<W>(pc, cs + (int64_t)pos * d + lg * W);
+        load_tab<W>(ps, sn + (int64_t)pos * d + lg * W);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const float n = rnd<T>(norm_scale<T>(a.v[k], rs, ww.v[k], w_off));
@@ -204,8 +213,9 @@ __global__ void qkv_bwd_pack_kernel(const T* __restrict__ dq, const T* __restric
             rs = rstd_k[row * nk + hk];
         }
         const int pos = (int)(row % seq);
-        const float* pc = cs + (int64_t)pos * d + lg * W;
-        const float* ps = sn + (int64_t)pos * d + (first ? lg * W + hd : lg * W - hd);       // the PARTNER's sine
+        float pc[W], ps[W];
+        load_tab<W>(pc, cs + (int64_t)pos * d + lg * W);
+        load_tab<W>(ps, sn + (int64_t)pos * d + (first ? lg * W + hd : lg * W - hd));       // the PARTNER's sine
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const float q = __shfl_xor(p.v[k], lpg >> 1, 64);

@@ -84,10 +84,14 @@ def weights_from_hf(model):
 class Gemma3LRP:
     """explain(input_ids) -> dict(idx, logit, R_tok, logits): AttnLRP (lxt.efficient) token relevances of a Gemma-3 text decoder"""
 
-    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", max_seq=4096):
+    def __init__(self, cfg, W, dtype=torch.bfloat16, device="cuda", max_seq=4096, sparse_top=True):
         if not torch.cuda.is_available():
             raise RuntimeError("Gemma3LRP needs a HIP device: the LRP kernels have no CPU fallback")
         self.cfg, self.dtype, self.device = dict(cfg), dtype, torch.device(device)
+        # top-layer sparsity (as LlamaLRP): only the explained position's logit is used, so above the last layer's attention every row but one
+        # per prompt is dead in the forward and carries zero gradient in the backward -- its o-projection, norms and MLP run on B rows instead
+        # of B S, its attention on one query row per prompt (result-preserving: test_gemma3_engine_top_layer_sparsity_equals_dense)
+        self.sparse_top = bool(sparse_top)
         self.eps, self.act = dict(EFFICIENT), cfg["act"]
         self.eps_g = self.eps["act"]
         dev = self.device
@@ -210,6 +214,22 @@ class Gemma3LRP:
             v_t = ops.transpose_heads(v, B, S, nk, d) if self.attn_t else None
             o, lse = new(("o", li), M, nqd), f32(("lse", li), B, nq, S)
             causal, win, iv = self._attn_mask(li, row_iv)
+            if self.sparse_top and li == len(self.layers) - 1:
+                # ---- the top layer above its attention: one row per prompt
+                ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], causal, win, q_begin=S - 1, row_iv=iv)
+                last = torch.arange(B, device=dev) * S + (S - 1)
+                o_l, h_l = o.index_select(0, last), h.index_select(0, last)
+                a_l = ops.linear_fwd(o_l, Lw["wo"], out=new("a_l", B, H))
+                pa_l, rstd_pa_l = ops.add_rmsnorm_fwd(a_l, None, Lw["ln_pa"], eps, 1.0)
+                h1_l = new("h1_l", B, H)
+                x2_l, rstd2_l = ops.add_rmsnorm_fwd(h_l, pa_l, Lw["ln_pf"], eps, 1.0, hsum_out=h1_l)
+                gu_l, m_l = ops.gemm_gated_fwd(x2_l, Lw["wgu"], new("gu_l", B, 2 * I), new("m_l", B, I), self.act)
+                dn_l = ops.linear_fwd(m_l, Lw["wd"], out=new("dn_l", B, H))
+                pff_l, rstd_pff_l = ops.add_rmsnorm_fwd(dn_l, None, Lw["ln_pff"], eps, 1.0)
+                st.update(top=True, qkv=qkv, qr=qr, kr=kr, lse=lse, o_l=o_l, gu_l=gu_l, rstd_pa_l=rstd_pa_l, rstd2_l=rstd2_l, rstd_pff_l=rstd_pff_l)
+                stash.append(st)
+                h_prev, branch = h1_l, pff_l
+                break
             ops.attn_fwd(qr, kr, v, v_t, o, lse, B, S, nq, nk, d, c["scale"], causal, win, row_iv=iv)
             a = ops.linear_fwd(o, Lw["wo"], out=new("a", M, H))
             # post-attention norm, residual add, pre-feed-forward norm
@@ -240,8 +260,11 @@ class Gemma3LRP:
             ops.add_rmsnorm_fwd(dn, None, Lw["ln_pff"], eps, 1.0, y=pff, rstd=st["rstd_pff"])
             h_prev, branch = h1, pff
         last = torch.arange(B, device=dev) * S + (S - 1)
-        h_last = h_prev.index_select(0, last)
-        b_last = branch.index_select(0, last) if branch is not None else None
+        if h_prev.shape[0] == B and stash and stash[-1].get("top", False):
+            h_last, b_last = h_prev, branch                        # (the sparse top layer left one row per prompt already)
+        else:
+            h_last = h_prev.index_select(0, last)
+            b_last = branch.index_select(0, last) if branch is not None else None
         hL_last = new("hL_last", B, H)
         xn, rstd_f = ops.add_rmsnorm_fwd(h_last, b_last, self.norm, eps, 1.0, hsum_out=hL_last)
         logits = ops.linear_fwd(xn, self.lm_head, out=f32("logits", B, c["vocab"]))
@@ -260,41 +283,63 @@ class Gemma3LRP:
         zeros = lambda tag, *s: ar.get(tag, s, dt, zero=True)  # noqa: E731
         # LM head (gradient of the explained logit) + final (1 + w) norm on the one explained row of each prompt, scattered into [M, H]
         Gh_last = ops.head_seed(self.lm_head, fw["logits"], idx, self.norm, fw["rstd_f"], new("Gh_last", B, H), 1.0, E["lin"])
-        Gs = zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, fw["last"], Gh_last)       # gradient w.r.t. h_L = h1 + pff
+        top = bool(fw["stash"]) and fw["stash"][-1].get("top", False)
+        Gs = None if top else zeros(("Gs", len(self.layers) & 1), M, H).index_copy_(0, fw["last"], Gh_last)       # gradient w.r.t. h_L = h1 + pff
         site, Gdn = fw["site"], None
         for li in range(len(self.layers) - 1, -1, -1):
             Lw, st = self.layers[li], fw["stash"][li]
             cos, sin = self.rope[c["layer_types"][li]]
             causal, win, iv = self._attn_mask(li, fw["row_iv"])
-            # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
-            if Gdn is None:      # (with the site kernels the layer above has produced Gdn together with Gs)
-                Gdn = new("Gdn", M, H)
-                ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
-            if st["coef"]:
-                Agu = ops.gemm_gated_bwd_coef(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I))
+            q_begin = 0
+            if st.get("top", False):
+                # ---- one row per prompt through the post-feed-forward norm, the MLP, the two norms around the residual add and the o-projection; then
+                # scatter into the dense operands of the attention backward (zero fill + row scatter; D's live column S - 1 is a strided scatter)
+                Gdn_l, Gs1_l, Ga_l = new("Gdn_l", B, H), new("Gs1_l", B, H), new("Ga_l", B, H)
+                ops.rmsnorm_bwd_add2(None, Gh_last, Lw["ln_pff"], st["rstd_pff_l"], None, None, Gdn_l, None, None, 1.0, 0.0, 0.0)
+                Agu_l = ops.gemm_gated_bwd(Gdn_l, Lw["wd"], st["gu_l"], new("Agu_l", B, 2 * I), self.eps_g, E["lin"], self.act)
+                Gx2_l = ops.linear_dgrad(Agu_l, Lw["wgu"], out=new("Gx2_l", B, H))
+                ops.rmsnorm_bwd_add2(Gh_last, Gx2_l, Lw["ln_pf"], st["rstd2_l"], None, None, Gs1_l, None, None, 1.0, 0.0, 0.0)
+                ops.rmsnorm_bwd_add2(None, Gs1_l, Lw["ln_pa"], st["rstd_pa_l"], None, None, Ga_l, None, None, 1.0, 0.0, 0.0)
+                Gof_l = ops.linear_dgrad(Ga_l, Lw["wo"], out=new("Gof_l", B, nqd))
+                Gho_l, D_l = new("Gho_l", B, nqd), f32("D_l", B, nq, 1)
+                ops.attn_bwd_prep(Gof_l, st["o_l"], Gho_l, D_l, B, 1, nq, d, E["pv"], 0.5)
+                Gho = zeros("Gho", M, nqd).index_copy_(0, fw["last"], Gho_l)
+                D = ar.get("D", (B, nq, S), torch.float32, zero=True)
+                D.view(B * nq, S)[:, S - 1].copy_(D_l.view(B * nq))
+                Gs1 = zeros("Gs1", M, H).index_copy_(0, fw["last"], Gs1_l)
+                q_begin = S - 1
             else:
-                Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
-            Gx2 = ops.linear_dgrad(Agu, Lw["wgu"], out=new("Gx2", M, H))
-            Gs1, Ga = new("Gs1", M, H), new("Ga", M, H)
-            if site:      # pre-feed-forward norm + residual (gradient w.r.t. h1) and the post-attention norm in one pass
-                ops.sandwich_norm_bwd(Gs, Gx2, Lw["ln_pf"], st["rstd2"], Lw["ln_pa"], st["rstd_pa"], Gs1, Ga, 1.0)
-            else:
-                ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1
-                # ---- post-attention norm, o-proj, attention
-                ops.rmsnorm_bwd_add2(None, Gs1, Lw["ln_pa"], st["rstd_pa"], None, None, Ga, None, None, 1.0, 0.0, 0.0)
-            Gof = ops.linear_dgrad(Ga, Lw["wo"], out=new("Gof", M, nqd))
-            Gho, D = new("Gho", M, nqd), f32("D", B, nq, S)
-            ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
+                # ---- post-feed-forward norm, gated MLP, pre-feed-forward norm + residual
+                if Gdn is None:      # (with the site kernels the layer above has produced Gdn together with Gs)
+                    Gdn = new("Gdn", M, H)
+                    ops.rmsnorm_bwd_add2(None, Gs, Lw["ln_pff"], st["rstd_pff"], None, None, Gdn, None, None, 1.0, 0.0, 0.0)
+                if st["coef"]:
+                    Agu = ops.gemm_gated_bwd_coef(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I))
+                else:
+                    Agu = ops.gemm_gated_bwd(Gdn, Lw["wd"], st["gu"], wide("Agu", M, 2 * I), self.eps_g, E["lin"], self.act)
+                Gx2 = ops.linear_dgrad(Agu, Lw["wgu"], out=new("Gx2", M, H))
+                Gs1, Ga = new("Gs1", M, H), new("Ga", M, H)
+                if site:      # pre-feed-forward norm + residual (gradient w.r.t. h1) and the post-attention norm in one pass
+                    ops.sandwich_norm_bwd(Gs, Gx2, Lw["ln_pf"], st["rstd2"], Lw["ln_pa"], st["rstd_pa"], Gs1, Ga, 1.0)
+                else:
+                    ops.rmsnorm_bwd_add2(Gs, Gx2, Lw["ln_pf"], st["rstd2"], None, None, Gs1, None, None, 1.0, 0.0, 0.0)     # w.r.t. h1
+                    # ---- post-attention norm, o-proj, attention
+                    ops.rmsnorm_bwd_add2(None, Gs1, Lw["ln_pa"], st["rstd_pa"], None, None, Ga, None, None, 1.0, 0.0, 0.0)
+                Gof = ops.linear_dgrad(Ga, Lw["wo"], out=new("Gof", M, nqd))
+                Gho, D = new("Gho", M, nqd), f32("D", B, nq, S)
+                ops.attn_bwd_prep(Gof, st["o"], Gho, D, B, S, nq, d, E["pv"], 0.5)
             q, k, v = st["qr"], st["kr"], st["qkv"][:, nqd + nkd:]
             k_t = q_t = Gho_t = None
             if self.attn_t:
                 k_t = ops.transpose_heads(k, B, S, nk, d)
                 q_t = ops.transpose_heads(q, B, S, nq, d)
                 Gho_t = ops.transpose_heads(Gho, B, S, nq, d)
-            dq, dk_h, dv_h = new("dq", M, nqd), new("dk_h", M, nqd), new("dv_h", M, nqd)
-            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win, row_iv=iv)
+            dq = new("dq", M, nqd) if q_begin == 0 else zeros("dq", M, nqd)          # (queries below q_begin carry no relevance: rows stay zero)
+            dk_h, dv_h = new("dk_h", M, nqd), new("dv_h", M, nqd)
+            ops.attn_bwd_dq(q, k, v, k_t, Gho, st["lse"], D, dq, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win, q_begin=q_begin,
+                            row_iv=iv)
             ops.attn_bwd_dkv(q, k, v, q_t, Gho, Gho_t, st["lse"], D, dk_h, dv_h, B, S, nq, nk, d, c["scale"], E["mask"], E["qk"], causal, win,
-                             row_iv=iv)
+                             q_begin=q_begin, row_iv=iv)
             Aqkv = new("Aqkv", M, nqkv)
             if site:      # the group sums, RoPE's backward and the q / k norms' scale in one pass over dq / dk_h / dv_h
                 ops.qkv_bwd_pack(dq, dk_h, dv_h, Lw["qn"], Lw["kn"], st["rstd_q"], st["rstd_k"], cos, sin, Aqkv, S, nq, nk, d, 1.0)

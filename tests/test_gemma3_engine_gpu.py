@@ -171,3 +171,28 @@ def test_gemma3_engine_site_kernels_equal_the_per_module_sequence(g3, dtype):
     finally:
         ops.SITE_FUSION = True
     assert torch.equal(on["logits"], off["logits"]) and torch.equal(on["G_emb"], off["G_emb"]) and torch.equal(on["R_tok"], off["R_tok"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemma3_engine_top_layer_sparsity_equals_dense(g3, dtype):
+    """round 6 (as LlamaLRP since round 3): above the last layer's attention only the explained row of each prompt is live -- o-projection, the
+    four norms and the MLP of that layer run on B rows, its attention on one query row per prompt (q_begin), in the forward and in the backward.
+    Result-preserving: fp32 within 1e-5 of the dense evaluation (batch of two, ragged left-padded batch), bf16 within its rounding noise"""
+    fx = load("gemma3_tiny.npz")
+    ids = torch.as_tensor(fx["ids"]).long()
+    model = build_gemma3(seed=3, attn="eager")
+    dense = g3.Gemma3LRP.from_hf(model, dtype=dtype, max_seq=512, sparse_top=False)
+    sparse = g3.Gemma3LRP.from_hf(model, dtype=dtype, max_seq=512, sparse_top=True)
+    batch = torch.stack([ids, ids.flip(0)])
+    a, b = dense.explain(batch, return_G=True), sparse.explain(batch, return_G=True)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert torch.equal(a["idx"], b["idx"]) and nmax(b["logits"], a["logits"]) < tol
+    assert nmax(b["R_tok"], a["R_tok"]) < tol and nmax(b["G_emb"], a["G_emb"]) < tol
+    S, lens = ids.numel(), (ids.numel(), 61, 17)
+    pad = torch.zeros(3, S, dtype=torch.long)
+    for r, L in enumerate(lens):
+        pad[r, S - L:] = ids[:L]
+    a, b = dense.explain(pad, lengths=list(lens)), sparse.explain(pad, lengths=list(lens), target=None)
+    assert torch.equal(a["idx"], b["idx"]) and nmax(b["R_tok"], a["R_tok"]) < tol
+    for r, L in enumerate(lens):
+        assert float(b["R_tok"][r, : S - L].abs().max()) == 0.0 if L < S else True
