@@ -263,19 +263,23 @@ class Gemma3MMLRP:
             raise NotImplementedError("Gemma3MMLRP.explain: padded image + text batches are not supported (every prompt must fill the batch's sequence length)")
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
             raise NotImplementedError("Gemma3MMLRP.explain: padded image + text batches are not supported (attention_mask has masked positions)")
-        is_img = ids == self.image_token_id
-        tt = is_img if token_type_ids is None else torch.as_tensor(token_type_ids).to(dev).bool()
-        rows = is_img.reshape(-1).nonzero()[:, 0]                                # flat positions of the image tokens, in order
+        # the prompt's bookkeeping (image positions, per-row key intervals) is HOST work on the host copy of the ids: with ids handed over on the CPU
+        # (the usual tokenizer output) explain() contains no device -> host round trip ahead of the launches -- three of them (nonzero, any, the
+        # interval builder's .cpu()) used to drain the queue at the top of every call, and the tower's many short kernels then ran behind the host
+        ids_h = input_ids if input_ids.device.type == "cpu" else input_ids.cpu()
+        is_img_h = ids_h == self.image_token_id
+        tt_h = is_img_h if token_type_ids is None else torch.as_tensor(token_type_ids).cpu().bool()
+        rows_h = is_img_h.reshape(-1).nonzero()[:, 0]                            # flat positions of the image tokens, in order
         n_img = pixel_values.shape[0]
-        if rows.numel() != n_img * vi.T:
-            raise ValueError(f"{rows.numel()} image tokens in input_ids for {n_img} images of {vi.T} tokens each")
+        if rows_h.numel() != n_img * vi.T:
+            raise ValueError(f"{rows_h.numel()} image tokens in input_ids for {n_img} images of {vi.T} tokens each")
+        iv_h = mm_row_intervals(tt_h, tx.cfg["window"]) if bool(tt_h.any()) else None
+        rows, is_img = rows_h.to(dev), is_img_h.to(dev)
         fv = vi.forward(pixel_values)
         safe = torch.where(is_img, torch.zeros_like(ids), ids) if self.image_token_id >= tx.cfg["vocab"] else ids
         emb = tx.embed.index_select(0, safe.reshape(-1)) * tx.embed_scale.to(dev)
         emb.index_copy_(0, rows, fv["feat"].to(emb.dtype))                       # HF: inputs_embeds.masked_scatter(image mask, image features)
-        iv = None
-        if bool(tt.any()):
-            iv = {k: (lo.to(dev), hi.to(dev)) for k, (lo, hi) in mm_row_intervals(tt, tx.cfg["window"]).items()}
+        iv = None if iv_h is None else {k: (lo.to(dev), hi.to(dev)) for k, (lo, hi) in iv_h.items()}
         fw = tx.forward(emb, B, S, iv)
         if target is None:
             idx, _ = ops.argmax_rows(fw["logits"])
