@@ -52,12 +52,23 @@ def _collectives_off():
     return not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not SINGLE_RANK_COLLECTIVES)
 
 
+BCAST_CHUNK = 1 << 30     # elements per broadcast call (module attribute: tests lower it)
+
+
 def broadcast_weights(tensors, src=0):
     """in-place broadcast of a list of (already allocated) tensors from rank `src`"""
     if _collectives_off():
         return
     for t in tensors:
-        dist.broadcast(t, src=src)
+        if t.is_contiguous() and t.numel() > BCAST_CHUNK:
+            # pieces of <= 2^30 elements (2 GiB of bf16): the flat weight buffer of an 8B model is 8.0e9 elements -- beyond INT32_MAX, and this path
+            # has never run on more than one rank (no multi-GPU box was available in any round); eight 2-GiB broadcasts cost nothing against one
+            # 16-GiB one (per-link bound either way) and keep every count a collective library has been exercised with
+            flat = t.view(-1)
+            for i in range(0, flat.numel(), BCAST_CHUNK):
+                dist.broadcast(flat[i: i + BCAST_CHUNK], src=src)
+        else:
+            dist.broadcast(t, src=src)
 
 
 _CK_MOD = (1 << 61) - 1

@@ -27,6 +27,11 @@ WORKER = textwrap.dedent("""
     w = [torch.full((5, 3), float(rank + 1)), torch.arange(4.0) * (rank + 1)]
     D.broadcast_weights(w, src=0)
     assert torch.equal(w[0], torch.full((5, 3), 1.0)) and torch.equal(w[1], torch.arange(4.0))
+    D.BCAST_CHUNK = 5                                             # the chunked form (flat buffers beyond 2^30 elements): 17 elements in pieces of 5
+    big = [torch.arange(17.0).view(17) * (rank + 1), torch.full((2, 3), float(rank))]
+    D.broadcast_weights(big, src=0)
+    assert torch.equal(big[0], torch.arange(17.0)) and torch.equal(big[1], torch.zeros(2, 3))
+    D.BCAST_CHUNK = 1 << 30
     lo, hi = D.shard_range(7, rank, world)
     assert (lo, hi) == ({2: [(0, 4), (4, 7)], 4: [(0, 2), (2, 4), (4, 6), (6, 7)]}[world][rank])
     # replica self-check: equal replicas pass; a replica whose words arrived in another ORDER (same multiset: the round-4 plain sum could not
