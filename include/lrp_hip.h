@@ -42,7 +42,7 @@ extern "C" {
 #define LRP_ACT_TANH 3       /* BERT pooler (identity rule on nn.Tanh, ref: lxt/explicit/models/bert.py:60-65) */
 
 /* library identity / sanity */
-int lrp_version(void);                 /* ABI version, currently 8 (round 6, second step: + the Gemma-3 site kernels lrp_sandwich_norm_fwd / _bwd / _ok, lrp_qk_norm_rope_fwd, lrp_qkv_bwd_pack; nothing else changed).  Version 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
+int lrp_version(void);                 /* ABI version, currently 8 (round 6, second step: + the Gemma-3 site kernels lrp_sandwich_norm_fwd / _bwd / _ok, lrp_qk_norm_rope_fwd, lrp_qkv_bwd_pack; - the pair entries lrp_gemm_gated_fwd / _bwd / _bwd_ws, which the host never called).  Version 7 (round 6: the fused gated-MLP GEMMs stash the backward's COEFFICIENTS -- lrp_gemm_gated_coef_ok / _fwd_coef / _bwd_coef, and RoPE rides in the QKV forward's epilogue -- lrp_gemm_nt_rs_rope[_ok]; lrp_gemm_gated_fwd / _bwd are the GEMM + element-wise pair only; lrp_gemm_gated_fwd_rs (now the rs argument of _fwd_coef) and the de-phased tile walk -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, measured negative in round 5 -- are GONE: the library holds no mutable state again).  Version 6 (round 5) added the K1n family -- lrp_gemm_norm_fused_ok, lrp_gemm_res_ssq, lrp_rms_rstd, lrp_gemm_nt_rs, lrp_gemm_nn_rs, lrp_gemm_gated_fwd_rs, lrp_gemm_nn_rs_res -- lrp_set_gemm_scratch / lrp_gemm_scratch_bytes, lrp_attn_bwd_dq_d[_ok], lrp_gqa_reduce_rope and lrp_linear_stream_fwd_tk / _splits / _ws / _tickets; version 5 added lrp_linear_stream_dgrad_tk / _tickets; version 4: (round 4 added lrp_linear_stream_fwd / _ok, lrp_linear_stream_dgrad / _ok / _ws, lrp_act_grad, lrp_layernorm_bwd_plain; nothing else changed).  Version 3: the one-pass lrp_linear_eps_smallm[_ws] of version 2 is gone (superseded by
                                           lrp_linear_smallm_fwd / _dgrad and lrp_gemm_skinny), lrp_gemm_skinny accepts any row count;
                                           added lrp_head_rmsnorm_fwd / _bwd, lrp_gemm_nn, lrp_gemm_skinny[_ws|_splits], lrp_gemm_gated_fwd / _bwd[_ws], lrp_gated_act_*_il.
                                           Every other version-2 signature is unchanged. */
@@ -250,19 +250,15 @@ int lrp_gated_act_bwd(const void* Gm, const void* g, const void* u, void* Ag, vo
 /* The same two rules on the INTERLEAVED output of a fused gate/up Linear (the engine's layout: the rows of the fused weight [2 I, H] are
  * ordered in blocks of 64 = [gate rows 32 b .. 32 b + 31 | up rows 32 b .. 32 b + 31], so one 64-column block of gu = W_gu x holds gate AND up
  * of the same 32 intermediate indices -- and so does one wave's accumulator tile of the GEMM):
- *   lrp_gated_act_fwd_il / _bwd_il : the element-wise kernels on gu / Agu [M, 2 I] in that layout
- *   lrp_gemm_gated_fwd / _bwd      : the Linear + the element-wise kernel one after the other (gu = x W_gu^T stored; Gm = A_dn W_dn in `ws`,
- *                                    lrp_gemm_gated_bwd_ws() bytes) -- small M, shapes the fused form below refuses
+ *   lrp_gated_act_fwd_il / _bwd_il : the element-wise kernels on gu / Agu [M, 2 I] in that layout (small M, fp32, shapes the fused form below
+ *                                    refuses: the caller runs them behind the Linear entry that fits its row count -- lrp_linear_stream_fwd,
+ *                                    lrp_gemm_skinny, lrp_gemm_nt / _nn; the pair entries lrp_gemm_gated_fwd / _bwd[_ws] of ABI 3-7, which hard-wired
+ *                                    the large-M GEMM, are gone in ABI 8: the host never called them)
  * ref: lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281. */
 #define LRP_GATED_IL 32
 int lrp_gated_act_fwd_il(const void* gu, void* m, int M, int I, int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
 int lrp_gated_act_bwd_il(const void* Gm, const void* gu, void* Agu, int M, int I, int64_t ldgm, int64_t ldgu, int64_t ldagu,
                          float eps_g, float eps_lin, int act, int dtype, void* stream);
-int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
-                       int64_t ldgu, int64_t ldm, int act, int dtype, void* stream);
-int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype);
-int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda, int64_t ldw,
-                       int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws, void* stream);
 /* FUSED form, M = B S rows (round 6): the rules run in the epilogues of the two GEMMs around them and the forward stashes the backward's
  * COEFFICIENTS instead of g and u.  The gate/up GEMM has g and u of an intermediate index in fp32 registers; it evaluates the activation once
  * and writes   m  = act(g) u,

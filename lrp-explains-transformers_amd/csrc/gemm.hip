@@ -566,35 +566,6 @@ bool gated_fused_ok(int M, int Ncols, int K, int I, int64_t lda, int64_t ldb, in
 }
 }  // namespace
 
-// the GEMM + element-wise pair on the stored gate/up output gu (small M, fp32, shapes the fused form refuses)
-extern "C" int lrp_gemm_gated_fwd(const void* x, const void* Wgu, void* gu, void* m, int M, int I, int K, int64_t ldx, int64_t ldw,
-                                  int64_t ldgu, int64_t ldm, int act, int dtype, void* stream) {
-    if (!x || !Wgu || !gu || !m || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
-    if (M == 0 || I == 0) return LRP_OK;
-    if (I % LRP_GATED_IL) return LRP_ESHAPE;
-    const int rc = lrp_gemm_nt(x, Wgu, gu, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 1, 0, 0, 0, dtype, dtype, stream);
-    if (rc != LRP_OK) return rc;
-    return lrp_gated_act_fwd_il(gu, m, M, I, ldgu, ldm, act, dtype, stream);
-}
-
-extern "C" int64_t lrp_gemm_gated_bwd_ws(int M, int I, int K, int64_t lda, int64_t ldw, int act, int dtype) {
-    if (dtype != LRP_BF16 || M <= 0 || I <= 0) return 0;
-    return (int64_t)M * I * 2;                                              // Gm [M, I]
-}
-
-extern "C" int lrp_gemm_gated_bwd(const void* Adn, const void* Wdn, const void* gu, void* Agu, int M, int I, int K, int64_t lda,
-                                  int64_t ldw, int64_t ldgu, int64_t ldagu, float eps_g, float eps_lin, int act, int dtype, void* ws,
-                                  void* stream) {
-    if (!Adn || !Wdn || !gu || !Agu || M < 0 || I < 0 || K < 0 || act < 0 || act > 3) return LRP_EINVAL;
-    if (M == 0 || I == 0) return LRP_OK;
-    if (dtype != LRP_BF16 || (I % LRP_GATED_IL)) return LRP_ESHAPE;
-    if ((lda % 8) || (ldw % 8) || (reinterpret_cast<uintptr_t>(Adn) & 15) || (reinterpret_cast<uintptr_t>(Wdn) & 15)) return LRP_EALIGN;
-    if (!ws) return LRP_EINVAL;
-    const int rc = lrp_gemm_nn(Adn, Wdn, ws, nullptr, M, I, K, lda, ldw, I, dtype, dtype, stream);
-    if (rc != LRP_OK) return rc;
-    return lrp_gated_act_bwd_il(ws, gu, Agu, M, I, I, ldgu, ldagu, eps_g, eps_lin, act, dtype, stream);
-}
-
 // ---- round 6: the fused form stashes the backward's COEFFICIENTS (include/lrp_hip.h).  Both launches of a layer must be problems the
 // ping-pong kernel's fused epilogues take: the gate/up forward [M, 2 I] over K = hidden (NT) and the down-projection dgrad [M, I] over hidden (NN)
 extern "C" int lrp_gemm_gated_coef_ok(int M, int I, int H, int64_t ldx, int64_t ldwgu, int64_t lda, int64_t ldwd, int act, int dtype) {

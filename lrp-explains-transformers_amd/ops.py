@@ -416,7 +416,7 @@ GATED_IL = 32            # interleave block of a fused gate/up weight (include/l
 
 def interleave_gate_up(wg, wu, out=None):
     """fused gate/up weight [2 I, H] with its rows in blocks of 64 = [32 gate rows | 32 up rows]: one 64-column block of W_gu x -- and one
-    wave's accumulator tile of the GEMM -- then holds gate AND up of the same 32 intermediate indices (lrp_gemm_gated_fwd / _bwd)"""
+    wave's accumulator tile of the GEMM -- then holds gate AND up of the same 32 intermediate indices (lrp_gated_act_fwd_il / _bwd_il, lrp_gemm_gated_fwd_coef / _bwd_coef)"""
     I, H = wg.shape
     if I % GATED_IL:
         raise ValueError(f"intermediate size {I} is not a multiple of {GATED_IL}")

@@ -329,7 +329,7 @@ def _act64(x, act):
 
 @pytest.mark.parametrize("M,I,K,act", [(300, 512, 128, "silu"), (40, 64, 256, "silu"), (520, 1024, 256, "gelu_tanh")])
 def test_gemm_gated_pair(ops, M, I, K, act):
-    """lrp_gemm_gated_fwd / _bwd: the gate/up Linear + the element-wise gated-MLP rule kernels on the STORED gate/up output (small M; ref
+    """ops.gemm_gated_fwd / _bwd: the gate/up Linear + the element-wise gated-MLP rule kernels (lrp_gated_act_fwd_il / _bwd_il) on the STORED gate/up output (small M; ref
     lxt/efficient/patches.py:145-157, lxt/explicit/models/llama.py:84-86,273-281), interleaved layout (ops.interleave_gate_up), vs fp64."""
     g_ = torch.Generator().manual_seed(M + I)
     bf = torch.bfloat16
