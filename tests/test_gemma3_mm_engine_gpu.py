@@ -41,6 +41,11 @@ def test_gemma3_mm_engine_fp32_vs_reference_fixture(mm, impl):
     assert max(errs) < 1e-4
     # the word embeddings at image positions were replaced by the image features: exactly zero relevance there
     assert float(Rt[tt[0].bool().cuda()].abs().max()) == 0.0
+    # ids / token types handed over on the DEVICE (the bookkeeping then takes its one host copy) and the image mask derived from the ids alone:
+    # the same explanation, bit for bit
+    out_d = eng.explain(ids.cuda(), pv.cuda(), token_type_ids=tt.cuda())
+    out_i = eng.explain(ids, pv)
+    assert torch.equal(out_d["R_tok"], out["R_tok"]) and torch.equal(out_d["R_pix"], out["R_pix"]) and torch.equal(out_i["R_tok"], out["R_tok"])
 
 
 @pytest.mark.parametrize("impl", ["sdpa", "eager"])
